@@ -1,0 +1,178 @@
+"""ORACLE tooling — generate golden vectors by running the REAL reference (imported from
+/root/reference, build container only) and store inputs + the reference's outputs under
+tests/golden/*.npz.  Re-run:  python -m oracle.make_golden  (from the repo root).
+
+Weights are not stored: they are re-created from `ssr_speech_amd.weights` (name/seed hash), the
+fixture holds the seed.  Every fixture records torch.__version__ (the reference pins no torch
+version).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import  # noqa: E402
+import ssr_speech_amd  # noqa: E402,F401
+from ssr_speech_amd import weights as W  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _ref_model(ssr, args, seed):
+    m = ssr.SSR_Speech(args).eval()
+    sd = W.lm_state_dict(args, seed=seed)
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(k.startswith("accuracy_metrics") for k in missing.missing_keys), missing
+    return m, sd
+
+
+LM_CASES = [
+    # name, tiny-config kwargs, L, T, mask_interval, decode kwargs, torch seed
+    ("tts_greedy_cfg5", dict(), 12, 20, [[20, 20]], dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=5, aug_text=True), 11),
+    ("tts_greedy_cfg1", dict(), 9, 16, [[16, 16]], dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=-1, kvcache=1, cfg_coef=2.0, cfg_stride=1, aug_text=True), 12),
+    ("tts_greedy_nocfg", dict(), 10, 18, [[18, 18]], dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=1, aug_text=False), 13),
+    ("tts_greedy_nokv", dict(), 8, 12, [[12, 12]], dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=0, cfg_coef=1.5, cfg_stride=5, aug_text=True), 14),
+    ("edit_mid_greedy", dict(), 12, 30, [[10, 17]], dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=1, aug_text=True), 15),
+    ("edit_start_greedy", dict(), 10, 24, [[0, 6]], dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=2, aug_text=True), 16),
+    ("edit_2span_greedy", dict(), 12, 30, [[5, 9], [18, 22]], dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=1, aug_text=True), 17),
+    ("edit_3span_greedy", dict(), 12, 36, [[4, 8], [14, 15], [30, 36]], dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=0, cfg_coef=1.5, cfg_stride=3, aug_text=True), 18),
+    ("tts_sample_topk", dict(), 12, 20, [[20, 20]], dict(top_k=10, top_p=0.8, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=5, aug_text=True), 19),
+    ("tts_sample_topp_temp", dict(), 12, 20, [[20, 20]], dict(top_k=0, top_p=0.8, temperature=2, stop_repetition=1, kvcache=1, cfg_coef=1.5, cfg_stride=1, aug_text=True), 20),
+    ("tts_greedy_hd128", dict(d_model=256, nhead=2, layers=2, vocab=128), 14, 22, [[22, 22]], dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=5, aug_text=True), 21),
+]
+
+
+def make_lm():
+    ssr = ref_import.import_lm()
+    out = {}
+    for name, cfg, L, T, mi, kw, seed in LM_CASES:
+        args = W.lm_args_tiny(**cfg)
+        m, sd = _ref_model(ssr, args, seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randint(0, args.text_vocab_size, (1, L), generator=g)
+        y = torch.randint(0, args.audio_vocab_size, (1, T, args.n_codebooks), generator=g)
+        if "sample" in name:  # make silence tokens reachable in the tiny vocab
+            kw = dict(kw, silence_tokens=[3, 7, 11])
+        mask_interval = torch.LongTensor([mi])
+        # record what the reference hands to its sampler (post-edit logits) and what comes back,
+        # plus the Exp(1) noise torch.multinomial consumed (drawn here from the same generator state)
+        rec = {"logits": [], "samples": [], "noise": []}
+        orig = ssr.topk_sampling
+
+        def spy(logits, top_k=10, top_p=1.0, temperature=1.0):
+            rec["logits"].append(logits.detach().clone())
+            st = torch.get_rng_state()
+            q = torch.empty_like(logits).exponential_(1)
+            torch.set_rng_state(st)
+            rec["noise"].append(q)
+            tok = orig(logits, top_k=top_k, top_p=top_p, temperature=temperature)
+            rec["samples"].append(tok.detach().clone())
+            return tok
+
+        ssr.topk_sampling = spy
+        try:
+            torch.manual_seed(seed)
+            if kw.get("aug_text"):
+                st = torch.get_rng_state()
+                uncond = torch.randint(0, args.text_vocab_size + 1, (1, L))
+                torch.set_rng_state(st)
+            else:
+                uncond = torch.zeros(1, 0, dtype=torch.long)
+            with torch.no_grad():
+                res, marks, masks, nmi = m.inference(x, torch.LongTensor([L]), x, torch.LongTensor([L]), y, y, mask_interval, **kw)
+        finally:
+            ssr.topk_sampling = orig
+        kwn = {f"kw_{k}": np.asarray(v) for k, v in kw.items()}
+        out[name] = dict(
+            cfg=np.asarray([getattr(args, k) for k in ("d_model", "nhead", "num_decoder_layers", "audio_vocab_size")]),
+            weight_seed=np.asarray(seed), torch_seed=np.asarray(seed), x=x.numpy(), y=y.numpy(), mask_interval=mask_interval.numpy(),
+            uncond_x=uncond.numpy(), res=res.numpy(), marks=marks.numpy(), masks=np.asarray(masks), non_mask_intervals=np.asarray(nmi),
+            step_logits=torch.stack(rec["logits"]).numpy(), step_samples=torch.stack(rec["samples"]).numpy(),
+            step_noise=torch.stack(rec["noise"]).numpy(), torch_version=np.asarray(torch.__version__), **kwn)
+        print(f"  lm/{name}: res {tuple(res.shape)} steps {len(rec['logits'])}")
+    for name, d in out.items():
+        np.savez_compressed(os.path.join(GOLD, f"lm_{name}.npz"), **d)
+
+
+def make_layout():
+    """G1: layout builder (A3) + span re-assembly pieces straight from the reference methods."""
+    ssr = ref_import.import_lm()
+    args = W.lm_args_tiny()
+    m = ssr.SSR_Speech(args).eval()
+    cases = {"tts": (20, [[20, 20]]), "mid": (30, [[10, 17]]), "start": (24, [[0, 6]]), "end": (24, [[18, 24]]),
+             "two": (30, [[5, 9], [18, 22]]), "three": (36, [[4, 8], [14, 15], [30, 36]]), "insert": (16, [[8, 8]])}
+    d = {}
+    for name, (T, mi) in cases.items():
+        g = torch.Generator().manual_seed(T)
+        y = torch.randint(0, args.audio_vocab_size, (args.n_codebooks, T), generator=g)
+        starts = [a for a, _ in mi] + [T]
+        ends = [0] + [b for _, b in mi]
+        nmi = list(zip(ends, starts))
+        rearranged = m.rearrange(y, nmi, [tuple(v) for v in mi])
+        shifted = m.shift(rearranged)
+        inserted, mask_position = m.insert_mask(shifted)
+        cated, _ = m.cat_y(inserted)
+        num_task = len(mask_position) // 2
+        d[f"{name}_y"] = y.numpy()
+        d[f"{name}_mi"] = np.asarray(mi)
+        d[f"{name}_cated_full"] = cated.numpy()
+        d[f"{name}_mask_position"] = np.asarray(mask_position)
+        d[f"{name}_cated"] = cated[:, : mask_position[num_task]].numpy()
+        # delay-pattern round trip on a span, via the reference's own helpers (ssr.py:408-464)
+        span = torch.randint(0, args.audio_vocab_size, (args.n_codebooks, 7), generator=g)
+        pat = m.get_pattern_sequence(span, args.n_codebooks, args.empty_token)
+        d[f"{name}_span"] = span.numpy()
+        d[f"{name}_pattern"] = pat.numpy()
+        d[f"{name}_reverted"] = m.revert_pattern_sequence(pat, args.n_codebooks, special_token=args.empty_token).numpy()
+    np.savez_compressed(os.path.join(GOLD, "layout.npz"), **d)
+    print("  layout:", sorted(cases))
+
+
+def make_sampler():
+    """G5: top_k_top_p_filtering on a (k,p) grid incl. ties; multinomial-by-noise identity."""
+    ssr = ref_import.import_lm()
+    g = torch.Generator().manual_seed(5)
+    d = {}
+    base = torch.randn(4, 72, generator=g) * 2.0
+    base[1, 5] = base[1, 9] = base[1].max() + 0.5          # tie at the top
+    base[2, 10:14] = base[2, 20]                           # 5-way tie in the middle
+    d["logits"] = base.numpy()
+    for k in (0, 1, 3, 10, 72, 100):
+        for p in (1.0, 0.9, 0.5, 0.05):
+            f = ssr.top_k_top_p_filtering(base.clone(), top_k=k, top_p=p)
+            d[f"filt_k{k}_p{p}"] = f.numpy()
+    # torch.multinomial(probs,1) == argmax(probs / Exp(1) noise drawn from the same generator state
+    probs = torch.softmax(base, -1)
+    eq = []
+    for s in range(20):
+        torch.manual_seed(100 + s)
+        st = torch.get_rng_state()
+        q = torch.empty_like(probs).exponential_(1)
+        torch.set_rng_state(st)
+        tok = torch.multinomial(probs, 1)
+        eq.append(bool(torch.equal(tok, torch.argmax(probs / q, -1, keepdim=True))))
+    d["multinomial_is_argmax_p_over_q"] = np.asarray(eq)
+    assert all(eq), eq
+    np.savez_compressed(os.path.join(GOLD, "sampler.npz"), **d)
+    print("  sampler ok")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["layout", "sampler", "lm", "codec"]
+    torch.set_num_threads(8)
+    if "layout" in which:
+        make_layout()
+    if "sampler" in which:
+        make_sampler()
+    if "lm" in which:
+        make_lm()
+    if "codec" in which:
+        from oracle import make_golden_codec
+        make_golden_codec.main(GOLD)
