@@ -1,0 +1,182 @@
+"""bench.py — AR-decode throughput of the HIP engine on the BASELINE.json configuration
+"English 830M zero-shot TTS, cfg_stride=5 top-k sampling, batch=1 on one MI355X" (configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one decode step of the hot path (one codec frame = 4 codec tokens per utterance) over one
+batch of synthetic input: 830M-shape weights from the deterministic generator (seed 0, fp32), L=130 random
+phoneme ids, a 160-frame random prompt, CFG doubling (2 rows), top_k=40/top_p=0.8 sampling. Inputs and
+weights are resident in HBM before the timed region. One utterance per GPU (weak scaling: rank r decodes
+utterance r with seed+r, no data-path collective during decode; ONE all_gather of the generated tokens
+afterwards, timed separately).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the weight-streaming GEMV, HBM-bound) and
+`cpu_baseline` (the oracle = CPU restatement of the reference, timed on this box's host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+
+
+def synth_inputs(args_lm, rank, L=130, N=160):
+    g = torch.Generator().manual_seed(2024 + rank)
+    x = torch.randint(0, 100, (1, L), generator=g)
+    y = torch.randint(0, 2048, (1, N, 4), generator=g)
+    unc = torch.randint(0, 101, (1, L), generator=g)
+    return x, y, unc
+
+
+def cpu_baseline(args_lm, sd_gpu, x, y, unc, n_steps=25):
+    """Oracle (port of the reference's CPU path) on this box's host cores; returns codec-tokens/s."""
+    from oracle import lm as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = O.reference_params({k: v.cpu() for k, v in sd_gpu.items()})
+    marks = []
+    trace = {}
+
+    class Clock(dict):
+        def setdefault(self, k, d=None):
+            if k == "samples":
+                marks.append(time.perf_counter())
+            return dict.setdefault(self, k, d)
+
+    trace = Clock()
+    mi = torch.LongTensor([[[y.shape[1], y.shape[1]]]])
+    t0 = time.perf_counter()
+    O.inference(sd, args_lm, x, y, mi, uncond_x=unc, max_steps=n_steps, trace=trace, top_k=40, top_p=0.8, temperature=1.0,
+                stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=5, aug_text=True)
+    prefill_s = marks[0] - t0
+    dt = np.diff(np.asarray(marks))[5:]          # steps 6.. (skip the first few: allocator warm-up)
+    return dict(value=round(4.0 / float(dt.mean()), 2), unit="codec-tokens/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/lm.py (CPU restatement of models/ssr.py inference), same 830M weights/inputs: prefill S0={x.shape[1] + y.shape[1] + 10} x2 rows "
+                       f"({prefill_s:.2f} s) + {n_steps} decode steps, steps 6-{n_steps} timed ({1000 * float(dt.mean()):.1f} ms/step)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    import ssr_speech_amd  # noqa: F401
+    from ssr_speech_amd import layout as LY
+    from ssr_speech_amd import weights as W
+    from ssr_speech_amd.engine import DecodeEngine, DecodeKnobs, LMWeightsArena
+
+    args_lm = W.lm_args_830m()
+    sd = W.lm_state_dict(args_lm, seed=0, device=dev)
+    arena = LMWeightsArena(args_lm, sd, dev)
+    x, y, unc = synth_inputs(args_lm, rank)
+    L, N = x.shape[1], y.shape[1]
+    total = a.warmup + a.steps
+    cated, _, num_task, _ = LY.build_layout(y[0].T.numpy(), np.asarray([[N, N]]), args_lm)
+    T0 = cated.shape[1]
+    assert T0 + 1 + total <= 10 * L, "bench would hit the reference's length cap (10*L): lower --steps"
+    eng = DecodeEngine(arena, 1, True, ((L + T0 + total + 8 + 1023) // 1024) * 1024, ((total + 255) // 256) * 256)
+    kn = DecodeKnobs(top_k=40, top_p=0.8, temperature=1.0, stop_repetition=2, cfg_coef=1.5, cfg_stride=5, use_cfg=True,
+                     text_len=L, n_spans=num_task, seed=2024 + rank)
+    seed_try = 0
+    while True:
+        kn.seed = 2024 + rank + 1000 * seed_try
+        eng.start([x[0].numpy(), unc[0].numpy()], [cated], [kn], noise=None)
+        torch.cuda.synchronize()
+        eng.decode(a.warmup, use_graph=not a.no_graph)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        eng.decode(a.steps, use_graph=not a.no_graph)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t1 = time.perf_counter()
+        st = eng.states()[0]
+        if st.n_steps == total or seed_try >= 3:
+            break
+        seed_try += 1           # the sampler drew <eog> inside the timed region: different stream, same workload
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        # the one collective of the path: gather every rank's generated codec tokens (before wmencodec decode)
+        gathered = torch.empty(world * eng.generated.numel(), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(gathered, eng.generated.view(-1))
+        torch.cuda.synchronize()
+        allgather_ms = 1000 * (time.perf_counter() - g0)
+    else:
+        allgather_ms = None
+
+    if rank == 0:
+        ms_per_step = 1000 * elapsed / a.steps
+        tokens_per_step = 4 * world                      # K=4 codebooks x 1 frame x one utterance per GPU
+        value = tokens_per_step * a.steps / elapsed
+        # ---- roofline of the dominant kernel (weight-streaming GEMV): event-timed per launch, eager
+        kt = eng.time_kernels(8)
+        n_gemv = kt["gemv"]["launches_per_step"]
+        w_bytes = arena.nbytes_per_step() - 4 * (arena.K + 1) * arena.D      # GEMV-streamed bytes (embedding rows excluded)
+        bytes_per_launch = w_bytes / n_gemv
+        gemv_us = kt["gemv"]["us_per_launch"]
+        achieved = bytes_per_launch / (gemv_us * 1e-6) / 1e9
+        S_mid = L + T0 + a.warmup + a.steps // 2
+        kv_bytes = 262144 * 2 * S_mid * (arena.L / 16) * (arena.D / 2048)
+        step_gbs = (arena.nbytes_per_step() + kv_bytes) / (ms_per_step * 1e-3) / 1e9
+        out = {
+            "metric": "codec-tokens/sec/GPU (AR decode) + RTF for 10 s TTS, English 830M",
+            "value": round(value, 1), "unit": "codec-tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "English-830M-shape zero-shot TTS decode, cfg_stride=5, top_k=40/top_p=0.8 sampling, batch=1 (2 CFG rows) per GPU; "
+                                   f"L={L} phonemes, {N}-frame prompt, context {L + T0 + a.warmup}..{L + T0 + total}",
+                       "utterances_per_gpu": 1, "rows": 2, "graph": not a.no_graph, "steps_completed": int(st.n_steps)},
+            "per_gpu_value": round(value / world, 1),
+            "decode_rtf_10s": round((500 * ms_per_step / 1000) / 10.0, 4),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "gemv_kernel<2> (fused LN/combine + GEMV + bias/act/residual)",
+                         "bytes_per_launch": int(bytes_per_launch), "launches_per_step": n_gemv, "us_per_launch": round(gemv_us, 3),
+                         "step_level": {"bytes_per_step": int(arena.nbytes_per_step() + kv_bytes), "achieved": round(step_gbs, 1),
+                                        "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
+                         "other_kernels_us": {k: round(v["us_per_launch"], 3) for k, v in kt.items() if k != "gemv"}},
+        }
+        if allgather_ms is not None:
+            out["allgather_ms"] = round(allgather_ms, 3)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args_lm, sd, x, y, unc)
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

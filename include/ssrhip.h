@@ -1,0 +1,244 @@
+/* ssrhip.h — C-ABI of libssrhip.so: the MI355X (gfx950) kernels and decode engine behind the
+ * `ssr_speech_amd` Python classes that mirror SSR-Speech's inference surface.
+ *
+ * The reference (WangHelin1997/SSR-Speech) has NO native/FFI layer on this path — it is plain
+ * PyTorch modules — so every entry point below names the reference *Python*
+ * function(s) whose arithmetic it replaces (paths relative to the reference root).  A maintainer's
+ * binding is a ctypes stub.
+ *
+ * Conventions
+ *   - plain C types only; all `*_dev` / `float*` / `int*` arguments are DEVICE pointers into buffers
+ *     the caller owns (torch-allocated); the library never allocates or frees device memory.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); no internal device sync.
+ *   - return 0 on success, negative on error; `ssrhip_last_error()` returns a thread-local message.
+ *   - fp32 everywhere (the reference's CPU path is fp32); integer tokens are int32 on the device.
+ *   - "rows": B = utterances x (2 if classifier-free guidance else 1); row 2u is the conditional row
+ *     of utterance u and row 2u+1 its unconditional row (models/ssr.py:571-577, 690-696).
+ */
+#ifndef SSRHIP_H
+#define SSRHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSRHIP_VERSION 100
+#define SSRHIP_PAGE 128          /* KV-cache page = 128 positions */
+#define SSRHIP_MAX_CODEBOOKS 4
+#define SSRHIP_MAX_SILENCE 8
+
+typedef void* ssrhip_stream_t;
+
+int ssrhip_version(void);
+/* sizeof() of the ABI structs, for binding self-checks: 0 kv, 1 gemv_args, 2 attn_args, 3 embed_args,
+ * 4 sampler_cfg, 5 sampler_state, 6 sample_args, 7 gemm_args, 8 lm_weights, 9 lm_dims, 10 lm_buffers, 11 prefill_args */
+int ssrhip_sizeof(int which);
+const char* ssrhip_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Paged KV cache (replaces the dense, re-concatenated `past` tensor: models/ssr.py:685-686,
+ * models/modules/activation.py:626-631).
+ *   pool  [n_pages][n_layer][2][n_head][SSRHIP_PAGE][head_dim] fp32
+ *   table [n_seq][max_pages] int32 : logical page -> physical page of that sequence (row)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ssrhip_kv {
+  float* pool;
+  const int32_t* table;
+  int32_t max_pages;   /* table row stride */
+  int32_t n_layer, n_head, head_dim;
+} ssrhip_kv;
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused weight-streaming GEMV for B<=4 rows:  y[b][n] = epi( sum_k pro(x)[b][k] * W[n][k] + bias[n] )
+ * replaces F.linear at: activation.py:86 (packed in-proj), :637 (out-proj), transformer.py:386-388
+ * (linear1/ReLU/linear2), models/ssr.py:175-179 (prediction heads), fused with
+ * transformer.py:58-75 (LayerNorm, eps 1e-5) as prologue and the residual add (transformer.py:328-329).
+ * ---------------------------------------------------------------------------------------------- */
+enum { SSRHIP_PRO_NONE = 0, SSRHIP_PRO_LAYERNORM = 1, SSRHIP_PRO_ATTN_COMBINE = 2 };
+enum { SSRHIP_ACT_NONE = 0, SSRHIP_ACT_RELU = 1, SSRHIP_ACT_GELU_ERF = 2 };
+enum { SSRHIP_EPI_STORE = 0, SSRHIP_EPI_RESIDUAL = 1, SSRHIP_EPI_QKV_APPEND = 2 };
+
+typedef struct ssrhip_gemv_args {
+  const float* W;        /* [groups][N][K] row-major (PyTorch Linear.weight layout) */
+  const float* bias;     /* [groups][N] or NULL */
+  const float* x;        /* PRO_NONE/LAYERNORM: [B][x_stride] (+ g*K);  ATTN_COMBINE: unused */
+  float* y;              /* STORE: [B][y_stride] (+ g*N); RESIDUAL: y += ...; QKV_APPEND: q out [B][K] */
+  int32_t B, N, K, groups;
+  int32_t x_stride, y_stride;
+  int32_t pro, act, epi;
+  const float* ln_w; const float* ln_b; float ln_eps;           /* PRO_LAYERNORM */
+  /* PRO_ATTN_COMBINE: split-KV partials written by ssrhip_attn_decode */
+  const float* part_o; const float* part_ml; int32_t max_splits; /* [R][H][max_splits][hd], [R][H][max_splits][2] */
+  const int32_t* row_len;                                        /* [B] keys visible to each row */
+  /* EPI_QKV_APPEND: N == 3K; q -> y, k/v -> cache at position kv_pos[b] of sequence b */
+  ssrhip_kv kv; int32_t layer; const int32_t* kv_pos;
+} ssrhip_gemv_args;
+
+int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-query attention over the paged cache, split over pages (one workgroup per page):
+ * replaces F.scaled_dot_product_attention at activation.py:634 for tgt_len==1 (and, row by row,
+ * the causal prefill).  Row r attends to positions [0, row_len[r]) of sequence row_seq[r]
+ * (row_seq==NULL -> r).  Writes per-page partials (o, m, l); combine via ssrhip_gemv PRO_ATTN_COMBINE
+ * or ssrhip_attn_combine.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ssrhip_attn_args {
+  const float* q;          /* [R][q_stride] (first n_head*head_dim floats of each row) */
+  int32_t q_stride;        /* 0 -> n_head*head_dim */
+  ssrhip_kv kv; int32_t layer;
+  const int32_t* row_seq;  /* [R] or NULL */
+  const int32_t* row_len;  /* [R] */
+  int32_t R, max_splits;   /* max_splits >= ceil(max(row_len)/SSRHIP_PAGE) */
+  float scale;             /* 1/sqrt(head_dim) */
+  float* part_o; float* part_ml;
+} ssrhip_attn_args;
+
+int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t stream);
+int ssrhip_attn_combine(const ssrhip_attn_args* a, float* out /* [R][n_head*head_dim] */, ssrhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Token embedding + sinusoidal position: replaces embed_y (models/ssr.py:191-198, :655-660, :757-761),
+ * TokenEmbedding / SinePositionalEmbedding.forward (models/modules/embedding.py:44-48, 94-97).
+ *   kind[r]==0: text row   x = text_emb[tok[r][0]] + alpha_text * pe[pos[r]]
+ *   kind[r]==1: audio row  x = sum_k audio_emb[k][tok[r][k]] + alpha_audio * pe[pos[r]]
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ssrhip_embed_args {
+  const float* text_emb;   /* [n_text][D] */
+  const float* audio_emb;  /* [K][card][D] */
+  const float* pe;         /* [max_pos][D] */
+  float alpha_text, alpha_audio;
+  const int32_t* tok;      /* [R][SSRHIP_MAX_CODEBOOKS] */
+  const int32_t* pos;      /* [R] */
+  const int32_t* kind;     /* [R] or NULL (all audio) */
+  int32_t R, D, K, card;
+  float* out;              /* [R][D] */
+} ssrhip_embed_args;
+
+int ssrhip_embed(const ssrhip_embed_args* a, ssrhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-step sampler + logit state machine, one workgroup per utterance, no host sync:
+ * replaces models/ssr.py:689-754 (CFG combine, special-token edits, eog cascade, silence penalty,
+ * topk_sampling/top_k_top_p_filtering :26-86, stop rules, span hand-over :646-660).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ssrhip_sampler_cfg {     /* per utterance, device memory, read-only during decode */
+  int32_t top_k; float top_p; float temperature; int32_t stop_repetition;
+  float cfg_coef; float cfg_one_minus; /* fp32(1 - cfg_coef) computed in double like the reference :692 */
+  int32_t cfg_stride; int32_t use_cfg;
+  int32_t n_silence; int32_t silence[SSRHIP_MAX_SILENCE];
+  int32_t text_len;        /* L of the (doubled) text batch, for the 10*L cap :739 */
+  int32_t n_spans;         /* num_task */
+  int32_t empty_token, eog, eos, sos, mts, max_n_spans;
+  int32_t max_steps;       /* capacity of `generated` per utterance */
+  uint32_t seed_lo, seed_hi; /* on-device RNG stream when noise==NULL */
+} ssrhip_sampler_cfg;
+
+typedef struct ssrhip_sampler_state {   /* per utterance, device memory, mutated every step */
+  int32_t span;            /* current span index */
+  int32_t num_gen, num_eog, num_cfg_tag, prev_token, consec_silence;
+  int32_t audio_pos;       /* position of the token being fed this step (y_input.shape[1]-1) */
+  int32_t n_steps;         /* samples written so far (all spans) */
+  int32_t done;            /* 1 when all spans finished (or max_steps hit: 2) */
+  int32_t span_end[3];     /* n_steps at the end of each finished span */
+  int32_t pad[3];
+} ssrhip_sampler_state;
+
+typedef struct ssrhip_sample_args {
+  const float* logits;     /* [B][K][card]; rows 2u,2u+1 when use_cfg else row u */
+  int32_t n_utt, K, card;
+  const ssrhip_sampler_cfg* cfg;
+  ssrhip_sampler_state* state;
+  const float* noise;      /* [n_utt][max_steps][K][card] Exp(1) draws, or NULL */
+  int32_t* generated;      /* [n_utt][max_steps][K] */
+  int32_t* next_tok;       /* [B][SSRHIP_MAX_CODEBOOKS] token ids fed to ssrhip_embed next step */
+  int32_t* next_pos;       /* [B] audio position of the next input */
+  int32_t* kv_pos;         /* [B] incremented for live utterances */
+  int32_t* row_len;        /* [B] = kv_pos+1 */
+  float* dbg_logits;       /* optional [n_utt][K][card] post-edit logits (tests) or NULL */
+} ssrhip_sample_args;
+
+int ssrhip_sample(const ssrhip_sample_args* a, ssrhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 FMA chain) for the
+ * prefill rows and the codec:  C[M][N] = epi( A[M][K] . W[N][K]^T + bias[N] ), act/residual as GEMV.
+ * replaces the same F.linear call sites as ssrhip_gemv when tgt_len > 4.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ssrhip_gemm_args {
+  const float* A; const float* W; const float* bias; float* C;
+  int32_t M, N, K, lda, ldc;
+  int32_t act, residual;   /* residual: C += ... */
+} ssrhip_gemm_args;
+int ssrhip_gemm(const ssrhip_gemm_args* a, ssrhip_stream_t stream);
+
+/* LayerNorm over rows (transformer.py:58-75) */
+int ssrhip_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int32_t R, int32_t D,
+                     ssrhip_stream_t stream);
+
+/* Scatter the k/v thirds of a packed qkv buffer [R][3D] into the paged cache; row r -> sequence
+ * row_seq[r], position row_pos[r].  (activation.py:626-631 for the prefill rows) */
+int ssrhip_kv_scatter(const float* qkv, const ssrhip_kv* kv, int32_t layer, const int32_t* row_seq,
+                      const int32_t* row_pos, int32_t R, ssrhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Decode engine: one LM, B rows; prefill + N decode steps replayed from a captured hipGraph.
+ * replaces the body of SSR_Speech.inference (models/ssr.py:597-754) on the device.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ssrhip_lm_weights {      /* device pointers; per-layer arrays have n_layer entries (host arrays) */
+  const float* text_emb; const float* audio_emb; const float* pe; float alpha_text, alpha_audio;
+  const float* const* ln1_w; const float* const* ln1_b;
+  const float* const* in_proj_w; const float* const* in_proj_b;
+  const float* const* out_proj_w; const float* const* out_proj_b;
+  const float* const* ln2_w; const float* const* ln2_b;
+  const float* const* ffn1_w; const float* const* ffn1_b;
+  const float* const* ffn2_w; const float* const* ffn2_b;
+  const float* lnf_w; const float* lnf_b;
+  const float* head1_w; const float* head1_b;   /* [K*Hh][D], [K*Hh]   (predict_layer.k.0 stacked) */
+  const float* head2_w; const float* head2_b;   /* [K][card][Hh], [K][card] (predict_layer.k.2 stacked) */
+} ssrhip_lm_weights;
+
+typedef struct ssrhip_lm_dims {
+  int32_t d_model, n_head, n_layer, d_ffn, n_codebooks, card, head_hidden, n_text, max_pos;
+} ssrhip_lm_dims;
+
+typedef struct ssrhip_lm_buffers {      /* caller-allocated device workspaces */
+  int32_t B, n_utt, max_splits;
+  float* x;        /* [B][D] residual stream */
+  float* q;        /* [B][D] */
+  float* h;        /* [B][max(d_ffn, K*Hh)] */
+  float* logits;   /* [B][K][card] */
+  float* part_o;   /* [B][H][max_splits][hd] */
+  float* part_ml;  /* [B][H][max_splits][2] */
+  int32_t* next_tok; int32_t* next_pos; int32_t* kv_pos; int32_t* row_len;
+  ssrhip_kv kv;
+  ssrhip_sampler_cfg* cfg; ssrhip_sampler_state* state;
+  const float* noise; int32_t* generated; float* dbg_logits;
+} ssrhip_lm_buffers;
+
+typedef struct ssrhip_lm ssrhip_lm;     /* opaque host-side object (graph + launch descriptors) */
+
+int ssrhip_lm_create(const ssrhip_lm_dims* d, const ssrhip_lm_weights* w, const ssrhip_lm_buffers* b, ssrhip_lm** out);
+void ssrhip_lm_destroy(ssrhip_lm* lm);
+/* enqueue `n_steps` decode steps (graph replays when use_graph!=0) */
+int ssrhip_lm_decode(ssrhip_lm* lm, int32_t n_steps, int32_t use_graph, ssrhip_stream_t stream);
+/* prefill R rows ([text || audio] of every sequence, flattened): fills the cache for all layers.
+ * ws: workspace floats: x[R][D], xn[R][D], qkv[R][3D], o[R][D], h[R][d_ffn], part_o, part_ml sized for R. */
+typedef struct ssrhip_prefill_args {
+  const int32_t* tok; const int32_t* pos; const int32_t* kind;   /* embed inputs, [R].. */
+  const int32_t* row_seq; const int32_t* row_pos; const int32_t* row_len; /* cache coordinates, [R] */
+  int32_t R, max_splits;
+  float* x; float* xn; float* qkv; float* o; float* h; float* part_o; float* part_ml;
+} ssrhip_prefill_args;
+int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ssrhip_stream_t stream);
+
+/* time `n` launches of the graph's dominant kernels with hipEvents on `stream` (bench.py roofline);
+ * returns average microseconds per decode step in *us_per_step. */
+int ssrhip_lm_time_steps(ssrhip_lm* lm, int32_t n_steps, ssrhip_stream_t stream, float* us_per_step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSRHIP_H */

@@ -1,0 +1,170 @@
+// attn.hip — single-query attention over the paged KV cache, split over pages (flash-decoding), gfx950.
+//
+// One workgroup (4 waves) per (page, head, row); wave w scores 32 keys of the page.
+// Layout: a key/value row (head_dim fp32) is covered by LPK = head_dim/4 lanes with one float4 each, so one
+// wave-instruction loads 64/LPK whole rows, fully coalesced (512 B contiguous per row at head_dim 128).
+// All K and V loads of the wave's 32 keys are issued up front (the kernel is latency-, not
+// bandwidth-bound: every cache element is used exactly once per step, so there is no reuse for LDS to
+// exploit; LDS only carries the 4-wave merge). q.k partial products are reduced across the LPK lanes
+// with xor-shuffles on NI independent values at once; softmax statistics (m, l) and the un-normalised
+// output are written per page and merged by the consumer (ssrhip_gemv PRO_ATTN_COMBINE or
+// ssrhip_attn_combine) — deterministic, no atomics.
+// Replaces F.scaled_dot_product_attention (models/modules/activation.py:634); the additive mask the
+// reference builds (models/ssr.py:227-255) is exactly "row r sees positions < row_len[r]".
+#include "common.h"
+
+namespace {
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args a) {
+  constexpr int LPK = HD / 4;         // lanes per key row
+  constexpr int KPI = 64 / LPK;       // key rows per wave-instruction
+  constexpr int NI = 32 / KPI;        // load instructions for the wave's 32 keys
+  __shared__ __attribute__((aligned(16))) float sm[4][HD + 4];   // row stride keeps float4 stores 16-B aligned
+  const int split = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
+  const int len = a.row_len[r];
+  const int base = split * SSRHIP_PAGE;
+  if (base >= len) return;            // uniform per block
+  const int seq = a.row_seq ? a.row_seq[r] : r;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPK;         // which key row inside one wave-instruction
+  const int c4 = (lane % LPK) * 4;    // this lane's 4 columns
+  const int H = a.kv.n_head;
+
+  const float4 q = ld4(a.q + (size_t)r * (a.q_stride ? a.q_stride : H * HD) + h * HD + c4);
+  const int page = a.kv.table[(size_t)seq * a.kv.max_pages + split];
+  const float* kp = a.kv.pool + ((((size_t)page * a.kv.n_layer + a.layer) * 2 + 0) * H + h) * SSRHIP_PAGE * HD;
+  const float* vp = kp + (size_t)H * SSRHIP_PAGE * HD;
+
+  float4 kk[NI], vv[NI];
+  float s[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int j = wave * 32 + i * KPI + sub;             // key index inside the page
+    const bool ok = (base + j) < len;
+    kk[i] = ok ? ld4(kp + (size_t)j * HD + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int j = wave * 32 + i * KPI + sub;
+    const bool ok = (base + j) < len;
+    vv[i] = ok ? ld4(vp + (size_t)j * HD + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) s[i] = dot4(q, kk[i], 0.f);
+  // reduce each s[i] over the LPK lanes of its key row
+#pragma unroll
+  for (int o = LPK / 2; o > 0; o >>= 1) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) s[i] += __shfl_xor(s[i], o, 64);
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int j = wave * 32 + i * KPI + sub;
+    s[i] = ((base + j) < len) ? s[i] * a.scale : -INFINITY;
+    m = fmaxf(m, s[i]);
+  }
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float l = 0.f;
+  float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m > -INFINITY) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float p = expf(s[i] - m);   // exp(-inf) == 0 for masked keys
+      l += p;
+      o4.x = fmaf(p, vv[i].x, o4.x);
+      o4.y = fmaf(p, vv[i].y, o4.y);
+      o4.z = fmaf(p, vv[i].z, o4.z);
+      o4.w = fmaf(p, vv[i].w, o4.w);
+    }
+  }
+  // merge the KPI key-row groups of the wave (lanes with equal c4)
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    l += __shfl_xor(l, o, 64);
+    o4.x += __shfl_xor(o4.x, o, 64);
+    o4.y += __shfl_xor(o4.y, o, 64);
+    o4.z += __shfl_xor(o4.z, o, 64);
+    o4.w += __shfl_xor(o4.w, o, 64);
+  }
+  if (lane < LPK) {
+    *reinterpret_cast<float4*>(&sm[wave][c4]) = o4;
+  }
+  if (lane == 0) { sm[wave][HD] = m; sm[wave][HD + 1] = l; }
+  __syncthreads();
+  // 4-wave merge by the first LPK lanes of wave 0 (fixed order)
+  if (threadIdx.x < LPK) {
+    float M = fmaxf(fmaxf(sm[0][HD], sm[1][HD]), fmaxf(sm[2][HD], sm[3][HD]));
+    float L = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float mw = sm[w][HD];
+      const float f = (mw > -INFINITY) ? expf(mw - M) : 0.f;
+      L = fmaf(f, sm[w][HD + 1], L);
+      acc.x = fmaf(f, sm[w][c4 + 0], acc.x);
+      acc.y = fmaf(f, sm[w][c4 + 1], acc.y);
+      acc.z = fmaf(f, sm[w][c4 + 2], acc.z);
+      acc.w = fmaf(f, sm[w][c4 + 3], acc.w);
+    }
+    const size_t pi = ((size_t)r * H + h) * a.max_splits + split;
+    *reinterpret_cast<float4*>(a.part_o + pi * HD + c4) = acc;
+    if (threadIdx.x == 0) { a.part_ml[pi * 2] = M; a.part_ml[pi * 2 + 1] = L; }
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const ssrhip_attn_args a, float* out) {
+  const int H = a.kv.n_head, D = H * HD;
+  const int r = blockIdx.x;
+  const int ns = (a.row_len[r] + SSRHIP_PAGE - 1) / SSRHIP_PAGE;
+  for (int e = threadIdx.x * 4; e < D; e += 1024) {
+    const int h = e / HD, d = e % HD;
+    const float* ml = a.part_ml + ((size_t)r * H + h) * a.max_splits * 2;
+    const float* po = a.part_o + (((size_t)r * H + h) * a.max_splits) * HD + d;
+    float M = -INFINITY;
+    for (int s = 0; s < ns; ++s) M = fmaxf(M, ml[2 * s]);
+    float den = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < ns; ++s) {
+      const float w = expf(ml[2 * s] - M);
+      den = fmaf(w, ml[2 * s + 1], den);
+      const float4 o = ld4(po + (size_t)s * HD);
+      acc.x = fmaf(w, o.x, acc.x);
+      acc.y = fmaf(w, o.y, acc.y);
+      acc.z = fmaf(w, o.z, acc.z);
+      acc.w = fmaf(w, o.w, acc.w);
+    }
+    const float inv = 1.0f / den;
+    *reinterpret_cast<float4*>(out + (size_t)r * D + e) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+
+int check(const ssrhip_attn_args* a, const char* who) {
+  SSR_REQUIRE(a && a->q && a->kv.pool && a->kv.table && a->row_len && a->part_o && a->part_ml, "%s: null argument", who);
+  SSR_REQUIRE(a->kv.head_dim == 64 || a->kv.head_dim == 128, "%s: head_dim %d not in {64,128}", who, a->kv.head_dim);
+  SSR_REQUIRE(a->R > 0 && a->max_splits > 0 && a->max_splits <= a->kv.max_pages, "%s: bad R/max_splits", who);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t stream) {
+  if (int e = check(a, "ssrhip_attn_decode")) return e;
+  dim3 grid(a->max_splits, a->kv.n_head, a->R);
+  if (a->kv.head_dim == 128) hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ssrhip_attn_combine(const ssrhip_attn_args* a, float* out, ssrhip_stream_t stream) {
+  if (int e = check(a, "ssrhip_attn_combine")) return e;
+  SSR_REQUIRE(out, "ssrhip_attn_combine: out is null");
+  if (a->kv.head_dim == 128) hipLaunchKernelGGL(attn_combine_kernel<128>, dim3(a->R), dim3(256), 0, (hipStream_t)stream, *a, out);
+  else hipLaunchKernelGGL(attn_combine_kernel<64>, dim3(a->R), dim3(256), 0, (hipStream_t)stream, *a, out);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}

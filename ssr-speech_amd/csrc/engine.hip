@@ -1,0 +1,289 @@
+// engine.hip — host side of the decode engine: launch descriptors for one decode step, hipGraph
+// capture/replay, prefill orchestration, per-kernel event timing. No device allocation here: all
+// buffers belong to the caller (torch tensors), the engine owns only the graph objects and a private
+// capture stream.
+//
+// One decode step = embed -> n_layer x [LN1+QKV GEMV(+KV append) -> paged attention (split-KV partials)
+// -> combine+out-proj GEMV(+residual) -> LN2+FFN1 GEMV(+ReLU) -> FFN2 GEMV(+residual)]
+// -> final-LN + 4 head MLP-1 GEMV(+GELU) -> grouped head MLP-2 GEMV -> sampler/state machine.
+// The step touches no host state, so the captured graph replays unchanged for every step
+// (positions, tokens, stop flags all live in device memory).
+// Replaces the per-iteration body of SSR_Speech.inference (models/ssr.py:671-770).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+void ssrhip_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* ssrhip_last_error(void) { return g_err; }
+extern "C" int ssrhip_version(void) { return SSRHIP_VERSION; }
+extern "C" int ssrhip_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(ssrhip_kv);
+    case 1: return sizeof(ssrhip_gemv_args);
+    case 2: return sizeof(ssrhip_attn_args);
+    case 3: return sizeof(ssrhip_embed_args);
+    case 4: return sizeof(ssrhip_sampler_cfg);
+    case 5: return sizeof(ssrhip_sampler_state);
+    case 6: return sizeof(ssrhip_sample_args);
+    case 7: return sizeof(ssrhip_gemm_args);
+    case 8: return sizeof(ssrhip_lm_weights);
+    case 9: return sizeof(ssrhip_lm_dims);
+    case 10: return sizeof(ssrhip_lm_buffers);
+    case 11: return sizeof(ssrhip_prefill_args);
+    default: return -1;
+  }
+}
+
+struct ssrhip_lm {
+  ssrhip_lm_dims d;
+  ssrhip_lm_weights w;
+  ssrhip_lm_buffers b;
+  std::vector<const float*> ptrs[12];
+  hipStream_t cap_stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+namespace {
+
+enum { CAT_GEMV = 0, CAT_ATTN = 1, CAT_EMBED = 2, CAT_SAMPLE = 3, N_CAT = 4 };
+
+struct Timer {   // optional per-launch event timing
+  bool on = false;
+  hipStream_t s = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float ms[N_CAT] = {0, 0, 0, 0};
+  int n[N_CAT] = {0, 0, 0, 0};
+};
+
+#define STEP_CALL(cat, call)                                    \
+  do {                                                          \
+    if (tm && tm->on) hipEventRecord(tm->e0, tm->s);            \
+    int _rc = (call);                                           \
+    if (_rc) return _rc;                                        \
+    if (tm && tm->on) {                                         \
+      hipEventRecord(tm->e1, tm->s);                            \
+      hipEventSynchronize(tm->e1);                              \
+      float _ms = 0.f;                                          \
+      hipEventElapsedTime(&_ms, tm->e0, tm->e1);                \
+      tm->ms[cat] += _ms;                                       \
+      tm->n[cat] += 1;                                          \
+    }                                                           \
+  } while (0)
+
+int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
+  const ssrhip_lm_dims& d = lm->d;
+  const ssrhip_lm_weights& w = lm->w;
+  const ssrhip_lm_buffers& b = lm->b;
+  const int D = d.d_model, B = b.B, K = d.n_codebooks, Hh = d.head_hidden;
+
+  ssrhip_embed_args ea;
+  memset(&ea, 0, sizeof(ea));
+  ea.text_emb = w.text_emb; ea.audio_emb = w.audio_emb; ea.pe = w.pe;
+  ea.alpha_text = w.alpha_text; ea.alpha_audio = w.alpha_audio;
+  ea.tok = b.next_tok; ea.pos = b.next_pos; ea.kind = nullptr;
+  ea.R = B; ea.D = D; ea.K = K; ea.card = d.card; ea.out = b.x;
+  STEP_CALL(CAT_EMBED, ssrhip_embed(&ea, s));
+
+  for (int l = 0; l < d.n_layer; ++l) {
+    ssrhip_gemv_args g;
+    // LN1 + packed QKV projection, q -> b.q, k/v appended in place into the paged cache
+    memset(&g, 0, sizeof(g));
+    g.W = w.in_proj_w[l]; g.bias = w.in_proj_b[l]; g.x = b.x; g.y = b.q;
+    g.B = B; g.N = 3 * D; g.K = D; g.groups = 1; g.x_stride = D; g.y_stride = D;
+    g.pro = SSRHIP_PRO_LAYERNORM; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_QKV_APPEND;
+    g.ln_w = w.ln1_w[l]; g.ln_b = w.ln1_b[l]; g.ln_eps = 1e-5f;
+    g.kv = b.kv; g.layer = l; g.kv_pos = b.kv_pos;
+    STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+
+    ssrhip_attn_args at;
+    memset(&at, 0, sizeof(at));
+    at.q = b.q; at.kv = b.kv; at.layer = l; at.row_seq = nullptr; at.row_len = b.row_len;
+    at.R = B; at.max_splits = b.max_splits; at.scale = 1.0f / sqrtf((float)(D / d.n_head));
+    at.part_o = b.part_o; at.part_ml = b.part_ml;
+    STEP_CALL(CAT_ATTN, ssrhip_attn_decode(&at, s));
+
+    // split-KV combine + out-proj + residual
+    memset(&g, 0, sizeof(g));
+    g.W = w.out_proj_w[l]; g.bias = w.out_proj_b[l]; g.x = nullptr; g.y = b.x;
+    g.B = B; g.N = D; g.K = D; g.groups = 1; g.x_stride = D; g.y_stride = D;
+    g.pro = SSRHIP_PRO_ATTN_COMBINE; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_RESIDUAL;
+    g.part_o = b.part_o; g.part_ml = b.part_ml; g.max_splits = b.max_splits; g.row_len = b.row_len;
+    g.kv = b.kv;
+    STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+
+    // LN2 + FFN1 + ReLU
+    memset(&g, 0, sizeof(g));
+    g.W = w.ffn1_w[l]; g.bias = w.ffn1_b[l]; g.x = b.x; g.y = b.h;
+    g.B = B; g.N = d.d_ffn; g.K = D; g.groups = 1; g.x_stride = D; g.y_stride = d.d_ffn;
+    g.pro = SSRHIP_PRO_LAYERNORM; g.act = SSRHIP_ACT_RELU; g.epi = SSRHIP_EPI_STORE;
+    g.ln_w = w.ln2_w[l]; g.ln_b = w.ln2_b[l]; g.ln_eps = 1e-5f;
+    STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+
+    // FFN2 + residual
+    memset(&g, 0, sizeof(g));
+    g.W = w.ffn2_w[l]; g.bias = w.ffn2_b[l]; g.x = b.h; g.y = b.x;
+    g.B = B; g.N = D; g.K = d.d_ffn; g.groups = 1; g.x_stride = d.d_ffn; g.y_stride = D;
+    g.pro = SSRHIP_PRO_NONE; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_RESIDUAL;
+    STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+  }
+  {
+    ssrhip_gemv_args g;
+    // final LayerNorm + first Linear of the K prediction heads (stacked) + GELU
+    memset(&g, 0, sizeof(g));
+    g.W = w.head1_w; g.bias = w.head1_b; g.x = b.x; g.y = b.h;
+    g.B = B; g.N = K * Hh; g.K = D; g.groups = 1; g.x_stride = D; g.y_stride = K * Hh;
+    g.pro = SSRHIP_PRO_LAYERNORM; g.act = SSRHIP_ACT_GELU_ERF; g.epi = SSRHIP_EPI_STORE;
+    g.ln_w = w.lnf_w; g.ln_b = w.lnf_b; g.ln_eps = 1e-5f;
+    STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+    // second Linear of each head: K groups
+    memset(&g, 0, sizeof(g));
+    g.W = w.head2_w; g.bias = w.head2_b; g.x = b.h; g.y = b.logits;
+    g.B = B; g.N = d.card; g.K = Hh; g.groups = K; g.x_stride = K * Hh; g.y_stride = K * d.card;
+    g.pro = SSRHIP_PRO_NONE; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_STORE;
+    STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+  }
+  ssrhip_sample_args sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.logits = b.logits; sa.n_utt = b.n_utt; sa.K = K; sa.card = d.card;
+  sa.cfg = b.cfg; sa.state = b.state; sa.noise = b.noise; sa.generated = b.generated;
+  sa.next_tok = b.next_tok; sa.next_pos = b.next_pos; sa.kv_pos = b.kv_pos; sa.row_len = b.row_len;
+  sa.dbg_logits = b.dbg_logits;
+  STEP_CALL(CAT_SAMPLE, ssrhip_sample(&sa, s));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ssrhip_lm_create(const ssrhip_lm_dims* d, const ssrhip_lm_weights* w, const ssrhip_lm_buffers* b, ssrhip_lm** out) {
+  SSR_REQUIRE(d && w && b && out, "ssrhip_lm_create: null argument");
+  SSR_REQUIRE(d->d_model % d->n_head == 0, "ssrhip_lm_create: d_model %% n_head != 0");
+  const int hd = d->d_model / d->n_head;
+  SSR_REQUIRE(hd == 64 || hd == 128, "ssrhip_lm_create: head_dim %d not in {64,128}", hd);
+  SSR_REQUIRE(b->B == 1 || b->B == 2 || b->B == 4, "ssrhip_lm_create: B=%d rows not in {1,2,4}", b->B);
+  SSR_REQUIRE(d->n_codebooks <= SSRHIP_MAX_CODEBOOKS, "ssrhip_lm_create: too many codebooks");
+  ssrhip_lm* lm = new ssrhip_lm();
+  lm->d = *d; lm->w = *w; lm->b = *b;
+  // deep-copy the per-layer pointer arrays (the caller's ctypes arrays may be temporaries)
+  const float* const** fields[12] = {&lm->w.ln1_w, &lm->w.ln1_b, &lm->w.in_proj_w, &lm->w.in_proj_b, &lm->w.out_proj_w, &lm->w.out_proj_b,
+                                     &lm->w.ln2_w, &lm->w.ln2_b, &lm->w.ffn1_w, &lm->w.ffn1_b, &lm->w.ffn2_w, &lm->w.ffn2_b};
+  for (int f = 0; f < 12; ++f) {
+    const float* const* src = *fields[f];
+    if (!src) { delete lm; ssrhip_set_error("ssrhip_lm_create: null per-layer pointer array %d", f); return -1; }
+    lm->ptrs[f].assign(src, src + d->n_layer);
+    *fields[f] = lm->ptrs[f].data();
+  }
+  *out = lm;
+  return 0;
+}
+
+extern "C" void ssrhip_lm_destroy(ssrhip_lm* lm) {
+  if (!lm) return;
+  if (lm->exec) hipGraphExecDestroy(lm->exec);
+  if (lm->graph) hipGraphDestroy(lm->graph);
+  if (lm->cap_stream) hipStreamDestroy(lm->cap_stream);
+  delete lm;
+}
+
+extern "C" int ssrhip_lm_decode(ssrhip_lm* lm, int32_t n_steps, int32_t use_graph, ssrhip_stream_t stream) {
+  SSR_REQUIRE(lm && n_steps >= 0, "ssrhip_lm_decode: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (!use_graph) {
+    for (int i = 0; i < n_steps; ++i)
+      if (int rc = enqueue_step(lm, s, nullptr)) return rc;
+    return 0;
+  }
+  if (!lm->exec) {
+    if (!lm->cap_stream) SSR_HIP(hipStreamCreateWithFlags(&lm->cap_stream, hipStreamNonBlocking));
+    SSR_HIP(hipStreamBeginCapture(lm->cap_stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_step(lm, lm->cap_stream, nullptr);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(lm->cap_stream, &g);
+    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) { ssrhip_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return -2; }
+    lm->graph = g;
+    SSR_HIP(hipGraphInstantiate(&lm->exec, lm->graph, nullptr, nullptr, 0));
+  }
+  for (int i = 0; i < n_steps; ++i) SSR_HIP(hipGraphLaunch(lm->exec, s));
+  return 0;
+}
+
+extern "C" int ssrhip_lm_time_steps(ssrhip_lm* lm, int32_t n_steps, ssrhip_stream_t stream, float* out) {
+  // out[0..3] = avg microseconds per launch of {gemv, attn, embed, sample}; out[4..7] = launches per step
+  SSR_REQUIRE(lm && n_steps > 0 && out, "ssrhip_lm_time_steps: bad argument");
+  Timer tm;
+  tm.on = true;
+  tm.s = (hipStream_t)stream;
+  SSR_HIP(hipEventCreate(&tm.e0));
+  SSR_HIP(hipEventCreate(&tm.e1));
+  int rc = 0;
+  for (int i = 0; i < n_steps && !rc; ++i) rc = enqueue_step(lm, tm.s, &tm);
+  hipEventDestroy(tm.e0);
+  hipEventDestroy(tm.e1);
+  if (rc) return rc;
+  for (int c = 0; c < N_CAT; ++c) {
+    out[c] = tm.n[c] ? 1000.f * tm.ms[c] / tm.n[c] : 0.f;
+    out[4 + c] = (float)tm.n[c] / n_steps;
+  }
+  return 0;
+}
+
+extern "C" int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ssrhip_stream_t stream) {
+  SSR_REQUIRE(lm && p && p->tok && p->pos && p->kind && p->row_seq && p->row_pos && p->row_len, "ssrhip_lm_prefill: null argument");
+  SSR_REQUIRE(p->x && p->xn && p->qkv && p->o && p->h && p->part_o && p->part_ml, "ssrhip_lm_prefill: null workspace");
+  const ssrhip_lm_dims& d = lm->d;
+  const ssrhip_lm_weights& w = lm->w;
+  const int D = d.d_model, R = p->R;
+  hipStream_t s = (hipStream_t)stream;
+
+  ssrhip_embed_args ea;
+  memset(&ea, 0, sizeof(ea));
+  ea.text_emb = w.text_emb; ea.audio_emb = w.audio_emb; ea.pe = w.pe;
+  ea.alpha_text = w.alpha_text; ea.alpha_audio = w.alpha_audio;
+  ea.tok = p->tok; ea.pos = p->pos; ea.kind = p->kind;
+  ea.R = R; ea.D = D; ea.K = d.n_codebooks; ea.card = d.card; ea.out = p->x;
+  if (int rc = ssrhip_embed(&ea, s)) return rc;
+
+  for (int l = 0; l < d.n_layer; ++l) {
+    if (int rc = ssrhip_layernorm(p->x, w.ln1_w[l], w.ln1_b[l], 1e-5f, p->xn, R, D, s)) return rc;
+    ssrhip_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.A = p->xn; g.W = w.in_proj_w[l]; g.bias = w.in_proj_b[l]; g.C = p->qkv;
+    g.M = R; g.N = 3 * D; g.K = D; g.lda = D; g.ldc = 3 * D;
+    if (int rc = ssrhip_gemm(&g, s)) return rc;
+    if (int rc = ssrhip_kv_scatter(p->qkv, &lm->b.kv, l, p->row_seq, p->row_pos, R, s)) return rc;
+
+    ssrhip_attn_args at;
+    memset(&at, 0, sizeof(at));
+    at.kv = lm->b.kv; at.layer = l; at.row_seq = p->row_seq; at.row_len = p->row_len;
+    at.R = R; at.max_splits = p->max_splits; at.scale = 1.0f / sqrtf((float)(D / d.n_head));
+    at.part_o = p->part_o; at.part_ml = p->part_ml;
+    at.q = p->qkv; at.q_stride = 3 * D;   // q is the first third of each packed qkv row
+    if (int rc = ssrhip_attn_decode(&at, s)) return rc;
+    if (int rc = ssrhip_attn_combine(&at, p->o, s)) return rc;
+
+    memset(&g, 0, sizeof(g));
+    g.A = p->o; g.W = w.out_proj_w[l]; g.bias = w.out_proj_b[l]; g.C = p->x;
+    g.M = R; g.N = D; g.K = D; g.lda = D; g.ldc = D; g.residual = 1;
+    if (int rc = ssrhip_gemm(&g, s)) return rc;
+
+    if (int rc = ssrhip_layernorm(p->x, w.ln2_w[l], w.ln2_b[l], 1e-5f, p->xn, R, D, s)) return rc;
+    memset(&g, 0, sizeof(g));
+    g.A = p->xn; g.W = w.ffn1_w[l]; g.bias = w.ffn1_b[l]; g.C = p->h;
+    g.M = R; g.N = d.d_ffn; g.K = D; g.lda = D; g.ldc = d.d_ffn; g.act = SSRHIP_ACT_RELU;
+    if (int rc = ssrhip_gemm(&g, s)) return rc;
+    memset(&g, 0, sizeof(g));
+    g.A = p->h; g.W = w.ffn2_w[l]; g.bias = w.ffn2_b[l]; g.C = p->x;
+    g.M = R; g.N = D; g.K = d.d_ffn; g.lda = d.d_ffn; g.ldc = D; g.residual = 1;
+    if (int rc = ssrhip_gemm(&g, s)) return rc;
+  }
+  return 0;
+}

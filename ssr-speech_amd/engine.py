@@ -1,0 +1,308 @@
+"""Host-side driver of the HIP decode engine (libssrhip.so): weight arena, paged KV cache, prefill
+rows, hipGraph decode loop, read-back.  PyTorch is used for device memory and streams only.
+
+The arithmetic replaced is the device part of `SSR_Speech.inference` (reference `models/ssr.py:597-754`);
+integer layout code lives in `layout.py`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PAGE, MAX_CODEBOOKS
+
+
+def sine_pe_table(n: int, dim: int) -> torch.Tensor:
+    """Sinusoidal table built on the CPU in fp32 exactly like the reference does
+    (models/modules/embedding.py:67-92: built on CPU, then moved to the device)."""
+    pe = torch.zeros(n, dim)
+    position = torch.arange(0, n, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * -(math.log(10000.0) / dim))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+@dataclass
+class DecodeKnobs:
+    """Per-utterance decode parameters (the `inference()` keyword surface, models/ssr.py:513-523)."""
+    top_k: int = -100
+    top_p: float = 1.0
+    temperature: float = 1.0
+    stop_repetition: int = -1
+    silence_tokens: Sequence[int] = (1388, 1898, 131)
+    cfg_coef: float = 1.5
+    cfg_stride: int = 1
+    use_cfg: bool = False
+    text_len: int = 0
+    n_spans: int = 1
+    seed: int = 0
+
+
+class LMWeightsArena:
+    """Device-resident fp32 weights in the layout the kernels want (one-time repack at load)."""
+
+    def __init__(self, args, sd: dict, device, max_pos: int = 8192):
+        f32 = dict(dtype=torch.float32, device=device)
+        self.args = args
+        self.device = device
+        self.D = int(args.d_model)
+        self.H = int(args.nhead)
+        self.L = int(args.num_decoder_layers)
+        self.K = int(args.n_codebooks)
+        V = int(args.audio_vocab_size)
+        self.card = V + int(args.n_special) + int(args.max_n_spans)
+        self.Hh = V // 2
+        self.F = 4 * self.D
+        self.n_text = int(args.text_vocab_size) + 1
+        self.max_pos = max_pos
+        g = lambda k: sd[k].detach().to(**f32).contiguous()
+        self.text_emb = g("text_embedding.word_embeddings.weight")
+        self.audio_emb = torch.stack([g(f"audio_embedding.{k}.word_embeddings.weight") for k in range(self.K)]).contiguous()
+        self.alpha_text = float(sd["text_positional_embedding.alpha"].reshape(-1)[0])
+        self.alpha_audio = float(sd["audio_positional_embedding.alpha"].reshape(-1)[0])
+        self.pe = sine_pe_table(max_pos, self.D).to(**f32).contiguous()
+        self.layers = []
+        for l in range(self.L):
+            p = f"decoder.layers.{l}."
+            self.layers.append(dict(
+                ln1_w=g(p + "norm1.weight"), ln1_b=g(p + "norm1.bias"),
+                in_proj_w=g(p + "self_attn.in_proj_weight"), in_proj_b=g(p + "self_attn.in_proj_bias"),
+                out_proj_w=g(p + "self_attn.out_proj.weight"), out_proj_b=g(p + "self_attn.out_proj.bias"),
+                ln2_w=g(p + "norm2.weight"), ln2_b=g(p + "norm2.bias"),
+                ffn1_w=g(p + "linear1.weight"), ffn1_b=g(p + "linear1.bias"),
+                ffn2_w=g(p + "linear2.weight"), ffn2_b=g(p + "linear2.bias")))
+        self.lnf_w, self.lnf_b = g("decoder.norm.weight"), g("decoder.norm.bias")
+        self.head1_w = torch.cat([g(f"predict_layer.{k}.0.weight") for k in range(self.K)], 0).contiguous()
+        self.head1_b = torch.cat([g(f"predict_layer.{k}.0.bias") for k in range(self.K)], 0).contiguous()
+        self.head2_w = torch.stack([g(f"predict_layer.{k}.2.weight") for k in range(self.K)]).contiguous()
+        self.head2_b = torch.stack([g(f"predict_layer.{k}.2.bias") for k in range(self.K)]).contiguous()
+
+    def nbytes_per_step(self) -> int:
+        """Algorithmic weight bytes one decode step must stream."""
+        n = 0
+        for lay in self.layers:
+            n += sum(t.numel() for t in lay.values())
+        n += self.lnf_w.numel() + self.lnf_b.numel()
+        n += self.head1_w.numel() + self.head1_b.numel() + self.head2_w.numel() + self.head2_b.numel()
+        n += (self.K + 1) * self.D  # K embedding rows + one pe row
+        return 4 * n
+
+    def c_struct(self):
+        w = _lib.LMWeights()
+        w.text_emb, w.audio_emb, w.pe = self.text_emb.data_ptr(), self.audio_emb.data_ptr(), self.pe.data_ptr()
+        w.alpha_text, w.alpha_audio = self.alpha_text, self.alpha_audio
+        self._arrays = {}
+        for name in ("ln1_w", "ln1_b", "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "ln2_w", "ln2_b",
+                     "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b"):
+            arr = (C.c_void_p * self.L)(*[lay[name].data_ptr() for lay in self.layers])
+            self._arrays[name] = arr
+            setattr(w, name, C.cast(arr, C.POINTER(C.c_void_p)))
+        w.lnf_w, w.lnf_b = self.lnf_w.data_ptr(), self.lnf_b.data_ptr()
+        w.head1_w, w.head1_b = self.head1_w.data_ptr(), self.head1_b.data_ptr()
+        w.head2_w, w.head2_b = self.head2_w.data_ptr(), self.head2_b.data_ptr()
+        return w
+
+    def dims(self):
+        return _lib.LMDims(self.D, self.H, self.L, self.F, self.K, self.card, self.Hh, self.n_text, self.max_pos)
+
+
+class DecodeEngine:
+    """B rows (= n_utt x (2 if CFG else 1)) decoded in lock-step; one captured hipGraph per engine."""
+
+    def __init__(self, arena: LMWeightsArena, n_utt: int, use_cfg: bool, max_seq: int, max_steps: int, debug_logits: bool = False):
+        self.lib = _lib.lib()
+        self.a = arena
+        dev = arena.device
+        self.device = dev
+        self.n_utt = n_utt
+        self.use_cfg = use_cfg
+        self.rows_per_utt = 2 if use_cfg else 1
+        self.B = n_utt * self.rows_per_utt
+        if self.B not in (1, 2, 4):
+            raise ValueError(f"rows B={self.B} not supported by this build (1, 2 or 4)")
+        self.max_pages = (max_seq + PAGE - 1) // PAGE
+        self.max_seq = self.max_pages * PAGE
+        self.max_steps = max_steps
+        D, H, L, K = arena.D, arena.H, arena.L, arena.K
+        self.hd = D // H
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        n_pages = self.B * self.max_pages
+        self.kv_pool = torch.empty(n_pages * L * 2 * H * PAGE * self.hd, **f32)
+        self.page_table = torch.arange(n_pages, **i32).view(self.B, self.max_pages).contiguous()
+        self.x = torch.zeros(self.B, D, **f32)
+        self.q = torch.zeros(self.B, D, **f32)
+        self.h = torch.zeros(self.B, max(arena.F, K * arena.Hh), **f32)
+        self.logits = torch.zeros(self.B, K, arena.card, **f32)
+        self.part_o = torch.zeros(self.B * H * self.max_pages * self.hd, **f32)
+        self.part_ml = torch.zeros(self.B * H * self.max_pages * 2, **f32)
+        self.next_tok = torch.zeros(self.B, MAX_CODEBOOKS, **i32)
+        self.next_pos = torch.zeros(self.B, **i32)
+        self.kv_pos = torch.zeros(self.B, **i32)
+        self.row_len = torch.zeros(self.B, **i32)
+        self.cfg_dev = torch.zeros(n_utt * C.sizeof(_lib.SamplerCfg), dtype=torch.uint8, device=dev)
+        self.state_dev = torch.zeros(n_utt * C.sizeof(_lib.SamplerState), dtype=torch.uint8, device=dev)
+        self.generated = torch.zeros(n_utt, max_steps, K, **i32)
+        self.noise = None
+        self.dbg_logits = torch.zeros(n_utt, K, arena.card, **f32) if debug_logits else None
+        self._w = arena.c_struct()
+        self._ctx = None
+        self._noise_ptr = 0
+
+    # ------------------------------------------------------------------ C structs
+    def kv_struct(self):
+        return _lib.KV(self.kv_pool.data_ptr(), self.page_table.data_ptr(), self.max_pages, self.a.L, self.a.H, self.hd)
+
+    def _create_ctx(self):
+        if self._ctx is not None:
+            self.lib.ssrhip_lm_destroy(self._ctx)
+            self._ctx = None
+        b = _lib.LMBuffers()
+        b.B, b.n_utt, b.max_splits = self.B, self.n_utt, self.max_pages
+        b.x, b.q, b.h, b.logits = self.x.data_ptr(), self.q.data_ptr(), self.h.data_ptr(), self.logits.data_ptr()
+        b.part_o, b.part_ml = self.part_o.data_ptr(), self.part_ml.data_ptr()
+        b.next_tok, b.next_pos = self.next_tok.data_ptr(), self.next_pos.data_ptr()
+        b.kv_pos, b.row_len = self.kv_pos.data_ptr(), self.row_len.data_ptr()
+        b.kv = self.kv_struct()
+        b.cfg, b.state = self.cfg_dev.data_ptr(), self.state_dev.data_ptr()
+        b.noise = self.noise.data_ptr() if self.noise is not None else 0
+        b.generated = self.generated.data_ptr()
+        b.dbg_logits = self.dbg_logits.data_ptr() if self.dbg_logits is not None else 0
+        d = self.a.dims()
+        ctx = C.c_void_p()
+        _lib.check(self.lib.ssrhip_lm_create(C.byref(d), C.byref(self._w), C.byref(b), C.byref(ctx)), "ssrhip_lm_create")
+        self._ctx = ctx
+        self._noise_ptr = b.noise
+
+    def close(self):
+        if self._ctx is not None:
+            self.lib.ssrhip_lm_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ set-up of one generation
+    def start(self, text_rows: List[np.ndarray], audio_cols: List[np.ndarray], knobs: List[DecodeKnobs],
+              noise: Optional[torch.Tensor] = None):
+        """text_rows[b]: int array [L_b] (row b's text ids); audio_cols[u]: int array [K, T0_u]
+        (layout-built prompt columns, WITHOUT the mask token that starts generation);
+        knobs[u]. Runs the prefill and arms the decode state."""
+        a, dev = self.a, self.device
+        K = a.K
+        assert len(text_rows) == self.B and len(audio_cols) == self.n_utt and len(knobs) == self.n_utt
+        toks, poss, kinds, seqs, rposs = [], [], [], [], []
+        kv0 = []
+        for b in range(self.B):
+            u = b // self.rows_per_utt
+            tx = np.asarray(text_rows[b], dtype=np.int64).reshape(-1)
+            au = np.asarray(audio_cols[u], dtype=np.int64)
+            Lb, T0 = tx.shape[0], au.shape[1]
+            if Lb + T0 + 1 > self.max_seq:
+                raise ValueError("sequence exceeds engine capacity")
+            t = np.zeros((Lb + T0, MAX_CODEBOOKS), dtype=np.int32)
+            t[:Lb, 0] = tx
+            t[Lb:, :K] = au.T
+            toks.append(t)
+            poss.append(np.concatenate([np.arange(Lb), np.arange(T0)]).astype(np.int32))
+            kinds.append(np.concatenate([np.zeros(Lb), np.ones(T0)]).astype(np.int32))
+            seqs.append(np.full(Lb + T0, b, dtype=np.int32))
+            rposs.append(np.arange(Lb + T0, dtype=np.int32))
+            kv0.append(Lb + T0)
+        tok = torch.from_numpy(np.concatenate(toks)).to(dev)
+        pos = torch.from_numpy(np.concatenate(poss)).to(dev)
+        kind = torch.from_numpy(np.concatenate(kinds)).to(dev)
+        seq = torch.from_numpy(np.concatenate(seqs)).to(dev)
+        rpos = torch.from_numpy(np.concatenate(rposs)).to(dev)
+        rlen = (rpos + 1).contiguous()
+        R = tok.shape[0]
+
+        # sampler config/state
+        cfgs = (_lib.SamplerCfg * self.n_utt)()
+        sts = (_lib.SamplerState * self.n_utt)()
+        args = a.args
+        for u, kn in enumerate(knobs):
+            c = cfgs[u]
+            c.top_k, c.top_p, c.temperature, c.stop_repetition = int(kn.top_k), float(kn.top_p), float(kn.temperature), int(kn.stop_repetition)
+            c.cfg_coef, c.cfg_one_minus = float(kn.cfg_coef), float(1 - kn.cfg_coef)
+            c.cfg_stride, c.use_cfg = int(kn.cfg_stride), int(self.use_cfg)
+            sil = list(kn.silence_tokens)[: _lib.MAX_SILENCE]
+            c.n_silence = len(sil)
+            for i, s in enumerate(sil):
+                c.silence[i] = int(s)
+            c.text_len, c.n_spans = int(kn.text_len), int(kn.n_spans)
+            c.empty_token, c.eog, c.eos, c.sos = int(args.empty_token), int(args.eog), int(args.eos), int(args.sos)
+            c.mts, c.max_n_spans, c.max_steps = int(args.mts), int(args.max_n_spans), int(self.max_steps)
+            c.seed_lo, c.seed_hi = int(kn.seed) & 0xFFFFFFFF, (int(kn.seed) >> 32) & 0xFFFFFFFF
+            s = sts[u]
+            s.span, s.num_gen, s.num_eog, s.num_cfg_tag, s.prev_token, s.consec_silence = 0, 0, 0, 1, -1, 0
+            s.audio_pos = int(np.asarray(audio_cols[u]).shape[1])
+            s.n_steps, s.done = 0, 0
+        self.cfg_dev.copy_(torch.frombuffer(bytearray(bytes(cfgs)), dtype=torch.uint8))
+        self.state_dev.copy_(torch.frombuffer(bytearray(bytes(sts)), dtype=torch.uint8))
+        self.noise = noise
+        want_noise = noise.data_ptr() if noise is not None else 0
+        if self._ctx is None or want_noise != self._noise_ptr:
+            self._create_ctx()
+
+        # first decode input of every row: the span-0 mask token at audio position T0 (ssr.py:655-662)
+        nt = np.zeros((self.B, MAX_CODEBOOKS), dtype=np.int32)
+        nt[:, :K] = int(args.mts)
+        self.next_tok.copy_(torch.from_numpy(nt))
+        self.next_pos.copy_(torch.tensor([np.asarray(audio_cols[b // self.rows_per_utt]).shape[1] for b in range(self.B)], dtype=torch.int32))
+        self.kv_pos.copy_(torch.tensor(kv0, dtype=torch.int32))
+        self.row_len.copy_(torch.tensor(kv0, dtype=torch.int32) + 1)
+        self.generated.zero_()
+
+        # prefill workspaces
+        f32 = dict(dtype=torch.float32, device=dev)
+        D, F, H = a.D, a.F, a.H
+        ms = (max(kv0) + PAGE - 1) // PAGE
+        ws = dict(x=torch.empty(R, D, **f32), xn=torch.empty(R, D, **f32), qkv=torch.empty(R, 3 * D, **f32),
+                  o=torch.empty(R, D, **f32), h=torch.empty(R, F, **f32),
+                  part_o=torch.empty(R * H * ms * self.hd, **f32), part_ml=torch.empty(R * H * ms * 2, **f32))
+        p = _lib.PrefillArgs()
+        p.tok, p.pos, p.kind = tok.data_ptr(), pos.data_ptr(), kind.data_ptr()
+        p.row_seq, p.row_pos, p.row_len = seq.data_ptr(), rpos.data_ptr(), rlen.data_ptr()
+        p.R, p.max_splits = R, ms
+        for k, v in ws.items():
+            setattr(p, k, v.data_ptr())
+        _lib.check(self.lib.ssrhip_lm_prefill(self._ctx, C.byref(p), _lib.stream_ptr()), "ssrhip_lm_prefill")
+        self._keep = (tok, pos, kind, seq, rpos, rlen, ws)   # alive until the stream has consumed them
+        return R
+
+    # ------------------------------------------------------------------ decode
+    def decode(self, n_steps: int, use_graph: bool = True):
+        _lib.check(self.lib.ssrhip_lm_decode(self._ctx, int(n_steps), int(use_graph), _lib.stream_ptr()), "ssrhip_lm_decode")
+
+    def states(self) -> List[_lib.SamplerState]:
+        raw = bytes(self.state_dev.cpu().numpy().tobytes())
+        arr = (_lib.SamplerState * self.n_utt).from_buffer_copy(raw)
+        return list(arr)
+
+    def run_to_completion(self, chunk: int = 16, use_graph: bool = True, max_total: Optional[int] = None):
+        total = 0
+        limit = self.max_steps if max_total is None else min(max_total, self.max_steps)
+        while total < limit:
+            n = min(chunk, limit - total)
+            self.decode(n, use_graph)
+            total += n
+            if all(s.done for s in self.states()):
+                break
+        return self.states()
+
+    def time_kernels(self, n_steps: int):
+        out = (C.c_float * 8)()
+        _lib.check(self.lib.ssrhip_lm_time_steps(self._ctx, int(n_steps), _lib.stream_ptr(), out), "ssrhip_lm_time_steps")
+        names = ("gemv", "attn", "embed", "sample")
+        return {n: dict(us_per_launch=out[i], launches_per_step=out[4 + i]) for i, n in enumerate(names)}

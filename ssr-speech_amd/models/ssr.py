@@ -1,0 +1,214 @@
+"""`SSR_Speech` — drop-in for the reference's `models.ssr.SSR_Speech` on the inference path
+(reference `models/ssr.py:88-812`): same constructor (`args` Namespace or `config` dict), same
+`state_dict` keys, same `inference(...)` signature and 4-tuple return.  The arithmetic runs in
+libssrhip.so (hand-written HIP for gfx950); this file holds only host orchestration.
+
+There is no CPU fallback: `inference` raises if the HIP library or a GPU is missing.
+`forward(batch)` (the training loss, models/ssr.py:280-379) is outside this package's scope and raises.
+"""
+from __future__ import annotations
+
+import copy
+import logging
+from argparse import Namespace
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import layout as LY
+from ..engine import DecodeEngine, DecodeKnobs, LMWeightsArena
+from ..weights import lm_param_specs
+
+
+def _set_param(root: nn.Module, dotted: str, p: nn.Parameter):
+    mod = root
+    parts = dotted.split(".")
+    for name in parts[:-1]:
+        if not hasattr(mod, name):
+            mod.add_module(name, nn.Module())
+        mod = getattr(mod, name)
+    mod.register_parameter(parts[-1], p)
+
+
+class SSR_Speech(nn.Module):
+    def __init__(self, args: Optional[Namespace] = None, config: Optional[Dict] = None):
+        super().__init__()
+        if args is not None and config is not None:
+            raise ValueError("Cannot provide both `args` and `config`.")          # ssr.py:99-100
+        if args is None:
+            if config is None:
+                raise ValueError("Either `args` or `config` must be provided.")  # ssr.py:109-110
+            args = Namespace(**config)
+        self.args = copy.copy(args)
+        if not getattr(self.args, "n_special", False):                            # ssr.py:114-116
+            self.args.n_special = 3
+        self.args.eos = getattr(self.args, "eos", -1)
+        if isinstance(self.args.audio_vocab_size, str):                           # ssr.py:118-119
+            self.args.audio_vocab_size = eval(self.args.audio_vocab_size)
+        a = self.args
+        self.n_text_tokens = a.text_vocab_size + 1
+        assert a.text_pad_token == a.text_vocab_size, f"self.args.text_vocab_size: {a.text_vocab_size}, self.args.text_pad_token: {a.text_pad_token}"
+        self.n_audio_tokens = [int(a.audio_vocab_size) + a.n_special + a.max_n_spans] * a.n_codebooks
+        assert a.audio_vocab_size == a.empty_token, a.empty_token                 # ssr.py:125-130
+        assert a.eog == a.audio_vocab_size + 1, a.eog
+        assert a.audio_pad_token == a.audio_vocab_size + 2, a.audio_pad_token
+        assert a.eos == a.audio_vocab_size + 3, a.eos
+        assert a.sos == a.audio_vocab_size + 4, a.sos
+        assert a.mts == a.audio_vocab_size + 5, a.mts
+        # parameters under the reference's names (values are placeholders until load_state_dict)
+        for name, (shape, _kind) in lm_param_specs(a).items():
+            _set_param(self, name, nn.Parameter(torch.zeros(shape, dtype=torch.float32), requires_grad=False))
+        self._arena: Optional[LMWeightsArena] = None
+        self._engines: Dict[tuple, DecodeEngine] = {}
+        self.debug_logits = False          # tests: keep the per-step post-edit logits
+        self.last_run: dict = {}
+
+    # ------------------------------------------------------------------ nn.Module plumbing
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        # tolerate the training-only torchmetrics states a checkpoint may carry
+        sd = {k: v for k, v in state_dict.items() if not k.startswith("accuracy_metrics.")}
+        out = super().load_state_dict(sd, strict=strict, **kw)
+        self._invalidate()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._invalidate()
+        return out
+
+    def _invalidate(self):
+        for e in getattr(self, "_engines", {}).values():
+            e.close()
+        self._engines = {}
+        self._arena = None
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def forward(self, batch):
+        raise NotImplementedError("SSR_Speech.forward (training loss, reference models/ssr.py:280-379) is outside the "
+                                  "scope of ssr_speech_amd: only the inference hot path is implemented.")
+
+    # ------------------------------------------------------------------ engine management
+    def _get_engine(self, n_utt: int, use_cfg: bool, need_seq: int, need_steps: int) -> DecodeEngine:
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("ssr_speech_amd.SSR_Speech.inference needs the model on a ROCm GPU (model.to('cuda')); "
+                               "there is no CPU path in this package.")
+        if self._arena is None:
+            self._arena = LMWeightsArena(self.args, self.state_dict(), dev)
+        cap_seq = ((need_seq + 1023) // 1024) * 1024
+        cap_steps = ((need_steps + 255) // 256) * 256
+        key = (n_utt, use_cfg, cap_seq, cap_steps, bool(self.debug_logits))
+        eng = self._engines.get(key)
+        if eng is None:
+            for e in self._engines.values():     # one engine (KV pool) resident at a time
+                e.close()
+            self._engines = {}
+            eng = DecodeEngine(self._arena, n_utt, use_cfg, cap_seq, cap_steps, debug_logits=self.debug_logits)
+            self._engines[key] = eng
+        return eng
+
+    # ------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def inference(
+        self,
+        x: torch.Tensor,
+        x_lens: torch.Tensor,
+        prompt_x: torch.Tensor,
+        prompt_x_lens: torch.Tensor,
+        y: torch.Tensor,
+        prompt: torch.Tensor,
+        mask_interval: List[torch.Tensor],
+        top_k: int = -100,
+        top_p: float = 1.0,
+        temperature: float = 1.0,
+        stop_repetition: int = -1,
+        kvcache: int = 1,
+        silence_tokens: List[int] = [1388, 1898, 131],
+        cfg_coef: float = 1.5,
+        cfg_stride: int = 1,
+        aug_text: bool = False,
+        aug_context: bool = False,
+        cfg_pretrained: bool = False,
+        *,
+        noise: Optional[torch.Tensor] = None,
+        uncond_x: Optional[torch.Tensor] = None,
+        max_new_steps: Optional[int] = None,
+        use_graph: bool = True,
+    ):
+        """Same contract as the reference's `SSR_Speech.inference` (models/ssr.py:504-812).
+
+        `kvcache` is accepted and ignored (the engine always keeps a paged KV cache; the reference
+        produces identical tokens for kvcache 0/1).  Keyword-only extras (not in the reference):
+        `noise` [steps,K,card] Exp(1) draws replacing the multinomial generator draw, `uncond_x`
+        overriding the random CFG text (ssr.py:574), `max_new_steps` (tests), `use_graph`."""
+        K = self.args.n_codebooks
+        assert cfg_coef >= 1.0, cfg_coef
+        assert x.ndim == 2, x.shape
+        assert x_lens.ndim == 1, x_lens.shape
+        assert y.ndim == 3, y.shape
+        y = y.transpose(2, 1)
+        assert prompt.ndim == 3, prompt.shape
+        prompt = prompt.transpose(2, 1)
+        assert y.shape[0] == 1 and y.shape[1] == K, y.shape
+        assert prompt.shape[0] == 1 and prompt.shape[1] == K, prompt.shape
+        assert mask_interval.shape == torch.Size((1, mask_interval.shape[1], 2)), mask_interval
+        if aug_context or cfg_pretrained:
+            # models/ssr.py:563-594: not reachable from inference_scale.py; SURVEY §8f N3 ("next" row)
+            raise NotImplementedError("aug_context / cfg_pretrained are not implemented in ssr_speech_amd yet")
+
+        dev = self.device
+        x_np = x.detach().cpu().numpy().astype(np.int64)
+        L = x_np.shape[1]
+        text_rows = [x_np[0]]
+        if aug_text:
+            if uncond_x is None:
+                # drawn from the global CPU generator, before any sampling draw — exactly ssr.py:574
+                uncond_x = torch.randint(0, self.n_text_tokens, (1, L))
+            text_rows.append(uncond_x.detach().cpu().numpy().astype(np.int64)[0])
+        y_np = y[0].detach().cpu().numpy().astype(np.int64)
+        mi = mask_interval[0].detach().cpu().numpy().astype(np.int64)
+        cated, mask_position, num_task, nmi = LY.build_layout(y_np, mi, self.args)
+        T0 = cated.shape[1]
+        # upper bound on steps: every span stops at the latest when y_len > 10*L (ssr.py:739) + K eog steps
+        cap = max(10 * L + 2 - T0, 1) + num_task * (K + 1)
+        if max_new_steps is not None:
+            cap = min(cap, max_new_steps)
+        eng = self._get_engine(1, bool(aug_text), L + T0 + cap + 8, cap)
+        knobs = DecodeKnobs(top_k=top_k, top_p=top_p, temperature=temperature, stop_repetition=stop_repetition,
+                            silence_tokens=tuple(int(s) for s in silence_tokens), cfg_coef=cfg_coef, cfg_stride=cfg_stride,
+                            use_cfg=bool(aug_text), text_len=L, n_spans=num_task, seed=int(torch.initial_seed()))
+        noise_dev = None
+        greedy = top_k == 1
+        if noise is not None:
+            nz = torch.ones(1, eng.max_steps, K, eng.a.card, dtype=torch.float32)
+            n = min(noise.shape[0], eng.max_steps)
+            nz[0, :n] = noise[:n].to(torch.float32).cpu()
+            noise_dev = nz.to(dev)
+        elif not greedy:
+            # reproduce the reference's CPU sampling stream: torch.multinomial(probs[K,card], 1) draws
+            # one Exp(1) tensor of that shape per step from the global generator
+            nz = torch.empty(1, eng.max_steps, K, eng.a.card, dtype=torch.float32)
+            for s in range(min(cap, eng.max_steps)):
+                nz[0, s].exponential_(1)
+            noise_dev = nz.to(dev)
+        eng.start(text_rows, [cated], [knobs], noise=noise_dev)
+        states = eng.run_to_completion(chunk=16, use_graph=use_graph, max_total=cap)
+        st = states[0]
+        gen = eng.generated[0, : st.n_steps].cpu().numpy().astype(np.int64)
+        self.last_run = dict(steps=st.n_steps, done=st.done, span_end=list(st.span_end), prefill_rows=(L + T0) * (2 if aug_text else 1))
+        if st.done != 1:
+            if max_new_steps is not None:
+                return None
+            raise RuntimeError(f"generation did not finish within {cap} steps (done={st.done})")
+        ends = [0] + [st.span_end[i] for i in range(num_task)]
+        spans = [gen[ends[i]:ends[i + 1]] for i in range(num_task)]
+        res, marks, masks, nmi_out = LY.assemble(y_np, spans, nmi, self.args)
+        res_t = torch.from_numpy(res).unsqueeze(0).to(dev)
+        marks_t = torch.from_numpy(marks).unsqueeze(0)          # CPU tensor, as the reference (ssr.py:805)
+        logging.info(f"ssr_speech_amd: generated {st.n_steps} steps")
+        return res_t, marks_t, masks, nmi_out

@@ -1,0 +1,158 @@
+"""GPU: the drop-in `SSR_Speech.inference` (HIP engine) against the REFERENCE's golden vectors
+(tests/golden/lm_*.npz, produced by oracle/make_golden.py from /root/reference) and, at the full
+830M shape, against the oracle run on this box's CPU.
+
+Bars: codec-token ids, marks and intervals bit-exact under greedy decode; sampled runs bit-exact
+when fed the recorded Exp(1) noise; per-step post-edit logits within 2e-4 absolute (fp32, different
+summation order; logits are O(1..10))."""
+import glob
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+import ssr_speech_amd  # noqa: F401
+from ssr_speech_amd import weights as W
+from ssr_speech_amd.models.ssr import SSR_Speech
+from oracle import lm as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(os.path.basename(p)[3:-4] for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "lm_*.npz")))
+LOGIT_ATOL = 2e-4
+
+
+def _load(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"lm_{name}.npz"))
+    d, h, nl, v = (int(t) for t in g["cfg"])
+    args = W.lm_args_tiny(d_model=d, nhead=h, layers=nl, vocab=v)
+    kw = {k[3:]: (g[k].tolist() if g[k].ndim else g[k].item()) for k in g.files if k.startswith("kw_")}
+    return g, args, kw
+
+
+def _model(args, seed):
+    m = SSR_Speech(args)
+    m.load_state_dict(W.lm_state_dict(args, seed=seed))
+    return m.to("cuda").eval()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_inference_tokens_match_reference(golden_dir, name):
+    g, args, kw = _load(golden_dir, name)
+    m = _model(args, int(g["weight_seed"]))
+    L = g["x"].shape[1]
+    x = torch.from_numpy(g["x"]).cuda()
+    y = torch.from_numpy(g["y"]).cuda()
+    extra = {}
+    if kw.get("aug_text"):
+        extra["uncond_x"] = torch.from_numpy(g["uncond_x"])
+    if "sample" in name:
+        extra["noise"] = torch.from_numpy(g["step_noise"])
+    res, marks, masks, nmi = m.inference(x, torch.LongTensor([L]).cuda(), x, torch.LongTensor([L]).cuda(), y, y,
+                                         torch.from_numpy(g["mask_interval"]).cuda(), **kw, **extra)
+    assert res.dtype == torch.int64 and res.device.type == "cuda" and marks.device.type == "cpu"
+    assert m.last_run["steps"] == g["step_samples"].shape[0]
+    assert np.array_equal(res.cpu().numpy(), g["res"])
+    assert np.array_equal(marks.numpy(), g["marks"])
+    assert np.array_equal(np.asarray(masks), g["masks"])
+    assert np.array_equal(np.asarray(nmi), g["non_mask_intervals"])
+
+
+@pytest.mark.parametrize("name", ["tts_greedy_cfg5", "edit_2span_greedy", "tts_greedy_hd128", "tts_sample_topp_temp"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_per_step_logits_match_reference(golden_dir, name, use_graph):
+    """Step the engine one decode step at a time and compare the logits it hands to the sampler
+    (after CFG combine + special-token edits) with what the reference handed to `topk_sampling`."""
+    from ssr_speech_amd import layout as LY
+    from ssr_speech_amd.engine import DecodeEngine, DecodeKnobs, LMWeightsArena
+    g, args, kw = _load(golden_dir, name)
+    sd = W.lm_state_dict(args, seed=int(g["weight_seed"]), device="cuda")
+    arena = LMWeightsArena(args, sd, torch.device("cuda"))
+    S = g["step_logits"].shape[0]
+    eng = DecodeEngine(arena, 1, bool(kw["aug_text"]), 1024, 256, debug_logits=True)
+    y = g["y"][0].T
+    cated, mp, num_task, nmi = LY.build_layout(y, g["mask_interval"][0], args)
+    rows = [g["x"][0]] + ([g["uncond_x"][0]] if kw["aug_text"] else [])
+    kn = DecodeKnobs(top_k=kw["top_k"], top_p=kw["top_p"], temperature=kw["temperature"], stop_repetition=kw["stop_repetition"],
+                     silence_tokens=tuple(kw.get("silence_tokens", (1388, 1898, 131))), cfg_coef=kw["cfg_coef"], cfg_stride=kw["cfg_stride"],
+                     use_cfg=bool(kw["aug_text"]), text_len=g["x"].shape[1], n_spans=num_task)
+    nz = torch.ones(1, eng.max_steps, args.n_codebooks, arena.card)
+    nz[0, :S] = torch.from_numpy(g["step_noise"])
+    eng.start(rows, [cated], [kn], noise=nz.cuda())
+    worst = 0.0
+    for s in range(S):
+        eng.decode(1, use_graph=use_graph)
+        torch.cuda.synchronize()
+        got = eng.dbg_logits[0].cpu().numpy()
+        ref = g["step_logits"][s]
+        worst = max(worst, float(np.abs(got - ref).max()))
+        assert np.allclose(got, ref, rtol=0, atol=LOGIT_ATOL), (s, np.abs(got - ref).max())
+    st = eng.states()[0]
+    assert st.done == 1 and st.n_steps == S
+    print(f"{name}: max |logit diff| over {S} steps = {worst:.2e}")
+
+
+def test_contract_errors():
+    args = W.lm_args_tiny()
+    m = _model(args, 1)
+    x = torch.zeros(1, 5, dtype=torch.long).cuda()
+    y = torch.zeros(1, 9, 4, dtype=torch.long).cuda()
+    mi = torch.LongTensor([[[9, 9]]]).cuda()
+    with pytest.raises(AssertionError):
+        m.inference(x, torch.LongTensor([5]), x, torch.LongTensor([5]), y, y, mi, cfg_coef=0.5)       # ssr.py:552
+    with pytest.raises(AssertionError):
+        m.inference(x[0], torch.LongTensor([5]), x, torch.LongTensor([5]), y, y, mi)                 # ssr.py:553
+    with pytest.raises(AssertionError):
+        m.inference(x, torch.LongTensor([5]), x, torch.LongTensor([5]), y.repeat(2, 1, 1), y, mi)    # ssr.py:559 batch-1 only
+    with pytest.raises(NotImplementedError):
+        m.forward({})
+    cpu = SSR_Speech(args)
+    with pytest.raises(RuntimeError):
+        cpu.inference(x.cpu(), torch.LongTensor([5]), x.cpu(), torch.LongTensor([5]), y.cpu(), y.cpu(), mi.cpu())
+
+
+def test_state_dict_keys_are_the_references():
+    args = W.lm_args_tiny()
+    m = SSR_Speech(args)
+    assert list(m.state_dict().keys()) == list(W.lm_param_specs(args).keys())
+    assert vars(m.args)["n_codebooks"] == 4
+
+
+def test_full_830m_greedy_steps_match_oracle_on_cpu():
+    """Full 'English 830M' shape (SURVEY §8 constants), synthetic weights: 24 greedy CFG steps on the GPU vs
+    the oracle on this box's CPU cores: same token ids, logits within LOGIT_ATOL·(scale)."""
+    args = W.lm_args_830m()
+    torch.manual_seed(0)
+    sd_gpu = W.lm_state_dict(args, seed=0, device="cuda")
+    m = SSR_Speech(args)
+    m.load_state_dict({k: v.cpu() for k, v in sd_gpu.items()})
+    m = m.to("cuda").eval()
+    gen = torch.Generator().manual_seed(2024)
+    L, N, steps = 40, 60, 24
+    x = torch.randint(0, 100, (1, L), generator=gen)
+    y = torch.randint(0, 2048, (1, N, 4), generator=gen)
+    unc = torch.randint(0, 101, (1, L), generator=gen)
+    mi = torch.LongTensor([[[N, N]]])
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=5, aug_text=True)
+    # oracle on the CPU (weights are bit-identical: same generator, checked below)
+    sd_cpu = O.reference_params({k: v.cpu() for k, v in sd_gpu.items()})
+    k0 = "decoder.layers.7.linear1.weight"
+    assert torch.equal(W.make_tensor(k0, sd_cpu[k0].shape, "lin:2048", 0), sd_cpu[k0].detach())
+    trace = {}
+    O.inference(sd_cpu, args, x, y, mi, uncond_x=unc, max_steps=steps, trace=trace, **kw)
+    ref_tok = torch.stack(trace["samples"]).numpy()
+    ref_log = torch.stack(trace["edited_logits"]).numpy()
+    # engine, stepped
+    m.debug_logits = True
+    out = m.inference(x.cuda(), torch.LongTensor([L]), x.cuda(), torch.LongTensor([L]), y.cuda(), y.cuda(), mi.cuda(),
+                      uncond_x=unc, max_new_steps=steps, **kw)
+    assert out is None and m.last_run["steps"] == steps
+    eng = next(iter(m._engines.values()))
+    got_tok = eng.generated[0, :steps].cpu().numpy()
+    assert np.array_equal(got_tok, ref_tok), (got_tok, ref_tok)
+    last = eng.dbg_logits[0].cpu().numpy()
+    err = np.abs(last - ref_log[steps - 1]).max()
+    print(f"830M: max |logit diff| at step {steps}: {err:.2e} (logit std {ref_log[steps-1][np.abs(ref_log[steps-1])<1e3].std():.2f})")
+    assert err < 5e-4
