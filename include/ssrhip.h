@@ -158,6 +158,7 @@ typedef struct ssrhip_sample_args {
   int32_t* kv_pos;         /* [B] incremented for live utterances */
   int32_t* row_len;        /* [B] = kv_pos+1 */
   float* dbg_logits;       /* optional [n_utt][K][card] post-edit logits (tests) or NULL */
+  ssrhip_embed_args embed; /* embed.out != NULL: also write the next input rows x[b] = embed(next_tok) (fused, saves a launch) */
 } ssrhip_sample_args;
 
 int ssrhip_sample(const ssrhip_sample_args* a, ssrhip_stream_t stream);
@@ -234,9 +235,10 @@ typedef struct ssrhip_prefill_args {
 } ssrhip_prefill_args;
 int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ssrhip_stream_t stream);
 
-/* time `n` launches of the graph's dominant kernels with hipEvents on `stream` (bench.py roofline);
- * returns average microseconds per decode step in *us_per_step. */
-int ssrhip_lm_time_steps(ssrhip_lm* lm, int32_t n_steps, ssrhip_stream_t stream, float* us_per_step);
+/* run `n_steps` eager decode steps with a hipEvent pair around EVERY kernel launch (bench.py roofline).
+ * out_us[i] = average microseconds of launch slot i of a step, out_kind[i] = 0 gemv | 1 attention | 2 sampler;
+ * returns the number of slots (<= n_out) or a negative error. */
+int ssrhip_lm_time_steps(ssrhip_lm* lm, int32_t n_steps, ssrhip_stream_t stream, float* out_us, int32_t* out_kind, int32_t n_out);
 
 #ifdef __cplusplus
 }

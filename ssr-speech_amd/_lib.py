@@ -79,7 +79,7 @@ class SampleArgs(C.Structure):
     _fields_ = [("logits", C.c_void_p), ("n_utt", C.c_int32), ("K", C.c_int32), ("card", C.c_int32),
                 ("cfg", C.c_void_p), ("state", C.c_void_p), ("noise", C.c_void_p), ("generated", C.c_void_p),
                 ("next_tok", C.c_void_p), ("next_pos", C.c_void_p), ("kv_pos", C.c_void_p), ("row_len", C.c_void_p),
-                ("dbg_logits", C.c_void_p)]
+                ("dbg_logits", C.c_void_p), ("embed", EmbedArgs)]
 
 
 class GemmArgs(C.Structure):
@@ -141,7 +141,7 @@ SYMBOLS = [
     ("ssrhip_lm_destroy", None, [C.c_void_p]),
     ("ssrhip_lm_decode", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("ssrhip_lm_prefill", C.c_int, [C.c_void_p, C.POINTER(PrefillArgs), C.c_void_p]),
-    ("ssrhip_lm_time_steps", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, c_f32p]),
+    ("ssrhip_lm_time_steps", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, c_f32p, c_i32p, C.c_int32]),
 ]
 
 ABI_STRUCTS = [KV, GemvArgs, AttnArgs, EmbedArgs, SamplerCfg, SamplerState, SampleArgs, GemmArgs, LMWeights, LMDims,

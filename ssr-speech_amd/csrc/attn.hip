@@ -52,12 +52,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args
   }
 #pragma unroll
   for (int i = 0; i < NI; ++i) s[i] = dot4(q, kk[i], 0.f);
-  // reduce each s[i] over the LPK lanes of its key row
+  // reduce each s[i] over the LPK lanes of its key row (DPP row rotations + permlane16_swap: no LDS)
 #pragma unroll
-  for (int o = LPK / 2; o > 0; o >>= 1) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) s[i] += __shfl_xor(s[i], o, 64);
-  }
+  for (int i = 0; i < NI; ++i) s[i] = (LPK == 32) ? half32_sum(s[i]) : row16_sum(s[i]);
   float m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
@@ -65,8 +62,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args
     s[i] = ((base + j) < len) ? s[i] * a.scale : -INFINITY;
     m = fmaxf(m, s[i]);
   }
-#pragma unroll
-  for (int o = LPK; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (LPK == 16) m = fmaxf(m, xor16_f(m));
+  m = fmaxf(m, xor32_f(m));
   float l = 0.f;
   float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (m > -INFINITY) {
@@ -81,14 +78,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args
     }
   }
   // merge the KPI key-row groups of the wave (lanes with equal c4)
-#pragma unroll
-  for (int o = LPK; o < 64; o <<= 1) {
-    l += __shfl_xor(l, o, 64);
-    o4.x += __shfl_xor(o4.x, o, 64);
-    o4.y += __shfl_xor(o4.y, o, 64);
-    o4.z += __shfl_xor(o4.z, o, 64);
-    o4.w += __shfl_xor(o4.w, o, 64);
+  if (LPK == 16) {
+    l += xor16_f(l);
+    o4.x += xor16_f(o4.x); o4.y += xor16_f(o4.y); o4.z += xor16_f(o4.z); o4.w += xor16_f(o4.w);
   }
+  l += xor32_f(l);
+  o4.x += xor32_f(o4.x); o4.y += xor32_f(o4.y); o4.z += xor32_f(o4.z); o4.w += xor32_f(o4.w);
   if (lane < LPK) {
     *reinterpret_cast<float4*>(&sm[wave][c4]) = o4;
   }

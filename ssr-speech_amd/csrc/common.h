@@ -35,16 +35,87 @@ void ssrhip_set_error(const char* fmt, ...);
   } while (0)
 
 #ifdef __HIPCC__
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- wave-wide all-reduce without LDS traffic: 4 DPP row rotations (within each 16-lane row) + the
+// gfx950 v_permlane16_swap / v_permlane32_swap for the cross-row steps. 8 VALU instructions, every lane
+// ends with the total; ~10x lower latency than six ds_bpermute round trips. The association order is
+// fixed, so results are bit-reproducible.
+// NOTE: the two operands of v_permlane{16,32}_swap must live in DIFFERENT registers (the instruction
+// swaps lanes between its two registers in place); feeding the builtin the same value twice lets hipcc
+// allocate one register for both and the swap degenerates to a no-op (seen on ROCm 7.2). `opaque_copy`
+// hides the equality from the compiler.
+__device__ __forceinline__ unsigned opaque_copy(unsigned v) {
+  asm volatile("; permlane operand copy" : "+v"(v));
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+struct U2 { unsigned a, b; };
+__device__ __forceinline__ U2 swap16(unsigned u) {
+  auto r = __builtin_amdgcn_permlane16_swap(u, opaque_copy(u), false, false);
+  return U2{r[0], r[1]};   // a = {row0,row0,row2,row2}, b = {row1,row1,row3,row3}
+}
+__device__ __forceinline__ U2 swap32(unsigned u) {
+  auto r = __builtin_amdgcn_permlane32_swap(u, opaque_copy(u), false, false);
+  return U2{r[0], r[1]};   // a = {lo,lo}, b = {hi,hi}
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+struct OpAdd { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+struct OpMax { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+
+template <class Op>
+__device__ __forceinline__ float wave_allreduce(float v, Op op) {
+  v = op(v, dpp_f<0x128>(v));   // row_ror:8
+  v = op(v, dpp_f<0x124>(v));   // row_ror:4
+  v = op(v, dpp_f<0x122>(v));   // row_ror:2
+  v = op(v, dpp_f<0x121>(v));   // row_ror:1
+  const U2 r = swap16(__builtin_bit_cast(unsigned, v));
+  v = op(__builtin_bit_cast(float, r.a), __builtin_bit_cast(float, r.b));
+  const U2 s = swap32(__builtin_bit_cast(unsigned, v));
+  return op(__builtin_bit_cast(float, s.a), __builtin_bit_cast(float, s.b));
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave_allreduce(v, OpAdd()); }
+__device__ __forceinline__ float wave_max(float v) { return wave_allreduce(v, OpMax()); }
+__device__ __forceinline__ int wave_min_i(int v) {
+  v = min(v, dpp_i<0x128>(v));
+  v = min(v, dpp_i<0x124>(v));
+  v = min(v, dpp_i<0x122>(v));
+  v = min(v, dpp_i<0x121>(v));
+  const U2 r = swap16((unsigned)v);
+  v = min((int)r.a, (int)r.b);
+  const U2 s = swap32((unsigned)v);
+  return min((int)s.a, (int)s.b);
+}
+// sum over groups of 32 / 16 lanes only (attention: one key row per group)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0x128>(v);
+  v += dpp_f<0x124>(v);
+  v += dpp_f<0x122>(v);
+  v += dpp_f<0x121>(v);
   return v;
 }
+__device__ __forceinline__ float half32_sum(float v) {
+  v = row16_sum(v);
+  const U2 r = swap16(__builtin_bit_cast(unsigned, v));
+  return __builtin_bit_cast(float, r.a) + __builtin_bit_cast(float, r.b);
+}
+// exchange with lane^16 / lane^32 (one VALU op each)
+__device__ __forceinline__ float xor16_f(float v) {
+  const U2 r = swap16(__builtin_bit_cast(unsigned, v));
+  const float a = __builtin_bit_cast(float, r.a), b = __builtin_bit_cast(float, r.b);
+  return ((threadIdx.x >> 4) & 1) ? a : b;
+}
+__device__ __forceinline__ float xor32_f(float v) {
+  const U2 r = swap32(__builtin_bit_cast(unsigned, v));
+  const float a = __builtin_bit_cast(float, r.a), b = __builtin_bit_cast(float, r.b);
+  return ((threadIdx.x >> 5) & 1) ? a : b;
+}
+
 __device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc) {
   acc = fmaf(a.x, b.x, acc);
   acc = fmaf(a.y, b.y, acc);

@@ -3,23 +3,20 @@
 // ssrhip_embed : sum of K codebook embeddings (or one text embedding) + alpha * sinusoidal pe row.
 // ssrhip_sample: everything the reference does on the host between `predict_layer` and the next
 //   `embed` (models/ssr.py:689-761): CFG combine, special-token edits, eog cascade, silence penalty,
-//   temperature / top-k / top-p filtering, one multinomial draw per codebook, stop rules, span hand-over.
+//   temperature / top-k / top-p filtering, one multinomial draw per codebook, stop rules, span hand-over,
+//   and (fused) the embedding of the tokens it just chose, i.e. the next step's input row.
 //   One workgroup per utterance, wave k owns codebook k; the ~2k logits of a codebook live in VGPRs
-//   (<= 34 per lane), top-k / top-p thresholds are found by a 32-step bisection on the order-preserving
-//   integer image of the logits (ballot+popcount for counts, fixed-order wave sums for mass) — no sort,
-//   no atomics, bit-reproducible.  No host round trip per step.
+//   (<= 34 per lane), top-k / top-p thresholds are found by bisection on the order-preserving integer
+//   image of the logits (ballot+popcount for counts, fixed-order DPP wave sums for mass) — no sort, no
+//   atomics, bit-reproducible.  No host round trip per step.
 #include "common.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void embed_kernel(const ssrhip_embed_args a) {
-  const int r = blockIdx.x;
+__device__ __forceinline__ void embed_row(const ssrhip_embed_args& a, int r, int kind, int pos, const int* tok, int t0, int nt) {
   const int D = a.D;
-  const int kind = a.kind ? a.kind[r] : 1;
-  const int pos = a.pos[r];
-  const int* tok = a.tok + (size_t)r * SSRHIP_MAX_CODEBOOKS;
   const float alpha = kind ? a.alpha_audio : a.alpha_text;
-  for (int d = threadIdx.x * 4; d < D; d += 1024) {
+  for (int d = t0 * 4; d < D; d += nt * 4) {
     float4 e;
     if (kind == 0) {
       e = ld4(a.text_emb + (size_t)tok[0] * D + d);
@@ -41,6 +38,11 @@ __global__ __launch_bounds__(256) void embed_kernel(const ssrhip_embed_args a) {
   }
 }
 
+__global__ __launch_bounds__(256) void embed_kernel(const ssrhip_embed_args a) {
+  const int r = blockIdx.x;
+  embed_row(a, r, a.kind ? a.kind[r] : 1, a.pos[r], a.tok + (size_t)r * SSRHIP_MAX_CODEBOOKS, threadIdx.x, 256);
+}
+
 constexpr int MAXE = 34;   // logits per lane: card <= 64*34 = 2176
 
 __device__ __forceinline__ uint32_t okey(float f) {   // order-preserving float -> uint32
@@ -56,6 +58,7 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
 __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a) {
   __shared__ int sh_sample[4];
   __shared__ int sh_argmax0;
+  __shared__ int sh_next[SSRHIP_MAX_CODEBOOKS + 2];   // next tokens, next audio pos, live flag
   const int u = blockIdx.x;
   const ssrhip_sampler_cfg& c = a.cfg[u];
   ssrhip_sampler_state& st = a.state[u];
@@ -74,6 +77,10 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
     const float* lc = a.logits + ((size_t)row0 * K + k) * card;
     const float* lu = lc + (size_t)K * card;
     const bool guided = c.use_cfg && (cfg_tag == c.cfg_stride);
+    bool penal = false;     // silence-repetition penalty applies to logits[0][prev_token] (:726-730)
+    if (k == 0 && num_eog == 0 && c.stop_repetition > 0 && consec > c.stop_repetition)
+      for (int s = 0; s < c.n_silence; ++s) penal |= (c.silence[s] == prev_token);
+    const float npen = (float)(consec - (c.stop_repetition - 1));
     float l[MAXE];
     // ---- CFG combine (:690-696) + edits (:699-730)
 #pragma unroll
@@ -89,14 +96,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
           if (k > num_eog && (i == c.eog || i == c.empty_token)) v = -10000.f;
         } else {
           if (k >= 1 && i == c.eog) v = -10000.f;
-          if (k == 0 && i == prev_token && c.stop_repetition > 0 && consec > c.stop_repetition) {
-            bool sil = false;
-            for (int s = 0; s < c.n_silence; ++s) sil |= (c.silence[s] == prev_token);
-            if (sil) {
-              const float n = (float)(consec - (c.stop_repetition - 1));
-              v = (v < 0.f) ? __fmul_rn(v, n) : __fdiv_rn(v, n);
-            }
-          }
+          if (penal && i == prev_token) v = (v < 0.f) ? __fmul_rn(v, npen) : __fdiv_rn(v, npen);
         }
         if (a.dbg_logits) a.dbg_logits[((size_t)u * K + k) * card + i] = v;
       }
@@ -110,97 +110,116 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
     int am = 0x7fffffff;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) if (l[e] == mx) am = min(am, e * 64 + lane);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) am = min(am, __shfl_xor(am, o, 64));
-    // ---- temperature (:80-81)
+    am = wave_min_i(am);
+    // ---- temperature (:80-81): true division, like the reference
     if (c.temperature != 1.0f) {
 #pragma unroll
       for (int e = 0; e < MAXE; ++e) l[e] = __fdiv_rn(l[e], c.temperature);
-      mx = __fdiv_rn(mx, c.temperature);
-      if (c.temperature < 0.f) {  // not meaningful, keep max consistent
-        mx = -INFINITY;
+      mx = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < MAXE; ++e) mx = fmaxf(mx, l[e]);
-        mx = wave_max(mx);
-      }
+      for (int e = 0; e < MAXE; ++e) mx = fmaxf(mx, l[e]);
+      mx = wave_max(mx);
     }
+    uint32_t key[MAXE];
+    uint32_t kmin = 0xffffffffu;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      key[e] = ((e * 64 + lane) < card && e < ne) ? okey(l[e]) : 0u;   // 0 = below every real key
+      kmin = min(kmin, key[e] ? key[e] : 0xffffffffu);
+    }
+    const uint32_t kmax = okey(mx);
+    // smallest real key of the wave (unsigned min via the order-preserving trick on ints)
+    int kmin_i = (int)(kmin ^ 0x80000000u);
+    kmin_i = wave_min_i(kmin_i);
+    kmin = (uint32_t)kmin_i ^ 0x80000000u;
+    // bisection only needs the bits below the highest bit in which kmin and kmax differ
+    const int hibit = (kmax == kmin) ? -1 : (31 - __clz((int)(kmax ^ kmin)));
+    const uint32_t lowmask = (hibit < 0) ? 0u : ((hibit >= 31) ? 0xffffffffu : ((2u << hibit) - 1u));
+    const uint32_t prefix = kmax & ~lowmask;                                        // common high bits
     // ---- top-k (:38-44): keep logits >= k-th largest value (ties kept)
     uint32_t thr = 0;   // keep keys >= thr
     if (c.top_k > 0) {
       const int kk = min(max(c.top_k, 1), card);
       if (kk == 1) {
-        thr = okey(mx);
+        thr = kmax;
       } else if (kk < card) {
-        uint32_t t = 0;   // largest key with count(keys > t) > kk-1
-        for (int bit = 31; bit >= 0; --bit) {
-          const uint32_t cand = t | (1u << bit);
+        uint32_t t = prefix;   // largest key with count(keys > t) > kk-1, or prefix-1 if none
+        bool any = false;
+        {  // is count(keys > prefix) > kk-1 ? (otherwise the threshold sits at/below prefix: keep all >= kmin)
           int cnt = 0;
 #pragma unroll
-          for (int e = 0; e < MAXE; ++e) cnt += __popcll(__ballot(okey(l[e]) > cand && (e * 64 + lane) < card));
-          if (cnt > kk - 1) t = cand;
+          for (int e = 0; e < MAXE; ++e) cnt += __popcll(__ballot(key[e] > prefix));
+          any = cnt > kk - 1;
         }
-        thr = t + 1;
+        if (any) {
+          for (int bit = hibit; bit >= 0; --bit) {
+            const uint32_t cand = t | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int e = 0; e < MAXE; ++e) cnt += __popcll(__ballot(key[e] > cand));
+            if (cnt > kk - 1) t = cand;
+          }
+          thr = t + 1;
+        } else {
+          thr = kmin;   // count(keys > prefix) <= kk-1: only keys == prefix may be cut; prefix==kmin here
+        }
       }
     }
-    // ---- softmax over the kept set, then top-p (:46-67)
+    // ---- softmax numerators over the kept set, then top-p (:46-67)
     float p[MAXE];
     float Z = 0.f;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
-      const bool keep = (e * 64 + lane) < card && okey(l[e]) >= thr;
-      p[e] = keep ? expf(l[e] - mx) : 0.f;
+      p[e] = (key[e] != 0u && key[e] >= thr) ? __expf(l[e] - mx) : 0.f;
       Z += p[e];
     }
     Z = wave_sum(Z);
     if (c.top_p < 1.0f) {
+      // smallest key t* with mass(keys > t*) <= top_p * Z ; keep keys >= t*
+      const float lim = c.top_p * Z;
+      float m0 = 0.f;
 #pragma unroll
-      for (int e = 0; e < MAXE; ++e) p[e] = __fdiv_rn(p[e], Z);
-      // smallest key t* such that mass(keys > t*) <= top_p ; keep keys >= t*
-      uint32_t t = 0;
-      for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t cand = t | (1u << bit);
-        float m = 0.f;
+      for (int e = 0; e < MAXE; ++e) m0 += (key[e] > prefix) ? p[e] : 0.f;
+      m0 = wave_sum(m0);
+      if (m0 > lim) {
+        uint32_t t = prefix;
+        for (int bit = hibit; bit >= 0; --bit) {
+          const uint32_t cand = t | (1u << bit);
+          float m = 0.f;
 #pragma unroll
-        for (int e = 0; e < MAXE; ++e) m += (okey(l[e]) > cand) ? p[e] : 0.f;
-        m = wave_sum(m);
-        if (m > c.top_p) t = cand;
+          for (int e = 0; e < MAXE; ++e) m += (key[e] > cand) ? p[e] : 0.f;
+          m = wave_sum(m);
+          if (m > lim) t = cand;
+        }
+        thr = max(thr, t + 1);
+#pragma unroll
+        for (int e = 0; e < MAXE; ++e) p[e] = (key[e] >= thr) ? p[e] : 0.f;
       }
-      // is mass(keys > 0) <= top_p already? then everything is kept (t stays 0)
-      const uint32_t thr_p = t + 1;
-      thr = max(thr, thr_p);
-      Z = 0.f;
-#pragma unroll
-      for (int e = 0; e < MAXE; ++e) {
-        const bool keep = (e * 64 + lane) < card && okey(l[e]) >= thr;
-        p[e] = keep ? expf(l[e] - mx) : 0.f;
-        Z += p[e];
-      }
-      Z = wave_sum(Z);
     }
-    // ---- multinomial(softmax, 1) == argmax(prob / q), q ~ Exp(1)   (torch CPU fast path; :85)
+    // ---- multinomial(softmax, 1) == argmax(prob / q), q ~ Exp(1)   (torch CPU fast path; :85).
+    // The positive normaliser does not change the argmax, so it is dropped.
     const float* nz = a.noise ? a.noise + (((size_t)u * c.max_steps + step) * K + k) * card : nullptr;
     float best = -1.f;
     int bi = 0x7fffffff;
+    const uint32_t sd = hash32(c.seed_lo + (uint32_t)step * 0x9E3779B1u) ^ hash32(c.seed_hi + (uint32_t)k * 0x85EBCA6Bu + 0x632BE5ABu);
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
       const int i = e * 64 + lane;
-      if (e < ne && i < card && p[e] > 0.f) {
+      if (p[e] > 0.f) {
         float q;
         if (nz) q = nz[i];
         else {
-          const uint32_t hsh = hash32(hash32(c.seed_lo + (uint32_t)step * 0x9E3779B1u) ^ hash32(c.seed_hi + (uint32_t)(k * card + i) * 0x85EBCA6Bu));
-          q = -logf(((float)(hsh >> 8) + 1.0f) * (1.0f / 16777216.0f));
-          q = fmaxf(q, 1e-30f);
+          const uint32_t hsh = hash32(sd + (uint32_t)i * 0x9E3779B1u);
+          q = fmaxf(-__logf(((float)(hsh >> 8) + 1.0f) * (1.0f / 16777216.0f)), 1e-30f);
         }
-        const float sc = __fdiv_rn(__fdiv_rn(p[e], Z), q);
+        const float sc = __fdividef(p[e], q);
         if (sc > best || (sc == best && i < bi)) { best = sc; bi = i; }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ob = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    {
+      const float wb = wave_max(best);
+      bi = (best == wb) ? bi : 0x7fffffff;
+      bi = wave_min_i(bi);
     }
     if (lane == 0) {
       sh_sample[k] = bi;
@@ -208,53 +227,63 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
     }
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-
-  // ---- state machine (:709-761), single thread
-  int s[SSRHIP_MAX_CODEBOOKS];
-  for (int j = 0; j < K; ++j) s[j] = sh_sample[j];
-  int ne_og = num_eog, cs = consec, pt = prev_token;
-  if (num_eog > 0) {
-    for (int j = 0; j < num_eog; ++j) s[j] = c.empty_token;
-    s[num_eog] = c.eog;
-    ne_og = num_eog + 1;
-  } else {
-    if (s[0] == c.eog || sh_argmax0 == c.eog || (st.audio_pos + 1) > c.text_len * 10) {
-      s[0] = c.eog;
-      ne_og = 1;
+  if (threadIdx.x == 0) {
+    // ---- state machine (:709-761), single thread
+    int s[SSRHIP_MAX_CODEBOOKS];
+    for (int j = 0; j < K; ++j) s[j] = sh_sample[j];
+    int ne_og = num_eog, cs = consec, pt = prev_token;
+    if (num_eog > 0) {
+      for (int j = 0; j < num_eog; ++j) s[j] = c.empty_token;
+      s[num_eog] = c.eog;
+      ne_og = num_eog + 1;
+    } else {
+      if (s[0] == c.eog || sh_argmax0 == c.eog || (st.audio_pos + 1) > c.text_len * 10) {
+        s[0] = c.eog;
+        ne_og = 1;
+      }
+      bool sil = false;
+      for (int j = 0; j < c.n_silence; ++j) sil |= (c.silence[j] == s[0]);
+      cs = (sil && s[0] == pt) ? cs + 1 : 0;
+      pt = s[0];
     }
-    bool sil = false;
-    for (int j = 0; j < c.n_silence; ++j) sil |= (c.silence[j] == s[0]);
-    cs = (sil && s[0] == pt) ? cs + 1 : 0;
-    pt = s[0];
-  }
-  if (c.use_cfg) st.num_cfg_tag = (cfg_tag == c.cfg_stride) ? 1 : cfg_tag + 1;
-  int* gen = a.generated + ((size_t)u * c.max_steps + step) * K;
-  for (int j = 0; j < K; ++j) gen[j] = s[j];
-  st.n_steps = step + 1;
-  st.num_gen = num_gen + 1;
-  st.num_eog = ne_og;
-  st.consec_silence = cs;
-  st.prev_token = pt;
-  bool done = false;
-  if (ne_og == K) {                 // span finished (:753): the all-eog sample is NOT fed back
-    st.span_end[st.span] = step + 1;
-    st.span += 1;
-    if (st.span >= c.n_spans) { st.done = 1; done = true; }
-    else {
-      st.num_gen = 0; st.num_eog = 0; st.num_cfg_tag = 1; st.prev_token = -1; st.consec_silence = 0;
-      for (int j = 0; j < K; ++j) s[j] = c.mts + st.span;   // next span starts from its mask token (:655)
+    if (c.use_cfg) st.num_cfg_tag = (cfg_tag == c.cfg_stride) ? 1 : cfg_tag + 1;
+    int* gen = a.generated + ((size_t)u * c.max_steps + step) * K;
+    for (int j = 0; j < K; ++j) gen[j] = s[j];
+    st.n_steps = step + 1;
+    st.num_gen = num_gen + 1;
+    st.num_eog = ne_og;
+    st.consec_silence = cs;
+    st.prev_token = pt;
+    bool done = false;
+    if (ne_og == K) {                 // span finished (:753): the all-eog sample is NOT fed back
+      st.span_end[st.span] = step + 1;
+      st.span += 1;
+      if (st.span >= c.n_spans) { st.done = 1; done = true; }
+      else {
+        st.num_gen = 0; st.num_eog = 0; st.num_cfg_tag = 1; st.prev_token = -1; st.consec_silence = 0;
+        for (int j = 0; j < K; ++j) s[j] = c.mts + st.span;   // next span starts from its mask token (:655)
+      }
+    }
+    if (!done && step + 1 >= c.max_steps) { st.done = 2; done = true; }
+    sh_next[SSRHIP_MAX_CODEBOOKS + 1] = done ? 0 : 1;
+    if (!done) {
+      st.audio_pos += 1;
+      sh_next[SSRHIP_MAX_CODEBOOKS] = st.audio_pos;
+      for (int j = 0; j < SSRHIP_MAX_CODEBOOKS; ++j) sh_next[j] = (j < K) ? s[j] : 0;
+      for (int rr = 0; rr < rows; ++rr) {
+        const int b = row0 + rr;
+        for (int j = 0; j < SSRHIP_MAX_CODEBOOKS; ++j) a.next_tok[b * SSRHIP_MAX_CODEBOOKS + j] = (j < K) ? s[j] : 0;
+        a.next_pos[b] = st.audio_pos;
+        a.kv_pos[b] += 1;
+        a.row_len[b] = a.kv_pos[b] + 1;
+      }
     }
   }
-  if (!done && step + 1 >= c.max_steps) { st.done = 2; done = true; }
-  if (!done) {
-    st.audio_pos += 1;
-    for (int rr = 0; rr < rows; ++rr) {
-      const int b = row0 + rr;
-      for (int j = 0; j < SSRHIP_MAX_CODEBOOKS; ++j) a.next_tok[b * SSRHIP_MAX_CODEBOOKS + j] = (j < K) ? s[j] : 0;
-      a.next_pos[b] = st.audio_pos;
-      a.kv_pos[b] += 1;
-      a.row_len[b] = a.kv_pos[b] + 1;
+  // ---- fused embedding of the next input row(s) (ssr.py:757-763): saves a launch per step
+  if (a.embed.out) {
+    __syncthreads();
+    if (sh_next[SSRHIP_MAX_CODEBOOKS + 1]) {
+      for (int rr = 0; rr < rows; ++rr) embed_row(a.embed, row0 + rr, 1, sh_next[SSRHIP_MAX_CODEBOOKS], sh_next, threadIdx.x, 256);
     }
   }
 }
@@ -275,6 +304,8 @@ extern "C" int ssrhip_sample(const ssrhip_sample_args* a, ssrhip_stream_t stream
               "ssrhip_sample: null argument");
   SSR_REQUIRE(a->K >= 1 && a->K <= SSRHIP_MAX_CODEBOOKS, "ssrhip_sample: K=%d", a->K);
   SSR_REQUIRE(a->card > 0 && a->card <= 64 * MAXE, "ssrhip_sample: card=%d exceeds %d", a->card, 64 * MAXE);
+  if (a->embed.out) SSR_REQUIRE(a->embed.audio_emb && a->embed.pe && a->embed.D % 4 == 0 && a->embed.K == a->K && a->embed.card == a->card,
+                                "ssrhip_sample: fused embed needs audio_emb, pe, matching K/card");
   hipLaunchKernelGGL(sample_kernel, dim3(a->n_utt), dim3(256), 0, (hipStream_t)stream, *a);
   SSR_LAUNCH_CHECK();
   return 0;

@@ -54,14 +54,15 @@ struct ssrhip_lm {
 
 namespace {
 
-enum { CAT_GEMV = 0, CAT_ATTN = 1, CAT_EMBED = 2, CAT_SAMPLE = 3, N_CAT = 4 };
+enum { CAT_GEMV = 0, CAT_ATTN = 1, CAT_SAMPLE = 2 };
 
-struct Timer {   // optional per-launch event timing
+struct Timer {   // optional per-launch event timing: one accumulator per launch slot of a step
   bool on = false;
   hipStream_t s = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  float ms[N_CAT] = {0, 0, 0, 0};
-  int n[N_CAT] = {0, 0, 0, 0};
+  int slot = 0;
+  std::vector<float> ms;
+  std::vector<int> kind;
 };
 
 #define STEP_CALL(cat, call)                                    \
@@ -74,8 +75,9 @@ struct Timer {   // optional per-launch event timing
       hipEventSynchronize(tm->e1);                              \
       float _ms = 0.f;                                          \
       hipEventElapsedTime(&_ms, tm->e0, tm->e1);                \
-      tm->ms[cat] += _ms;                                       \
-      tm->n[cat] += 1;                                          \
+      if ((int)tm->ms.size() <= tm->slot) { tm->ms.push_back(0.f); tm->kind.push_back(cat); } \
+      tm->ms[tm->slot] += _ms;                                  \
+      tm->slot += 1;                                            \
     }                                                           \
   } while (0)
 
@@ -85,13 +87,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
   const ssrhip_lm_buffers& b = lm->b;
   const int D = d.d_model, B = b.B, K = d.n_codebooks, Hh = d.head_hidden;
 
-  ssrhip_embed_args ea;
-  memset(&ea, 0, sizeof(ea));
-  ea.text_emb = w.text_emb; ea.audio_emb = w.audio_emb; ea.pe = w.pe;
-  ea.alpha_text = w.alpha_text; ea.alpha_audio = w.alpha_audio;
-  ea.tok = b.next_tok; ea.pos = b.next_pos; ea.kind = nullptr;
-  ea.R = B; ea.D = D; ea.K = K; ea.card = d.card; ea.out = b.x;
-  STEP_CALL(CAT_EMBED, ssrhip_embed(&ea, s));
+  if (tm) tm->slot = 0;
 
   for (int l = 0; l < d.n_layer; ++l) {
     ssrhip_gemv_args g;
@@ -157,6 +153,10 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
   sa.cfg = b.cfg; sa.state = b.state; sa.noise = b.noise; sa.generated = b.generated;
   sa.next_tok = b.next_tok; sa.next_pos = b.next_pos; sa.kv_pos = b.kv_pos; sa.row_len = b.row_len;
   sa.dbg_logits = b.dbg_logits;
+  // the sampler also embeds the tokens it chose: x of the next step (no separate embed launch)
+  sa.embed.text_emb = w.text_emb; sa.embed.audio_emb = w.audio_emb; sa.embed.pe = w.pe;
+  sa.embed.alpha_text = w.alpha_text; sa.embed.alpha_audio = w.alpha_audio;
+  sa.embed.R = B; sa.embed.D = D; sa.embed.K = K; sa.embed.card = d.card; sa.embed.out = b.x;
   STEP_CALL(CAT_SAMPLE, ssrhip_sample(&sa, s));
   return 0;
 }
@@ -216,9 +216,8 @@ extern "C" int ssrhip_lm_decode(ssrhip_lm* lm, int32_t n_steps, int32_t use_grap
   return 0;
 }
 
-extern "C" int ssrhip_lm_time_steps(ssrhip_lm* lm, int32_t n_steps, ssrhip_stream_t stream, float* out) {
-  // out[0..3] = avg microseconds per launch of {gemv, attn, embed, sample}; out[4..7] = launches per step
-  SSR_REQUIRE(lm && n_steps > 0 && out, "ssrhip_lm_time_steps: bad argument");
+extern "C" int ssrhip_lm_time_steps(ssrhip_lm* lm, int32_t n_steps, ssrhip_stream_t stream, float* out_us, int32_t* out_kind, int32_t n_out) {
+  SSR_REQUIRE(lm && n_steps > 0 && out_us && out_kind, "ssrhip_lm_time_steps: bad argument");
   Timer tm;
   tm.on = true;
   tm.s = (hipStream_t)stream;
@@ -229,11 +228,10 @@ extern "C" int ssrhip_lm_time_steps(ssrhip_lm* lm, int32_t n_steps, ssrhip_strea
   hipEventDestroy(tm.e0);
   hipEventDestroy(tm.e1);
   if (rc) return rc;
-  for (int c = 0; c < N_CAT; ++c) {
-    out[c] = tm.n[c] ? 1000.f * tm.ms[c] / tm.n[c] : 0.f;
-    out[4 + c] = (float)tm.n[c] / n_steps;
-  }
-  return 0;
+  const int n = (int)tm.ms.size();
+  SSR_REQUIRE(n <= n_out, "ssrhip_lm_time_steps: %d slots > n_out=%d", n, n_out);
+  for (int i = 0; i < n; ++i) { out_us[i] = 1000.f * tm.ms[i] / n_steps; out_kind[i] = tm.kind[i]; }
+  return n;
 }
 
 extern "C" int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ssrhip_stream_t stream) {
@@ -285,5 +283,12 @@ extern "C" int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ss
     g.M = R; g.N = D; g.K = d.d_ffn; g.lda = d.d_ffn; g.ldc = D; g.residual = 1;
     if (int rc = ssrhip_gemm(&g, s)) return rc;
   }
-  return 0;
+  // x of the first decode step: the rows' pending input tokens (the span-0 mask token, ssr.py:655-662)
+  const ssrhip_lm_buffers& b = lm->b;
+  memset(&ea, 0, sizeof(ea));
+  ea.text_emb = w.text_emb; ea.audio_emb = w.audio_emb; ea.pe = w.pe;
+  ea.alpha_text = w.alpha_text; ea.alpha_audio = w.alpha_audio;
+  ea.tok = b.next_tok; ea.pos = b.next_pos; ea.kind = nullptr;
+  ea.R = b.B; ea.D = D; ea.K = d.n_codebooks; ea.card = d.card; ea.out = b.x;
+  return ssrhip_embed(&ea, s);
 }

@@ -2,15 +2,20 @@
 //
 //   y[b][n] = epi( sum_k pro(x)[b][k] * W[n][k] + bias[n] )
 //
-// Roofline: HBM-bound. Every weight byte is read exactly once per step (2*B FLOP per 4 bytes),
-// so the kernel is organised around keeping 16-byte non-temporal loads in flight:
+// Roofline: HBM-bound. Every weight byte is read exactly once per step (2*B FLOP per 4 bytes), so the
+// kernel is organised around keeping 16-byte non-temporal loads in flight from the first cycle:
 //   * a wave owns whole weight rows (or one <=2048-float slice of them when K > 2048); its slice of
 //     x (<= 8 float4 per lane per batch row) lives in VGPRs for the whole kernel;
-//   * a row is 8 x global_load_dwordx4 per lane (1 KiB per wave-instruction, fully coalesced), two
-//     rows are issued back to back before the FMAs so 16 KiB per wave are in flight;
+//   * a row slice is 8 x global_load_dwordx4 per lane (1 KiB per wave-instruction, fully coalesced);
+//     rows are software-pipelined two deep (ping-pong register sets): the loads of row i+1 are issued
+//     before the FMAs of row i, and the FIRST row is requested before the prologue runs, so the
+//     LayerNorm / split-KV-combine prologue overlaps HBM latency instead of preceding it;
+//   * the grid is sized to be fully resident (<= 3 workgroups of 4 waves per CU) and rows are dealt
+//     round-robin, so every wave streams a similar number of bytes and there is no second "wave" of
+//     workgroups paying the prologue again;
 //   * no LDS on the weight path (each weight element is used once: staging would be pure overhead);
-//     LDS is used only to share the prologue (LayerNorm / split-KV combine) between the 4 waves and
-//     to add the K-slices of one row.
+//     LDS only shares the prologue result between the 4 waves and adds the K-slices of one row;
+//   * wave reductions are DPP/permlane (no ds_bpermute).
 // Replaces F.linear (+LayerNorm / ReLU / GELU / residual) of the reference: see include/ssrhip.h.
 #include "common.h"
 
@@ -21,32 +26,43 @@ struct GemvK {
   int nslice;     // waves cooperating on one row (K split), 1|2|4
   int slice_len;  // floats per slice (multiple of 4)
   int nch;        // float4 chunks per lane per slice (<= 8)
-  int rpw;        // rows per wave-group
+  int groups_x;   // wave-groups along N (= gridDim.x * 4/nslice)
   int hd;         // head_dim (QKV epilogue / combine prologue)
 };
 
 constexpr int MAXCH = 8;
-constexpr int MAX_RPW = 8;
+constexpr int MAX_IT = 8;   // max rows per wave-group when K is split (LDS partials)
 
+constexpr int NJ = 4;   // float4 per thread per row in the LayerNorm prologue (K <= 4096)
+
+// LayerNorm prologue, split so that the x loads are issued BEFORE the first weight row and consumed
+// after it (loads return in order per wave: x first, then the weight row keeps flying during the math).
 template <int B>
-__device__ __forceinline__ void stage_layernorm(const GemvK& p, int g, float* xs, float* red) {
-  // LayerNorm of B rows of length K into xs[B][K]; biased variance, eps inside the sqrt
-  // (F.layer_norm, models/modules/transformer.py:58-75). Two-pass (mean, then centered squares).
-  const int K = p.a.K;
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  float s[B];
+__device__ __forceinline__ void ln_issue(const GemvK& p, int g, float4 (&xv)[B][NJ]) {
+  const int K = p.a.K, t = threadIdx.x;
 #pragma unroll
   for (int b = 0; b < B; ++b) {
-    s[b] = 0.f;
     const float* xb = p.a.x + (size_t)b * p.a.x_stride + (size_t)g * K;
-    for (int k = t * 4; k < K; k += 1024) {
-      float4 v = ld4(xb + k);
-      *reinterpret_cast<float4*>(xs + b * K + k) = v;
-      s[b] += (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int k = t * 4 + j * 1024;
+      xv[b][j] = (k < K) ? ld4(xb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    s[b] = wave_sum(s[b]);
-    if (lane == 0) red[b * 4 + wave] = s[b];
+  }
+}
+
+template <int B>
+__device__ __forceinline__ void ln_finish(const GemvK& p, float4 (&xv)[B][NJ], float* xs, float* red) {
+  // biased variance, eps inside the sqrt (F.layer_norm, models/modules/transformer.py:58-75);
+  // two-pass (mean, then centered squares), values stay in registers between the passes.
+  const int K = p.a.K, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s += (xv[b][j].x + xv[b][j].y) + (xv[b][j].z + xv[b][j].w);   // zero beyond K
+    s = wave_sum(s);
+    if (lane == 0) red[b * 4 + wave] = s;
   }
   __syncthreads();
   float mean[B];
@@ -56,10 +72,12 @@ __device__ __forceinline__ void stage_layernorm(const GemvK& p, int g, float* xs
 #pragma unroll
   for (int b = 0; b < B; ++b) {
     float q = 0.f;
-    for (int k = t * 4; k < K; k += 1024) {
-      float4 v = *reinterpret_cast<float4*>(xs + b * K + k);
-      float dx = v.x - mean[b], dy = v.y - mean[b], dz = v.z - mean[b], dw = v.w - mean[b];
-      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (t * 4 + j * 1024 < K) {
+        const float dx = xv[b][j].x - mean[b], dy = xv[b][j].y - mean[b], dz = xv[b][j].z - mean[b], dw = xv[b][j].w - mean[b];
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
     }
     q = wave_sum(q);
     if (lane == 0) red[b * 4 + wave] = q;
@@ -69,14 +87,18 @@ __device__ __forceinline__ void stage_layernorm(const GemvK& p, int g, float* xs
   for (int b = 0; b < B; ++b) {
     const float var = ((red[b * 4 + 0] + red[b * 4 + 1]) + (red[b * 4 + 2] + red[b * 4 + 3])) / (float)K;
     const float rstd = 1.0f / sqrtf(var + p.a.ln_eps);
-    for (int k = t * 4; k < K; k += 1024) {
-      float4 v = *reinterpret_cast<float4*>(xs + b * K + k);
-      const float4 w = ld4(p.a.ln_w + k), bb = ld4(p.a.ln_b + k);
-      v.x = (v.x - mean[b]) * rstd * w.x + bb.x;
-      v.y = (v.y - mean[b]) * rstd * w.y + bb.y;
-      v.z = (v.z - mean[b]) * rstd * w.z + bb.z;
-      v.w = (v.w - mean[b]) * rstd * w.w + bb.w;
-      *reinterpret_cast<float4*>(xs + b * K + k) = v;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int k = t * 4 + j * 1024;
+      if (k < K) {
+        float4 v = xv[b][j];
+        const float4 w = ld4(p.a.ln_w + k), bb = ld4(p.a.ln_b + k);
+        v.x = (v.x - mean[b]) * rstd * w.x + bb.x;
+        v.y = (v.y - mean[b]) * rstd * w.y + bb.y;
+        v.z = (v.z - mean[b]) * rstd * w.z + bb.z;
+        v.w = (v.w - mean[b]) * rstd * w.w + bb.w;
+        *reinterpret_cast<float4*>(xs + b * K + k) = v;
+      }
     }
   }
   __syncthreads();
@@ -140,7 +162,7 @@ __device__ __forceinline__ void finalize(const GemvK& p, int g, int n, int b, fl
   }
 }
 
-template <int B, bool FULL>
+template <bool FULL>
 __device__ __forceinline__ void load_row(float4 (&w)[MAXCH], const float* wrow, int lane, int nch, int len) {
 #pragma unroll
   for (int i = 0; i < MAXCH; ++i) {
@@ -152,8 +174,30 @@ __device__ __forceinline__ void load_row(float4 (&w)[MAXCH], const float* wrow, 
   }
 }
 
+// one row slice: FMAs against the register-resident x, wave all-reduce, lanes 0..B-1 hand the result on
 template <int B>
-__global__ __launch_bounds__(256) void gemv_kernel(const GemvK p) {
+__device__ __forceinline__ void consume_row(const GemvK& p, const float4 (&w)[MAXCH], const float4 (&xr)[B][MAXCH], int g, int n,
+                                            int it, int lane, int wave, float* part) {
+  float mine = 0.f;
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    float s0 = 0.f, s1 = 0.f;   // two chains for ILP
+#pragma unroll
+    for (int i = 0; i < MAXCH; i += 2) {
+      if (i < p.nch) s0 = dot4(w[i], xr[b][i], s0);
+      if (i + 1 < p.nch) s1 = dot4(w[i + 1], xr[b][i + 1], s1);
+    }
+    const float s = wave_sum(s0 + s1);
+    if (lane == b) mine = s;
+  }
+  if (lane < B) {
+    if (p.nslice == 1) finalize(p, g, n, lane, mine);
+    else part[(wave * MAX_IT + it) * B + lane] = mine;
+  }
+}
+
+template <int B>
+__global__ __launch_bounds__(256, (B <= 2) ? 3 : 2) void gemv_kernel(const GemvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const ssrhip_gemv_args& a = p.a;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -163,13 +207,26 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvK p) {
   const int k0 = slice * p.slice_len;
   const int len = min(p.slice_len, K - k0);   // floats in this wave's slice (may be <= 0 for tiny K)
   const bool full = (len == p.nch * 256);
+  const int G = blockIdx.x * n_rg + rg;        // this wave-group's first row; then += groups_x
+  const float* Wg = a.W + (size_t)g * N * K + k0;
+
+  // ---- LayerNorm prologue: its (L2-resident) x loads go out first ...
+  float4 xv[B][NJ];
+  if (a.pro == SSRHIP_PRO_LAYERNORM) ln_issue<B>(p, g, xv);
+  // ---- ... then the first weight row is requested, before any prologue math
+  float4 wa[MAXCH], wb[MAXCH];
+  int n = G;
+  if (n < N) {
+    if (full) load_row<true>(wa, Wg + (size_t)n * K, lane, p.nch, len);
+    else load_row<false>(wa, Wg + (size_t)n * K, lane, p.nch, len);
+  }
 
   // ---- prologue: this wave's slice of x into registers
   float4 xr[B][MAXCH];
-  float* part = smem;                          // [4 waves][MAX_RPW][B] cross-slice partials
-  float* xs = smem + 4 * MAX_RPW * B + 16;     // staged x (LayerNorm / combine prologues)
+  float* part = smem;                          // [4 waves][MAX_IT][B] cross-slice partials
+  float* xs = smem + 4 * MAX_IT * B + 16;      // staged x (LayerNorm / combine prologues)
   if (a.pro == SSRHIP_PRO_LAYERNORM) {
-    stage_layernorm<B>(p, g, xs, smem);        // `red` aliases `part`: not live yet
+    ln_finish<B>(p, xv, xs, smem);             // `red` aliases `part`: not live yet
   } else if (a.pro == SSRHIP_PRO_ATTN_COMBINE) {
     stage_attn_combine<B>(p, xs);
   }
@@ -183,64 +240,44 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvK p) {
     }
   }
 
-  // ---- main loop: rows [n0, n1) of this wave-group, two rows in flight
-  const int G = blockIdx.x * n_rg + rg;
-  const int n0 = G * p.rpw, n1 = min(N, n0 + p.rpw);
-  const float* Wg = a.W + (size_t)g * N * K + k0;
-  for (int n = n0; n < n1; n += 2) {
-    const bool two = (n + 1 < n1);
-    float4 w0[MAXCH], w1[MAXCH];
-    if (full) {
-      load_row<B, true>(w0, Wg + (size_t)n * K, lane, p.nch, len);
-      if (two) load_row<B, true>(w1, Wg + (size_t)(n + 1) * K, lane, p.nch, len);
-    } else {
-      load_row<B, false>(w0, Wg + (size_t)n * K, lane, p.nch, len);
-      if (two) load_row<B, false>(w1, Wg + (size_t)(n + 1) * K, lane, p.nch, len);
+  // ---- main loop: ping-pong over this wave-group's rows
+  int it = 0;
+  while (n < N) {
+    int n2 = n + p.groups_x;
+    if (n2 < N) {
+      if (full) load_row<true>(wb, Wg + (size_t)n2 * K, lane, p.nch, len);
+      else load_row<false>(wb, Wg + (size_t)n2 * K, lane, p.nch, len);
     }
-    float acc[2][B];
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-      for (int i = 0; i < MAXCH; ++i) {
-        if (i < p.nch) {
-          s0 = dot4(w0[i], xr[b][i], s0);
-          if (two) s1 = dot4(w1[i], xr[b][i], s1);
-        }
-      }
-      acc[0][b] = wave_sum(s0);
-      acc[1][b] = two ? wave_sum(s1) : 0.f;
+    consume_row<B>(p, wa, xr, g, n, it, lane, wave, part);
+    ++it;
+    n = n2;
+    if (n >= N) break;
+    n2 = n + p.groups_x;
+    if (n2 < N) {
+      if (full) load_row<true>(wa, Wg + (size_t)n2 * K, lane, p.nch, len);
+      else load_row<false>(wa, Wg + (size_t)n2 * K, lane, p.nch, len);
     }
-    // lanes 0..2B-1 each own one (row, b) result
-    float mine = 0.f;
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int b = 0; b < B; ++b)
-        if (lane == r * B + b) mine = acc[r][b];
-    if (lane < 2 * B) {
-      const int r = lane / B, b = lane % B;
-      if (n + r < n1) {
-        if (p.nslice == 1) finalize(p, g, n + r, b, mine);
-        else part[(wave * MAX_RPW + (n - n0) + r) * B + b] = mine;
-      }
-    }
+    consume_row<B>(p, wb, xr, g, n, it, lane, wave, part);
+    ++it;
+    n = n2;
   }
   if (p.nslice > 1) {
     __syncthreads();
-    // thread t -> (rg, r, b); sum the slices in a fixed order
+    // thread t -> (rg, it, b); sum the slices in a fixed order
     const int t = threadIdx.x;
-    if (t < n_rg * p.rpw * B) {
-      const int b = t % B, r = (t / B) % p.rpw, rg2 = t / (B * p.rpw);
-      const int n = (blockIdx.x * n_rg + rg2) * p.rpw + r;
-      if (n < N) {
+    if (t < n_rg * MAX_IT * B) {
+      const int b = t % B, i2 = (t / B) % MAX_IT, rg2 = t / (B * MAX_IT);
+      const int nn = (blockIdx.x * n_rg + rg2) + i2 * p.groups_x;
+      if (nn < N) {
         float v = 0.f;
-        for (int s = 0; s < p.nslice; ++s) v += part[((rg2 * p.nslice + s) * MAX_RPW + r) * B + b];
-        finalize(p, g, n, b, v);
+        for (int s = 0; s < p.nslice; ++s) v += part[((rg2 * p.nslice + s) * MAX_IT + i2) * B + b];
+        finalize(p, g, nn, b, v);
       }
     }
   }
 }
+
+int g_num_cu = 0;
 
 }  // namespace
 
@@ -249,6 +286,11 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a->B == 1 || a->B == 2 || a->B == 4, "ssrhip_gemv: B=%d not in {1,2,4}", a->B);
   SSR_REQUIRE(a->K > 0 && a->K % 4 == 0 && a->K <= 8192, "ssrhip_gemv: K=%d must be a multiple of 4, <= 8192", a->K);
   SSR_REQUIRE(a->N > 0 && a->groups >= 1, "ssrhip_gemv: bad N/groups");
+  if (g_num_cu == 0) {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) g_num_cu = cu;
+    else g_num_cu = 256;
+  }
   GemvK p;
   p.a = *a;
   p.nslice = a->K <= 2048 ? 1 : (a->K <= 4096 ? 2 : 4);
@@ -256,15 +298,19 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   p.nch = (p.slice_len + 255) / 256;
   SSR_REQUIRE(p.nch <= MAXCH, "ssrhip_gemv: slice too long");
   const int n_rg = 4 / p.nslice;
-  int rpw = (a->N + 1024 * n_rg - 1) / (1024 * n_rg);
-  if (rpw > 1 && (rpw & 1)) ++rpw;
-  if (rpw > MAX_RPW) rpw = MAX_RPW;
-  p.rpw = rpw;
+  // resident grid: <= 3 workgroups per CU in total (over all groups); rows dealt round-robin to wave-groups
+  int max_blocks_x = (3 * g_num_cu) / a->groups;
+  if (max_blocks_x < 1) max_blocks_x = 1;
+  int rows_per_group = (a->N + max_blocks_x * n_rg - 1) / (max_blocks_x * n_rg);
+  if (p.nslice > 1 && rows_per_group > MAX_IT) rows_per_group = MAX_IT;   // more (non-resident) blocks instead
+  const int groups_x = (a->N + rows_per_group - 1) / rows_per_group;
+  const int blocks_x = (groups_x + n_rg - 1) / n_rg;
+  p.groups_x = blocks_x * n_rg;
   p.hd = (a->kv.head_dim > 0) ? a->kv.head_dim : 1;
-  size_t smem = (4 * MAX_RPW * a->B + 16) * sizeof(float);
+  size_t smem = (4 * MAX_IT * a->B + 16) * sizeof(float);
   if (a->pro != SSRHIP_PRO_NONE) {
     SSR_REQUIRE(a->groups == 1 || a->pro == SSRHIP_PRO_LAYERNORM, "ssrhip_gemv: combine prologue needs groups==1");
-    SSR_REQUIRE((size_t)a->B * a->K * 4 <= 96 * 1024, "ssrhip_gemv: staged prologue needs B*K*4 <= 96 KiB");
+    SSR_REQUIRE((size_t)a->B * a->K * 4 <= 60 * 1024 && a->K <= 4096, "ssrhip_gemv: staged prologue needs B*K*4 <= 60 KiB and K <= 4096");
     smem += (size_t)a->B * a->K * sizeof(float);
     if (a->pro == SSRHIP_PRO_LAYERNORM) SSR_REQUIRE(a->ln_w && a->ln_b && a->x, "ssrhip_gemv: LayerNorm prologue needs x, ln_w, ln_b");
     if (a->pro == SSRHIP_PRO_ATTN_COMBINE) {
@@ -278,7 +324,7 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
     SSR_REQUIRE(a->N == 3 * a->K && a->groups == 1 && a->kv.pool && a->kv.table && a->kv_pos && a->kv.head_dim > 0,
                 "ssrhip_gemv: QKV epilogue needs N==3K and a kv cache");
   }
-  dim3 grid((a->N + rpw * n_rg - 1) / (rpw * n_rg), a->groups);
+  dim3 grid(blocks_x, a->groups);
   hipStream_t s = (hipStream_t)stream;
   switch (a->B) {
     case 1: hipLaunchKernelGGL(gemv_kernel<1>, grid, dim3(256), smem, s, p); break;

@@ -302,7 +302,13 @@ class DecodeEngine:
         return self.states()
 
     def time_kernels(self, n_steps: int):
-        out = (C.c_float * 8)()
-        _lib.check(self.lib.ssrhip_lm_time_steps(self._ctx, int(n_steps), _lib.stream_ptr(), out), "ssrhip_lm_time_steps")
-        names = ("gemv", "attn", "embed", "sample")
-        return {n: dict(us_per_launch=out[i], launches_per_step=out[4 + i]) for i, n in enumerate(names)}
+        """Event-timed eager steps: list of (kind, avg_us) per launch slot of one decode step
+        (kind: 'gemv' | 'attn' | 'sample')."""
+        n_out = 8 * self.a.L + 16
+        us = (C.c_float * n_out)()
+        kind = (C.c_int32 * n_out)()
+        n = self.lib.ssrhip_lm_time_steps(self._ctx, int(n_steps), _lib.stream_ptr(), us, kind, n_out)
+        if n < 0:
+            _lib.check(n, "ssrhip_lm_time_steps")
+        names = ("gemv", "attn", "sample")
+        return [(names[kind[i]], float(us[i])) for i in range(n)]
