@@ -73,34 +73,68 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
   const int prev_token = st.prev_token, consec = st.consec_silence;
   const int step = st.n_steps;
 
+  // cfg fields are copied to registers once: the dbg_logits stores below may alias `c` as far as the
+  // compiler knows, which would otherwise force a scalar reload of every field after every store
+  const int c_eos = c.eos, c_sos = c.sos, c_mts = c.mts, c_mts_end = c.mts + c.max_n_spans;
+  const int c_empty = c.empty_token, c_eog = c.eog, c_topk = c.top_k, c_stoprep = c.stop_repetition;
+  const float c_topp = c.top_p, c_temp = c.temperature, c_coef = c.cfg_coef, c_om = c.cfg_one_minus;
+  const int c_maxsteps = c.max_steps, c_nsil = c.n_silence;
+  const uint32_t c_seedlo = c.seed_lo, c_seedhi = c.seed_hi;
+
   if (k < K) {
     const float* lc = a.logits + ((size_t)row0 * K + k) * card;
     const float* lu = lc + (size_t)K * card;
     const bool guided = c.use_cfg && (cfg_tag == c.cfg_stride);
     bool penal = false;     // silence-repetition penalty applies to logits[0][prev_token] (:726-730)
-    if (k == 0 && num_eog == 0 && c.stop_repetition > 0 && consec > c.stop_repetition)
-      for (int s = 0; s < c.n_silence; ++s) penal |= (c.silence[s] == prev_token);
-    const float npen = (float)(consec - (c.stop_repetition - 1));
-    float l[MAXE];
-    // ---- CFG combine (:690-696) + edits (:699-730)
+    if (k == 0 && num_eog == 0 && c_stoprep > 0 && consec > c_stoprep)
+      for (int s = 0; s < c_nsil; ++s) penal |= (c.silence[s] == prev_token);
+    const float npen = (float)(consec - (c_stoprep - 1));
+    const bool force_empty = (num_gen < K - 1) && (k > num_gen);     // :705-707
+    const bool cut_eog_empty = (num_eog > 0) && (k > num_eog);       // :710-712
+    const bool cut_eog = (num_eog == 0) && (k >= 1);                 // :722-723
+    float* dbg = a.dbg_logits ? a.dbg_logits + ((size_t)u * K + k) * card : nullptr;
+    // CFG combine + special-token edits of one logit, branch-free
+    auto edit = [&](int i, float vc, float vu) -> float {
+      float v = guided ? __fadd_rn(__fmul_rn(c_coef, vc), __fmul_rn(c_om, vu)) : vc;
+      const bool special = (i == c_eos) | (i == c_sos) | ((i >= c_mts) & (i < c_mts_end));
+      v = special ? -10000.f : v;
+      v = (force_empty & (i == c_empty)) ? 10000.f : v;
+      v = (cut_eog_empty & ((i == c_eog) | (i == c_empty))) ? -10000.f : v;
+      v = (cut_eog & (i == c_eog)) ? -10000.f : v;
+      return v;
+    };
+    // the one penalised entry is computed up front (one IEEE division per wave, not per element)
+    int pen_idx = -1;
+    float pen_val = 0.f;
+    if (penal && prev_token >= 0 && prev_token < card) {
+      const float v = edit(prev_token, lc[prev_token], guided ? lu[prev_token] : 0.f);
+      pen_val = (v < 0.f) ? __fmul_rn(v, npen) : __fdiv_rn(v, npen);
+      pen_idx = prev_token;
+    }
+    // all loads first (no store in between: the optional dbg store could alias them and would serialise
+    // 2x34 dependent L2 round trips), then the edits, then the optional debug dump
+    float l[MAXE], lun[MAXE];
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
       const int i = e * 64 + lane;
-      float v = -INFINITY;
-      if (e < ne && i < card) {
-        v = lc[i];
-        if (guided) v = __fadd_rn(__fmul_rn(c.cfg_coef, v), __fmul_rn(c.cfg_one_minus, lu[i]));
-        if (i == c.eos || i == c.sos || (i >= c.mts && i < c.mts + c.max_n_spans)) v = -10000.f;
-        if (num_gen < K - 1 && k > num_gen && i == c.empty_token) v = 10000.f;
-        if (num_eog > 0) {
-          if (k > num_eog && (i == c.eog || i == c.empty_token)) v = -10000.f;
-        } else {
-          if (k >= 1 && i == c.eog) v = -10000.f;
-          if (penal && i == prev_token) v = (v < 0.f) ? __fmul_rn(v, npen) : __fdiv_rn(v, npen);
-        }
-        if (a.dbg_logits) a.dbg_logits[((size_t)u * K + k) * card + i] = v;
+      const int ic = ((e < ne) && (i < card)) ? i : 0;
+      l[e] = lc[ic];
+      lun[e] = guided ? lu[ic] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const int i = e * 64 + lane;
+      const bool valid = (e < ne) && (i < card);
+      float v = edit(i, l[e], lun[e]);
+      v = (i == pen_idx) ? pen_val : v;
+      l[e] = valid ? v : -INFINITY;
+    }
+    if (dbg) {
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) {
+        const int i = e * 64 + lane;
+        if ((e < ne) && (i < card)) dbg[i] = l[e];
       }
-      l[e] = v;
     }
     // ---- argmax of the edited logits (first index on ties), needed for the stop rule :739
     float mx = -INFINITY;
@@ -112,9 +146,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
     for (int e = 0; e < MAXE; ++e) if (l[e] == mx) am = min(am, e * 64 + lane);
     am = wave_min_i(am);
     // ---- temperature (:80-81): true division, like the reference
-    if (c.temperature != 1.0f) {
+    if (c_temp != 1.0f) {
 #pragma unroll
-      for (int e = 0; e < MAXE; ++e) l[e] = __fdiv_rn(l[e], c.temperature);
+      for (int e = 0; e < MAXE; ++e) l[e] = __fdiv_rn(l[e], c_temp);
       mx = -INFINITY;
 #pragma unroll
       for (int e = 0; e < MAXE; ++e) mx = fmaxf(mx, l[e]);
@@ -138,8 +172,8 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
     const uint32_t prefix = kmax & ~lowmask;                                        // common high bits
     // ---- top-k (:38-44): keep logits >= k-th largest value (ties kept)
     uint32_t thr = 0;   // keep keys >= thr
-    if (c.top_k > 0) {
-      const int kk = min(max(c.top_k, 1), card);
+    if (c_topk > 0) {
+      const int kk = min(max(c_topk, 1), card);
       if (kk == 1) {
         thr = kmax;
       } else if (kk < card) {
@@ -174,9 +208,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
       Z += p[e];
     }
     Z = wave_sum(Z);
-    if (c.top_p < 1.0f) {
+    if (c_topp < 1.0f) {
       // smallest key t* with mass(keys > t*) <= top_p * Z ; keep keys >= t*
-      const float lim = c.top_p * Z;
+      const float lim = c_topp * Z;
       float m0 = 0.f;
 #pragma unroll
       for (int e = 0; e < MAXE; ++e) m0 += (key[e] > prefix) ? p[e] : 0.f;
@@ -198,23 +232,23 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
     }
     // ---- multinomial(softmax, 1) == argmax(prob / q), q ~ Exp(1)   (torch CPU fast path; :85).
     // The positive normaliser does not change the argmax, so it is dropped.
-    const float* nz = a.noise ? a.noise + (((size_t)u * c.max_steps + step) * K + k) * card : nullptr;
+    const float* nz = a.noise ? a.noise + (((size_t)u * c_maxsteps + step) * K + k) * card : nullptr;
     float best = -1.f;
     int bi = 0x7fffffff;
-    const uint32_t sd = hash32(c.seed_lo + (uint32_t)step * 0x9E3779B1u) ^ hash32(c.seed_hi + (uint32_t)k * 0x85EBCA6Bu + 0x632BE5ABu);
+    const uint32_t sd = hash32(c_seedlo + (uint32_t)step * 0x9E3779B1u) ^ hash32(c_seedhi + (uint32_t)k * 0x85EBCA6Bu + 0x632BE5ABu);
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
       const int i = e * 64 + lane;
-      if (p[e] > 0.f) {
-        float q;
-        if (nz) q = nz[i];
-        else {
-          const uint32_t hsh = hash32(sd + (uint32_t)i * 0x9E3779B1u);
-          q = fmaxf(-__logf(((float)(hsh >> 8) + 1.0f) * (1.0f / 16777216.0f)), 1e-30f);
-        }
-        const float sc = __fdividef(p[e], q);
-        if (sc > best || (sc == best && i < bi)) { best = sc; bi = i; }
+      float q;
+      if (nz) q = nz[(key[e] != 0u) ? i : 0];                         // wave-uniform branch
+      else {
+        const uint32_t hsh = hash32(sd + (uint32_t)i * 0x9E3779B1u);
+        q = fmaxf(-__logf(((float)(hsh >> 8) + 1.0f) * (1.0f / 16777216.0f)), 1e-30f);
       }
+      const float sc = (p[e] > 0.f) ? __fdividef(p[e], q) : -1.f;
+      const bool better = sc > best;                                   // e ascending => first index wins ties
+      best = better ? sc : best;
+      bi = better ? i : bi;
     }
     {
       const float wb = wave_max(best);

@@ -104,32 +104,103 @@ __device__ __forceinline__ void ln_finish(const GemvK& p, float4 (&xv)[B][NJ], f
   __syncthreads();
 }
 
+// splits (pages) whose partial outputs are prefetched ahead of the weight row (register budget: B*2*CS float4)
+template <int B> struct CSof { static constexpr int v = (B <= 2) ? 8 : 2; };
+
+// Split-KV combine prologue (merge of ssrhip_attn_decode's per-page partials):
+//   out[b][h][:] = sum_s w_s * o_s,  w_s = e^{m_s-M} l-normalised:  e^{m_s-M} / sum_t e^{m_t-M} l_t
+// Split like the LayerNorm prologue: ALL loads (the (m,l) pairs of every (row, head) and the first CS
+// partial outputs of this thread's two float4 columns) are issued before the first weight row, the math
+// runs while that row is in flight. Threads 0..B*H-1 turn (m,l) into the weights w_s once per block (LDS).
 template <int B>
-__device__ __forceinline__ void stage_attn_combine(const GemvK& p, float* xs) {
-  // Merge the per-page partials of ssrhip_attn_decode: out = sum_s e^{m_s-M} o_s / sum_s e^{m_s-M} l_s
-  const int K = p.a.K, hd = p.hd, H = K / hd, MS = p.a.max_splits;
-  for (int e = threadIdx.x * 4; e < K; e += 1024) {
-    const int h = e / hd, d = e % hd;
+struct CombineRegs {
+  static constexpr int CS = CSof<B>::v;
+  float4 o[B][2][CS];
+  float4 ml[CS / 2];      // CS (m,l) pairs of the (row, head) this thread owns in the weight table
+};
+
+template <int B>
+__device__ __forceinline__ void combine_issue(const GemvK& p, CombineRegs<B>& r, const int (&ns)[B]) {
+  constexpr int CS = CSof<B>::v;
+  const int K = p.a.K, hd = p.hd, H = K / hd, MS = p.a.max_splits, t = threadIdx.x;
+  if (t < B * H) {
+    const float* ml = p.a.part_ml + (size_t)t * MS * 2;
+    const int n = ns[t / H];
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const int ns = (p.a.row_len[b] + SSRHIP_PAGE - 1) / SSRHIP_PAGE;
-      const float* ml = p.a.part_ml + ((size_t)b * H + h) * MS * 2;
-      const float* po = p.a.part_o + (((size_t)b * H + h) * MS) * hd + d;
-      float M = -INFINITY;
-      for (int s = 0; s < ns; ++s) M = fmaxf(M, ml[2 * s]);
-      float den = 0.f;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s = 0; s < ns; ++s) {
-        const float w = expf(ml[2 * s] - M);
-        den = fmaf(w, ml[2 * s + 1], den);
-        const float4 o = ld4(po + (size_t)s * hd);
-        acc.x = fmaf(w, o.x, acc.x);
-        acc.y = fmaf(w, o.y, acc.y);
-        acc.z = fmaf(w, o.z, acc.z);
-        acc.w = fmaf(w, o.w, acc.w);
+    for (int i = 0; i < CS / 2; ++i) r.ml[i] = (2 * i < n) ? ld4(ml + 4 * i) : make_float4(-INFINITY, 0.f, -INFINITY, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = t * 4 + j * 1024;
+    if (e < K) {
+      const int h = e / hd, d = e % hd;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const float* po = p.a.part_o + (((size_t)b * H + h) * MS) * hd + d;
+#pragma unroll
+        for (int s2 = 0; s2 < CS; ++s2) r.o[b][j][s2] = (s2 < ns[b]) ? ld4(po + (size_t)s2 * hd) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      const float inv = 1.0f / den;
-      *reinterpret_cast<float4*>(xs + b * K + e) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+  }
+}
+
+template <int B>
+__device__ __forceinline__ void combine_finish(const GemvK& p, CombineRegs<B>& r, const int (&ns)[B], float* xs, float* wtab) {
+  constexpr int CS = CSof<B>::v;
+  const int K = p.a.K, hd = p.hd, H = K / hd, MS = p.a.max_splits, t = threadIdx.x;
+  if (t < B * H) {          // weights of (row, head) = t
+    const int n = ns[t / H];
+    const float* ml = p.a.part_ml + (size_t)t * MS * 2;
+    float M = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < CS / 2; ++i) M = fmaxf(M, fmaxf(r.ml[i].x, r.ml[i].z));
+    for (int s2 = CS; s2 < n; ++s2) M = fmaxf(M, ml[2 * s2]);
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < CS / 2; ++i) {
+      if (2 * i < n) den = fmaf(expf(r.ml[i].x - M), r.ml[i].y, den);
+      if (2 * i + 1 < n) den = fmaf(expf(r.ml[i].z - M), r.ml[i].w, den);
+    }
+    for (int s2 = CS; s2 < n; ++s2) den = fmaf(expf(ml[2 * s2] - M), ml[2 * s2 + 1], den);
+    const float inv = 1.0f / den;
+#pragma unroll
+    for (int i = 0; i < CS / 2; ++i) {
+      if (2 * i < n) wtab[t * MS + 2 * i] = expf(r.ml[i].x - M) * inv;
+      if (2 * i + 1 < n) wtab[t * MS + 2 * i + 1] = expf(r.ml[i].z - M) * inv;
+    }
+    for (int s2 = CS; s2 < n; ++s2) wtab[t * MS + s2] = expf(ml[2 * s2] - M) * inv;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = t * 4 + j * 1024;
+    if (e < K) {
+      const int h = e / hd, d = e % hd;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const float* w = wtab + (b * H + h) * MS;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s2 = 0; s2 < CS; ++s2) {
+          if (s2 < ns[b]) {
+            const float ws = w[s2];
+            acc.x = fmaf(ws, r.o[b][j][s2].x, acc.x);
+            acc.y = fmaf(ws, r.o[b][j][s2].y, acc.y);
+            acc.z = fmaf(ws, r.o[b][j][s2].z, acc.z);
+            acc.w = fmaf(ws, r.o[b][j][s2].w, acc.w);
+          }
+        }
+        const float* po = p.a.part_o + (((size_t)b * H + h) * MS) * hd + d;
+        for (int s2 = CS; s2 < ns[b]; ++s2) {      // long contexts: the remaining pages, not prefetched
+          const float ws = w[s2];
+          const float4 o = ld4(po + (size_t)s2 * hd);
+          acc.x = fmaf(ws, o.x, acc.x);
+          acc.y = fmaf(ws, o.y, acc.y);
+          acc.z = fmaf(ws, o.z, acc.z);
+          acc.w = fmaf(ws, o.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(xs + b * K + e) = acc;
+      }
     }
   }
   __syncthreads();
@@ -196,8 +267,8 @@ __device__ __forceinline__ void consume_row(const GemvK& p, const float4 (&w)[MA
   }
 }
 
-template <int B>
-__global__ __launch_bounds__(256, (B <= 2) ? 3 : 2) void gemv_kernel(const GemvK p) {
+template <int B, int PRO>
+__global__ __launch_bounds__(256, (B <= 2 && PRO != SSRHIP_PRO_ATTN_COMBINE) ? 3 : 2) void gemv_kernel(const GemvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const ssrhip_gemv_args& a = p.a;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -209,30 +280,39 @@ __global__ __launch_bounds__(256, (B <= 2) ? 3 : 2) void gemv_kernel(const GemvK
   const bool full = (len == p.nch * 256);
   const int G = blockIdx.x * n_rg + rg;        // this wave-group's first row; then += groups_x
   const float* Wg = a.W + (size_t)g * N * K + k0;
-
-  // ---- LayerNorm prologue: its (L2-resident) x loads go out first ...
-  float4 xv[B][NJ];
-  if (a.pro == SSRHIP_PRO_LAYERNORM) ln_issue<B>(p, g, xv);
-  // ---- ... then the first weight row is requested, before any prologue math
-  float4 wa[MAXCH], wb[MAXCH];
-  int n = G;
-  if (n < N) {
-    if (full) load_row<true>(wa, Wg + (size_t)n * K, lane, p.nch, len);
-    else load_row<false>(wa, Wg + (size_t)n * K, lane, p.nch, len);
-  }
-
-  // ---- prologue: this wave's slice of x into registers
-  float4 xr[B][MAXCH];
   float* part = smem;                          // [4 waves][MAX_IT][B] cross-slice partials
   float* xs = smem + 4 * MAX_IT * B + 16;      // staged x (LayerNorm / combine prologues)
-  if (a.pro == SSRHIP_PRO_LAYERNORM) {
-    ln_finish<B>(p, xv, xs, smem);             // `red` aliases `part`: not live yet
-  } else if (a.pro == SSRHIP_PRO_ATTN_COMBINE) {
-    stage_attn_combine<B>(p, xs);
+
+  // ---- prologue loads (L2-resident activations) go out first ...
+  float4 xv[(PRO == SSRHIP_PRO_LAYERNORM) ? B : 1][NJ];
+  CombineRegs<(PRO == SSRHIP_PRO_ATTN_COMBINE) ? B : 1> cr;
+  int ns[B];
+  if constexpr (PRO == SSRHIP_PRO_LAYERNORM) ln_issue<B>(p, g, reinterpret_cast<float4 (&)[B][NJ]>(xv));
+  if constexpr (PRO == SSRHIP_PRO_ATTN_COMBINE) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) ns[b] = (a.row_len[b] + SSRHIP_PAGE - 1) / SSRHIP_PAGE;
+    combine_issue<B>(p, reinterpret_cast<CombineRegs<B>&>(cr), ns);
   }
+  // ---- ... then the first TWO weight rows of this wave are requested, before any prologue math
+  // (loads return in order per wave: the prologue data arrives first, the rows keep flying under the math)
+  float4 wa[MAXCH], wb[MAXCH];
+  int na = G, nb = G + p.groups_x;
+  if (na < N) {
+    if (full) load_row<true>(wa, Wg + (size_t)na * K, lane, p.nch, len);
+    else load_row<false>(wa, Wg + (size_t)na * K, lane, p.nch, len);
+  }
+  if (nb < N) {
+    if (full) load_row<true>(wb, Wg + (size_t)nb * K, lane, p.nch, len);
+    else load_row<false>(wb, Wg + (size_t)nb * K, lane, p.nch, len);
+  }
+
+  // ---- prologue math -> this wave's slice of x into registers
+  float4 xr[B][MAXCH];
+  if constexpr (PRO == SSRHIP_PRO_LAYERNORM) ln_finish<B>(p, reinterpret_cast<float4 (&)[B][NJ]>(xv), xs, smem);   // `red` aliases `part`
+  if constexpr (PRO == SSRHIP_PRO_ATTN_COMBINE) combine_finish<B>(p, reinterpret_cast<CombineRegs<B>&>(cr), ns, xs, xs + B * K);
 #pragma unroll
   for (int b = 0; b < B; ++b) {
-    const float* xb = (a.pro == SSRHIP_PRO_NONE) ? (a.x + (size_t)b * a.x_stride + (size_t)g * K) : (xs + b * K);
+    const float* xb = (PRO == SSRHIP_PRO_NONE) ? (a.x + (size_t)b * a.x_stride + (size_t)g * K) : (xs + b * K);
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
       const int k = (i * 64 + lane) * 4;
@@ -240,26 +320,25 @@ __global__ __launch_bounds__(256, (B <= 2) ? 3 : 2) void gemv_kernel(const GemvK
     }
   }
 
-  // ---- main loop: ping-pong over this wave-group's rows
+  // ---- main loop: two rows in flight per wave, ping-pong register sets
   int it = 0;
-  while (n < N) {
-    int n2 = n + p.groups_x;
-    if (n2 < N) {
-      if (full) load_row<true>(wb, Wg + (size_t)n2 * K, lane, p.nch, len);
-      else load_row<false>(wb, Wg + (size_t)n2 * K, lane, p.nch, len);
-    }
-    consume_row<B>(p, wa, xr, g, n, it, lane, wave, part);
+  const int step2 = 2 * p.groups_x;
+  while (na < N) {
+    consume_row<B>(p, wa, xr, g, na, it, lane, wave, part);
     ++it;
-    n = n2;
-    if (n >= N) break;
-    n2 = n + p.groups_x;
-    if (n2 < N) {
-      if (full) load_row<true>(wa, Wg + (size_t)n2 * K, lane, p.nch, len);
-      else load_row<false>(wa, Wg + (size_t)n2 * K, lane, p.nch, len);
+    na += step2;
+    if (na < N) {
+      if (full) load_row<true>(wa, Wg + (size_t)na * K, lane, p.nch, len);
+      else load_row<false>(wa, Wg + (size_t)na * K, lane, p.nch, len);
     }
-    consume_row<B>(p, wb, xr, g, n, it, lane, wave, part);
+    if (nb >= N) break;
+    consume_row<B>(p, wb, xr, g, nb, it, lane, wave, part);
     ++it;
-    n = n2;
+    nb += step2;
+    if (nb < N) {
+      if (full) load_row<true>(wb, Wg + (size_t)nb * K, lane, p.nch, len);
+      else load_row<false>(wb, Wg + (size_t)nb * K, lane, p.nch, len);
+    }
   }
   if (p.nslice > 1) {
     __syncthreads();
@@ -277,6 +356,15 @@ __global__ __launch_bounds__(256, (B <= 2) ? 3 : 2) void gemv_kernel(const GemvK
   }
 }
 
+template <int B>
+void launch_b(const GemvK& p, dim3 grid, size_t smem, hipStream_t s) {
+  switch (p.a.pro) {
+    case SSRHIP_PRO_LAYERNORM: hipLaunchKernelGGL((gemv_kernel<B, SSRHIP_PRO_LAYERNORM>), grid, dim3(256), smem, s, p); break;
+    case SSRHIP_PRO_ATTN_COMBINE: hipLaunchKernelGGL((gemv_kernel<B, SSRHIP_PRO_ATTN_COMBINE>), grid, dim3(256), smem, s, p); break;
+    default: hipLaunchKernelGGL((gemv_kernel<B, SSRHIP_PRO_NONE>), grid, dim3(256), smem, s, p); break;
+  }
+}
+
 int g_num_cu = 0;
 
 }  // namespace
@@ -284,6 +372,7 @@ int g_num_cu = 0;
 extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->W && a->y, "ssrhip_gemv: null argument");
   SSR_REQUIRE(a->B == 1 || a->B == 2 || a->B == 4, "ssrhip_gemv: B=%d not in {1,2,4}", a->B);
+  SSR_REQUIRE(a->pro != SSRHIP_PRO_ATTN_COMBINE || (a->kv.head_dim > 0 && a->K <= 2048 && a->B * (a->K / a->kv.head_dim) <= 256), "ssrhip_gemv: combine prologue needs K <= 2048 and B*H <= 256");
   SSR_REQUIRE(a->K > 0 && a->K % 4 == 0 && a->K <= 8192, "ssrhip_gemv: K=%d must be a multiple of 4, <= 8192", a->K);
   SSR_REQUIRE(a->N > 0 && a->groups >= 1, "ssrhip_gemv: bad N/groups");
   if (g_num_cu == 0) {
@@ -301,10 +390,11 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   // resident grid: <= 3 workgroups per CU in total (over all groups); rows dealt round-robin to wave-groups
   int max_blocks_x = (3 * g_num_cu) / a->groups;
   if (max_blocks_x < 1) max_blocks_x = 1;
-  int rows_per_group = (a->N + max_blocks_x * n_rg - 1) / (max_blocks_x * n_rg);
-  if (p.nslice > 1 && rows_per_group > MAX_IT) rows_per_group = MAX_IT;   // more (non-resident) blocks instead
-  const int groups_x = (a->N + rows_per_group - 1) / rows_per_group;
-  const int blocks_x = (groups_x + n_rg - 1) / n_rg;
+  // exactly `max_blocks_x` workgroups (every CU gets the same share) unless there are fewer rows than wave-groups
+  int blocks_x = (a->N + n_rg - 1) / n_rg;
+  if (blocks_x > max_blocks_x) blocks_x = max_blocks_x;
+  if (p.nslice > 1 && (a->N + blocks_x * n_rg - 1) / (blocks_x * n_rg) > MAX_IT)   // LDS partial capacity: more blocks instead
+    blocks_x = ((a->N + MAX_IT - 1) / MAX_IT + n_rg - 1) / n_rg;
   p.groups_x = blocks_x * n_rg;
   p.hd = (a->kv.head_dim > 0) ? a->kv.head_dim : 1;
   size_t smem = (4 * MAX_IT * a->B + 16) * sizeof(float);
@@ -312,6 +402,7 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
     SSR_REQUIRE(a->groups == 1 || a->pro == SSRHIP_PRO_LAYERNORM, "ssrhip_gemv: combine prologue needs groups==1");
     SSR_REQUIRE((size_t)a->B * a->K * 4 <= 60 * 1024 && a->K <= 4096, "ssrhip_gemv: staged prologue needs B*K*4 <= 60 KiB and K <= 4096");
     smem += (size_t)a->B * a->K * sizeof(float);
+    if (a->pro == SSRHIP_PRO_ATTN_COMBINE) smem += (size_t)a->B * (a->K / a->kv.head_dim) * a->max_splits * sizeof(float) + 64;
     if (a->pro == SSRHIP_PRO_LAYERNORM) SSR_REQUIRE(a->ln_w && a->ln_b && a->x, "ssrhip_gemv: LayerNorm prologue needs x, ln_w, ln_b");
     if (a->pro == SSRHIP_PRO_ATTN_COMBINE) {
       SSR_REQUIRE(a->part_o && a->part_ml && a->row_len && a->kv.head_dim > 0 && a->K % a->kv.head_dim == 0 && a->kv.head_dim % 4 == 0,
@@ -327,9 +418,9 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   dim3 grid(blocks_x, a->groups);
   hipStream_t s = (hipStream_t)stream;
   switch (a->B) {
-    case 1: hipLaunchKernelGGL(gemv_kernel<1>, grid, dim3(256), smem, s, p); break;
-    case 2: hipLaunchKernelGGL(gemv_kernel<2>, grid, dim3(256), smem, s, p); break;
-    default: hipLaunchKernelGGL(gemv_kernel<4>, grid, dim3(256), smem, s, p); break;
+    case 1: launch_b<1>(p, grid, smem, s); break;
+    case 2: launch_b<2>(p, grid, smem, s); break;
+    default: launch_b<4>(p, grid, smem, s); break;
   }
   SSR_LAUNCH_CHECK();
   return 0;

@@ -1,0 +1,43 @@
+"""Summarise a rocprofv3 --kernel-trace CSV: per (kernel, grid) call count / avg / min duration, and the
+busy fraction of a decode-only window. Usage: python tools/prof_summary.py <kernel_trace.csv> [out.md]"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    for k in ("gemv_kernel", "attn_decode_kernel", "attn_combine_kernel", "sample_kernel", "embed_kernel", "gemm_kernel", "layernorm_kernel", "kv_scatter_kernel"):
+        if k in name:
+            return k + (name[name.index(k) + len(k):].split("(")[0] if "<" in name else "")
+    return "torch:" + name.split("<")[0].split("(")[0][-40:]
+
+
+def main(path, out=None):
+    rows = list(csv.DictReader(open(path)))
+    agg = defaultdict(list)
+    for r in rows:
+        d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1), int(r["Grid_Size_Y"]), int(r["LDS_Block_Size"]))
+        agg[key].append(d)
+    lines = ["| kernel | blocks_x | grid_y | lds | calls | avg us | min us | total ms |", "|---|---|---|---|---|---|---|---|"]
+    for key, ds in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        if key[0].startswith("torch:") and sum(ds) < 2e6:
+            continue
+        lines.append(f"| {key[0]} | {key[1]} | {key[2]} | {key[3]} | {len(ds)} | {sum(ds) / len(ds) / 1e3:.2f} | {min(ds) / 1e3:.2f} | {sum(ds) / 1e6:.2f} |")
+    ours = [r for r in rows if "ssrhip" in r["Kernel_Name"] or "anonymous" in r["Kernel_Name"]]
+    ours.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dec = [r for r in ours if "gemm_kernel" not in r["Kernel_Name"]]
+    tail = dec[-83 * 50:]
+    if len(tail) > 100:
+        span = int(tail[-1]["End_Timestamp"]) - int(tail[0]["Start_Timestamp"])
+        busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tail)
+        lines.append("")
+        lines.append(f"last {len(tail)} decode launches: span {span / 1e6:.3f} ms, kernel-busy {busy / 1e6:.3f} ms ({100 * busy / span:.1f} %), avg gap {(span - busy) / len(tail) / 1e3:.2f} us")
+    txt = "\n".join(lines)
+    print(txt)
+    if out:
+        open(out, "w").write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
