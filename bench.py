@@ -141,12 +141,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         # the one collective of the path: gather every rank's generated codec tokens (before wmencodec decode)
-        gathered = torch.empty(world * eng.generated.numel(), dtype=torch.int32, device=dev)
+        from ssr_speech_amd import dp
+        mine = eng.generated[0, : st.n_steps].t().contiguous()          # [K, steps] of this rank's utterance
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(gathered, eng.generated.view(-1))
+        everyone = dp.gather_tokens([mine], world, arena.K, pad_token=int(args_lm.empty_token), device=dev)
         torch.cuda.synchronize()
         allgather_ms = 1000 * (time.perf_counter() - g0)
+        assert len(everyone) == world and torch.equal(everyone[rank].to(torch.int32), mine)
     else:
         allgather_ms = None
 

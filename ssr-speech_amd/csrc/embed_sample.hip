@@ -21,11 +21,16 @@ __device__ __forceinline__ void embed_row(const ssrhip_embed_args& a, int r, int
     if (kind == 0) {
       e = ld4(a.text_emb + (size_t)tok[0] * D + d);
     } else {
-      // torch.stack(...).sum(dim=0): sequential sum over codebooks (ssr.py:193-196)
-      e = ld4(a.audio_emb + (size_t)tok[0] * D + d);
-      for (int k = 1; k < a.K; ++k) {
-        const float4 t = ld4(a.audio_emb + ((size_t)k * a.card + tok[k]) * D + d);
-        e.x += t.x; e.y += t.y; e.z += t.z; e.w += t.w;
+      // torch.stack(...).sum(dim=0): sequential sum over codebooks (ssr.py:193-196); the K row loads are
+      // issued together (independent HBM/L2 round trips), then added in codebook order
+      float4 t[SSRHIP_MAX_CODEBOOKS];
+#pragma unroll
+      for (int k = 0; k < SSRHIP_MAX_CODEBOOKS; ++k)
+        t[k] = (k < a.K) ? ld4(a.audio_emb + ((size_t)k * a.card + tok[k]) * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+      e = t[0];
+#pragma unroll
+      for (int k = 1; k < SSRHIP_MAX_CODEBOOKS; ++k) {
+        if (k < a.K) { e.x += t[k].x; e.y += t[k].y; e.z += t[k].z; e.w += t[k].w; }
       }
     }
     const float4 p = ld4(a.pe + (size_t)pos * D + d);
@@ -45,6 +50,13 @@ __global__ __launch_bounds__(256) void embed_kernel(const ssrhip_embed_args a) {
 
 constexpr int MAXE = 34;   // logits per lane: card <= 64*34 = 2176
 
+#ifdef SSR_SAMPLE_PROFILE   // tools/sampler_bench.hip: phase time stamps (shader clock) of wave 0
+__device__ unsigned long long g_sample_prof[16];
+#define STAMP(i) do { if (threadIdx.x == 0) g_sample_prof[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ uint32_t okey(float f) {   // order-preserving float -> uint32
   const uint32_t u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -53,6 +65,33 @@ __device__ __forceinline__ uint32_t okey(float f) {   // order-preserving float 
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
+}
+
+// count / mass of the wave's keys above a threshold: 4 independent per-lane chains (the kernel runs one wave
+// per SIMD, so dependent-issue latency, not throughput, is what costs), then one DPP wave reduction.
+__device__ __forceinline__ int count_gt(const uint32_t (&key)[MAXE], uint32_t cand) {
+  int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+  for (int e = 0; e + 3 < MAXE; e += 4) {
+    c0 += key[e] > cand; c1 += key[e + 1] > cand; c2 += key[e + 2] > cand; c3 += key[e + 3] > cand;
+  }
+#pragma unroll
+  for (int e = MAXE & ~3; e < MAXE; ++e) c0 += key[e] > cand;
+  // float-typed reduction is exact here: counts <= 2176 < 2^24
+  return (int)wave_sum((float)((c0 + c1) + (c2 + c3)));
+}
+__device__ __forceinline__ float mass_gt(const uint32_t (&key)[MAXE], const float (&p)[MAXE], uint32_t cand) {
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+#pragma unroll
+  for (int e = 0; e + 3 < MAXE; e += 4) {
+    m0 += (key[e] > cand) ? p[e] : 0.f;
+    m1 += (key[e + 1] > cand) ? p[e + 1] : 0.f;
+    m2 += (key[e + 2] > cand) ? p[e + 2] : 0.f;
+    m3 += (key[e + 3] > cand) ? p[e + 3] : 0.f;
+  }
+#pragma unroll
+  for (int e = MAXE & ~3; e < MAXE; ++e) m0 += (key[e] > cand) ? p[e] : 0.f;
+  return wave_sum((m0 + m1) + (m2 + m3));
 }
 
 __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a) {
@@ -81,6 +120,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
   const int c_maxsteps = c.max_steps, c_nsil = c.n_silence;
   const uint32_t c_seedlo = c.seed_lo, c_seedhi = c.seed_hi;
 
+  STAMP(0);
   if (k < K) {
     const float* lc = a.logits + ((size_t)row0 * K + k) * card;
     const float* lu = lc + (size_t)K * card;
@@ -121,12 +161,22 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
       l[e] = lc[ic];
       lun[e] = guided ? lu[ic] : 0.f;
     }
+    // every edited index lies in [empty_token, mts_end) (8 consecutive ids) or is the penalised token:
+    // only the (wave-uniform) element groups that contain them run the select chain
+    const int sp_lo = min(min(c_empty, c_eog), min(min(c_eos, c_sos), c_mts)) >> 6;
+    const int sp_hi = (max(max(c_empty, c_eog), max(max(c_eos, c_sos), c_mts_end - 1))) >> 6;
+    const int pen_e = pen_idx >> 6;     // -1 when there is no penalty
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
       const int i = e * 64 + lane;
       const bool valid = (e < ne) && (i < card);
-      float v = edit(i, l[e], lun[e]);
-      v = (i == pen_idx) ? pen_val : v;
+      float v;
+      if ((e >= sp_lo && e <= sp_hi) || e == pen_e) {           // wave-uniform
+        v = edit(i, l[e], lun[e]);
+        v = (i == pen_idx) ? pen_val : v;
+      } else {
+        v = guided ? __fadd_rn(__fmul_rn(c_coef, l[e]), __fmul_rn(c_om, lun[e])) : l[e];
+      }
       l[e] = valid ? v : -INFINITY;
     }
     if (dbg) {
@@ -136,6 +186,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
         if ((e < ne) && (i < card)) dbg[i] = l[e];
       }
     }
+    STAMP(1);
     // ---- argmax of the edited logits (first index on ties), needed for the stop rule :739
     float mx = -INFINITY;
 #pragma unroll
@@ -170,6 +221,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
     const int hibit = (kmax == kmin) ? -1 : (31 - __clz((int)(kmax ^ kmin)));
     const uint32_t lowmask = (hibit < 0) ? 0u : ((hibit >= 31) ? 0xffffffffu : ((2u << hibit) - 1u));
     const uint32_t prefix = kmax & ~lowmask;                                        // common high bits
+    STAMP(2);
     // ---- top-k (:38-44): keep logits >= k-th largest value (ties kept)
     uint32_t thr = 0;   // keep keys >= thr
     if (c_topk > 0) {
@@ -180,18 +232,12 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
         uint32_t t = prefix;   // largest key with count(keys > t) > kk-1, or prefix-1 if none
         bool any = false;
         {  // is count(keys > prefix) > kk-1 ? (otherwise the threshold sits at/below prefix: keep all >= kmin)
-          int cnt = 0;
-#pragma unroll
-          for (int e = 0; e < MAXE; ++e) cnt += __popcll(__ballot(key[e] > prefix));
-          any = cnt > kk - 1;
+          any = count_gt(key, prefix) > kk - 1;
         }
         if (any) {
           for (int bit = hibit; bit >= 0; --bit) {
             const uint32_t cand = t | (1u << bit);
-            int cnt = 0;
-#pragma unroll
-            for (int e = 0; e < MAXE; ++e) cnt += __popcll(__ballot(key[e] > cand));
-            if (cnt > kk - 1) t = cand;
+            if (count_gt(key, cand) > kk - 1) t = cand;
           }
           thr = t + 1;
         } else {
@@ -199,6 +245,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
         }
       }
     }
+    STAMP(3);
     // ---- softmax numerators over the kept set, then top-p (:46-67)
     float p[MAXE];
     float Z = 0.f;
@@ -211,31 +258,23 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
     if (c_topp < 1.0f) {
       // smallest key t* with mass(keys > t*) <= top_p * Z ; keep keys >= t*
       const float lim = c_topp * Z;
-      float m0 = 0.f;
-#pragma unroll
-      for (int e = 0; e < MAXE; ++e) m0 += (key[e] > prefix) ? p[e] : 0.f;
-      m0 = wave_sum(m0);
-      if (m0 > lim) {
+      if (mass_gt(key, p, prefix) > lim) {
         uint32_t t = prefix;
         for (int bit = hibit; bit >= 0; --bit) {
           const uint32_t cand = t | (1u << bit);
-          float m = 0.f;
-#pragma unroll
-          for (int e = 0; e < MAXE; ++e) m += (key[e] > cand) ? p[e] : 0.f;
-          m = wave_sum(m);
-          if (m > lim) t = cand;
+          if (mass_gt(key, p, cand) > lim) t = cand;
         }
         thr = max(thr, t + 1);
 #pragma unroll
         for (int e = 0; e < MAXE; ++e) p[e] = (key[e] >= thr) ? p[e] : 0.f;
       }
     }
+    STAMP(4);
     // ---- multinomial(softmax, 1) == argmax(prob / q), q ~ Exp(1)   (torch CPU fast path; :85).
     // The positive normaliser does not change the argmax, so it is dropped.
     const float* nz = a.noise ? a.noise + (((size_t)u * c_maxsteps + step) * K + k) * card : nullptr;
-    float best = -1.f;
-    int bi = 0x7fffffff;
     const uint32_t sd = hash32(c_seedlo + (uint32_t)step * 0x9E3779B1u) ^ hash32(c_seedhi + (uint32_t)k * 0x85EBCA6Bu + 0x632BE5ABu);
+    float sc[MAXE];
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
       const int i = e * 64 + lane;
@@ -245,11 +284,26 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
         const uint32_t hsh = hash32(sd + (uint32_t)i * 0x9E3779B1u);
         q = fmaxf(-__logf(((float)(hsh >> 8) + 1.0f) * (1.0f / 16777216.0f)), 1e-30f);
       }
-      const float sc = (p[e] > 0.f) ? __fdividef(p[e], q) : -1.f;
-      const bool better = sc > best;                                   // e ascending => first index wins ties
-      best = better ? sc : best;
-      bi = better ? i : bi;
+      sc[e] = (p[e] > 0.f) ? __fdividef(p[e], q) : -1.f;
     }
+    // per-lane best (lowest element index wins ties): 4 independent chains, then merged in index order
+    float bs[4] = {-1.f, -1.f, -1.f, -1.f};
+    int be[4] = {0, 1, 2, 3};
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) {
+      const bool better = sc[e] > bs[e & 3];
+      bs[e & 3] = better ? sc[e] : bs[e & 3];
+      be[e & 3] = better ? e : be[e & 3];
+    }
+    float best = bs[0];
+    int beste = be[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      const bool better = bs[j] > best || (bs[j] == best && be[j] < beste);
+      best = better ? bs[j] : best;
+      beste = better ? be[j] : beste;
+    }
+    int bi = beste * 64 + lane;
     {
       const float wb = wave_max(best);
       bi = (best == wb) ? bi : 0x7fffffff;
@@ -260,7 +314,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
       if (k == 0) sh_argmax0 = am;
     }
   }
+  STAMP(5);
   __syncthreads();
+  STAMP(6);
   if (threadIdx.x == 0) {
     // ---- state machine (:709-761), single thread
     int s[SSRHIP_MAX_CODEBOOKS];
@@ -313,6 +369,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
       }
     }
   }
+  STAMP(7);
   // ---- fused embedding of the next input row(s) (ssr.py:757-763): saves a launch per step
   if (a.embed.out) {
     __syncthreads();
@@ -320,6 +377,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
       for (int rr = 0; rr < rows; ++rr) embed_row(a.embed, row0 + rr, 1, sh_next[SSRHIP_MAX_CODEBOOKS], sh_next, threadIdx.x, 256);
     }
   }
+  STAMP(8);
 }
 
 }  // namespace

@@ -1,0 +1,55 @@
+"""Data-parallel sharding of independent utterances over the GPUs of one node and the ONE collective of the
+path: an all-gather of the generated codec tokens before codec decode. The reference has no
+multi-GPU inference (`--sample_batch_size` is a sequential loop, `inference_v2.py:331-333`); each utterance
+is an independent AR chain (own text, prompt, cache, RNG stream, stop state), so sharding needs no
+data-path collective during decode. Works with any torch.distributed backend (nccl == RCCL on ROCm; gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+
+
+def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block of utterances for `rank`: sizes differ by at most one, order preserved."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def utterance_seed(seed: int, global_index: int) -> int:
+    """Per-utterance RNG seed: independent of the world size (same convention as `inference_v2.py:332`, seed+num)."""
+    return int(seed) + int(global_index)
+
+
+def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token: int, device=None) -> List[torch.Tensor]:
+    """local[i]: int tensor [K, T_i] of this rank's utterances (rank-contiguous shard of `n_total`).
+    Returns the list of all `n_total` token tensors on every rank. One all_gather of lengths (n ints per
+    rank) and one all_gather of a padded [n_max, K, T_max] int32 block (a few KB..100 KB per rank)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [t.clone() for t in local]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if device is None:
+        device = local[0].device if len(local) else torch.device("cpu")
+    n_max = (n_total + world - 1) // world
+    lens = torch.zeros(n_max, dtype=torch.int32, device=device)
+    for i, t in enumerate(local):
+        lens[i] = t.shape[1]
+    all_lens = torch.empty(world * n_max, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(all_lens, lens)
+    t_max = int(all_lens.max().item())
+    block = torch.full((n_max, K, max(t_max, 1)), pad_token, dtype=torch.int32, device=device)
+    for i, t in enumerate(local):
+        block[i, :, : t.shape[1]] = t.to(torch.int32)
+    out = torch.empty((world,) + tuple(block.shape), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(out.view(-1), block.view(-1))
+    all_lens = all_lens.view(world, n_max)
+    res = []
+    for r in range(world):
+        s, e = shard_range(n_total, world, r)
+        for i in range(e - s):
+            res.append(out[r, i, :, : int(all_lens[r, i])].to(torch.int64).clone())
+    assert len(res) == n_total
+    return res

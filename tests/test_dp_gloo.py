@@ -1,0 +1,59 @@
+"""CPU, 2 processes over gloo: the N>1 path of the DP decode — sharding is a partition, per-utterance seeds do not depend
+on the world size, and the one all-gather returns every utterance's ragged token tensor to every rank in global order."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import ssr_speech_amd  # noqa: F401
+from ssr_speech_amd import dp
+
+
+def test_shard_range_is_a_partition():
+    for n in (0, 1, 5, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                s, e = dp.shard_range(n, world, r)
+                assert 0 <= s <= e <= n and (e - s) in (n // world, n // world + 1)
+                cover += list(range(s, e))
+            assert cover == list(range(n))
+    assert dp.utterance_seed(7, 3) == 10
+
+
+def _tokens(i, K=4):
+    g = torch.Generator().manual_seed(100 + i)
+    T = 5 + (i * 7) % 11
+    return torch.randint(0, 2048, (K, T), generator=g)
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s, e = dp.shard_range(n_total, world, rank)
+    local = [_tokens(i) for i in range(s, e)]
+    allt = dp.gather_tokens(local, n_total, 4, pad_token=2048)
+    ok = len(allt) == n_total and all(torch.equal(allt[i], _tokens(i)) for i in range(n_total))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [5, 8])
+def test_gather_tokens_world2(n_total):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
