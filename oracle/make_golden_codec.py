@@ -1,0 +1,85 @@
+"""ORACLE tooling — golden vectors for the codec from the REAL reference (build container only): see make_golden.py."""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import, codec as OC  # noqa: E402
+import ssr_speech_amd  # noqa: E402,F401
+from ssr_speech_amd import weights as W  # noqa: E402
+
+
+def ref_model(cfg, seed):
+    seanet, qt, wm = ref_import.import_codec()
+    kw = dict(channels=1, dimension=cfg.dimension, n_filters=cfg.n_filters, n_residual_layers=1, ratios=list(cfg.ratios), activation='ELU',
+              activation_params={'alpha': 1.}, norm='weight_norm', norm_params={}, kernel_size=cfg.kernel_size, residual_kernel_size=cfg.residual_kernel_size,
+              last_kernel_size=cfg.last_kernel_size, dilation_base=2, causal=False, pad_mode=cfg.pad_mode, true_skip=True, compress=cfg.compress,
+              lstm=cfg.lstm, disable_norm_outer_blocks=0)
+    dkw = dict(kw, trim_right_ratio=1.0, final_activation=None, final_activation_params=None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = wm.WMEncodecModel(seanet.SEANetEncoder(**kw), seanet.SEANetDecoder(**dkw), seanet.WMSEANetDecoder(**dkw),
+                              qt.ResidualVectorQuantizer(dimension=cfg.dimension, n_q=cfg.n_q, bins=cfg.bins, kmeans_init=False),
+                              frame_rate=cfg.frame_rate, sample_rate=cfg.sample_rate, channels=1).eval()
+    sd = W.codec_state_dict(cfg, seed=seed)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+CASES = [
+    # name, config factory, pad_mode, B, samples, seed
+    ("tiny_const", W.codec_config_tiny, "constant", 2, 48 * 9, 31),
+    ("tiny_reflect", W.codec_config_tiny, "reflect", 1, 48 * 7, 32),
+    ("tiny_odd", W.codec_config_tiny, "constant", 1, 48 * 5 + 7, 33),        # not a hop multiple: extra-padding rule
+    ("full_const_1s", W.codec_config_full, "constant", 1, 16000, 34),
+    ("full_reflect_short", W.codec_config_full, "reflect", 1, 320 * 12, 35),
+]
+
+
+def main(gold):
+    for name, mk, pad_mode, B, n, seed in CASES:
+        cfg = mk()
+        cfg.pad_mode = pad_mode
+        m, sd = ref_model(cfg, seed)
+        g = torch.Generator().manual_seed(seed)
+        wav = torch.randn(B, 1, n, generator=g) * 0.3
+        with torch.no_grad():
+            codes, scale, emb = m.encode(wav)
+            dec = m.decode(codes, scale)
+            T = codes.shape[-1]
+            labels = (torch.arange(T).unsqueeze(0).repeat(B, 1) >= T // 2).long()
+            wav_pad = torch.zeros(B, 1, T * cfg.hop)
+            wav_pad[..., : min(n, T * cfg.hop)] = wav[..., : T * cfg.hop]
+            wmout, mark = m.wmdecode(codes, labels, wav_pad, scale)
+            det = m.detect_watermark(wmout)
+            # the oracle restates the same thing op for op: must agree exactly
+            o_codes, _, o_emb = OC.encode(sd, wav, cfg)
+            o_dec = OC.decode(sd, codes, cfg)
+            o_wm, o_mark = OC.wmdecode(sd, codes, labels, wav_pad, cfg)
+            o_det = OC.detect_watermark(sd, wmout, cfg)
+        assert scale is None
+        worst = 0.0
+        for a, b, what in [(emb, o_emb, "emb"), (dec, o_dec, "decode"), (wmout, o_wm, "wmdecode"), (mark, o_mark, "mark")]:
+            d = float((a - b).abs().max())
+            worst = max(worst, d)
+            # same ATen ops on the same values: bit-exact except where ATen picks a different conv algorithm for a
+            # differently-strided input (seen once: 1.4e-6 on the 12-frame reflect case)
+            assert d <= 5e-6, (name, what, d)
+        assert torch.equal(codes, o_codes) and torch.equal(det, o_det), name
+        # top-1 / top-2 distance margins of the RVQ argmax (for tolerance-aware comparisons on the GPU)
+        np.savez_compressed(os.path.join(gold, f"codec_{name}.npz"), cfg=np.asarray([cfg.dimension, cfg.n_filters, cfg.bins, cfg.n_q] + list(cfg.ratios)),
+                            pad_mode=np.asarray(pad_mode), weight_seed=np.asarray(seed), wav=wav.numpy(), emb=emb.numpy(), codes=codes.numpy(),
+                            decoded=dec.numpy(), labels=labels.numpy(), wav_pad=wav_pad.numpy(), wmdecoded=wmout.numpy(), mark=mark.numpy(),
+                            detect=det.numpy(), torch_version=np.asarray(torch.__version__))
+        print(f"  codec/{name}: wav {tuple(wav.shape)} codes {tuple(codes.shape)} dec {tuple(dec.shape)} wm {tuple(wmout.shape)}  (oracle vs reference: max |diff| {worst:.1e}, codes identical)")
+
+
+if __name__ == "__main__":
+    main(os.path.join(ROOT, "tests", "golden"))

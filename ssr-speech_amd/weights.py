@@ -152,3 +152,145 @@ def lm_num_params(args) -> int:
             m *= d
         n += m
     return n
+
+
+# ---------------------------------------------------------------------------------------------
+# Codec (watermarked Encodec: SEANet encoder/decoder + LSTM + RVQ + watermark decoder) parameter inventory
+# ---------------------------------------------------------------------------------------------
+from dataclasses import dataclass, field
+
+
+@dataclass
+class CodecConfig:
+    """Hyper-parameters the reference keeps in the checkpoint's `xp.cfg` (`audiocraft/config/model/encodec/
+    default.yaml`, `encodec_large_nq4_s320.yaml`, SURVEY §8 header)."""
+    channels: int = 1
+    dimension: int = 128
+    n_filters: int = 64
+    n_residual_layers: int = 1
+    ratios: tuple = (8, 5, 4, 2)
+    kernel_size: int = 7
+    residual_kernel_size: int = 3
+    last_kernel_size: int = 7
+    compress: int = 2
+    lstm: int = 2
+    pad_mode: str = "constant"
+    n_q: int = 4
+    bins: int = 2048
+    sample_rate: int = 16000
+
+    @property
+    def hop(self) -> int:
+        h = 1
+        for r in self.ratios:
+            h *= r
+        return h
+
+    @property
+    def frame_rate(self) -> int:
+        return self.sample_rate // self.hop
+
+
+def codec_config_full() -> CodecConfig:
+    return CodecConfig()
+
+
+def codec_config_tiny() -> CodecConfig:
+    return CodecConfig(dimension=32, n_filters=8, ratios=(4, 3, 2, 2), bins=64)   # hop 48; the wm decoder needs 4 ratios
+
+
+def _conv_specs(sp, pfx, cout, cin, k, wn=True):
+    if wn:
+        sp[pfx + "conv.conv.bias"] = ((cout,), f"lin:{cin * k}")
+        sp[pfx + "conv.conv.weight_g"] = ((cout, 1, 1), "wn_g")
+        sp[pfx + "conv.conv.weight_v"] = ((cout, cin, k), f"lin:{cin * k}")
+    else:
+        sp[pfx + "conv.conv.weight"] = ((cout, cin, k), f"lin:{cin * k}")
+        sp[pfx + "conv.conv.bias"] = ((cout,), f"lin:{cin * k}")
+
+
+def _lstm_specs(sp, pfx, dim, layers):
+    for l in range(layers):
+        sp[pfx + f"lstm.weight_ih_l{l}"] = ((4 * dim, dim), f"lin:{dim}")
+        sp[pfx + f"lstm.weight_hh_l{l}"] = ((4 * dim, dim), f"lin:{dim}")
+        sp[pfx + f"lstm.bias_ih_l{l}"] = ((4 * dim,), f"lin:{dim}")
+        sp[pfx + f"lstm.bias_hh_l{l}"] = ((4 * dim,), f"lin:{dim}")
+
+
+def _encoder_specs(sp, pfx, c: CodecConfig):
+    """SEANetEncoder.model layout (`audiocraft/modules/seanet.py:113-150`)."""
+    assert c.n_residual_layers == 1, "only n_residual_layers=1 (dilation 1) is supported"
+    i, mult = 0, 1
+    _conv_specs(sp, f"{pfx}model.{i}.", c.n_filters, c.channels, c.kernel_size)
+    i += 1
+    for r in reversed(c.ratios):
+        dim = mult * c.n_filters
+        _conv_specs(sp, f"{pfx}model.{i}.block.1.", dim // c.compress, dim, c.residual_kernel_size)
+        _conv_specs(sp, f"{pfx}model.{i}.block.3.", dim, dim // c.compress, 1)
+        i += 2   # resblock, ELU
+        _conv_specs(sp, f"{pfx}model.{i}.", dim * 2, dim, 2 * r)
+        i += 1
+        mult *= 2
+    if c.lstm:
+        _lstm_specs(sp, f"{pfx}model.{i}.", mult * c.n_filters, c.lstm)
+        i += 1
+    i += 1       # ELU
+    _conv_specs(sp, f"{pfx}model.{i}.", c.dimension, mult * c.n_filters, c.last_kernel_size)
+
+
+def _decoder_specs(sp, pfx, c: CodecConfig):
+    """SEANetDecoder.model layout (`seanet.py:209-254`)."""
+    i, mult = 0, 2 ** len(c.ratios)
+    _conv_specs(sp, f"{pfx}model.{i}.", mult * c.n_filters, c.dimension, c.kernel_size)
+    i += 1
+    if c.lstm:
+        _lstm_specs(sp, f"{pfx}model.{i}.", mult * c.n_filters, c.lstm)
+        i += 1
+    for r in c.ratios:
+        dim = mult * c.n_filters
+        i += 1   # ELU
+        sp[f"{pfx}model.{i}.convtr.convtr.bias"] = ((dim // 2,), f"lin:{dim * 2 * r}")
+        sp[f"{pfx}model.{i}.convtr.convtr.weight_g"] = ((dim, 1, 1), "wn_g")           # norm over dim 0 = IN channels
+        sp[f"{pfx}model.{i}.convtr.convtr.weight_v"] = ((dim, dim // 2, 2 * r), f"lin:{dim * 2}")
+        i += 1
+        _conv_specs(sp, f"{pfx}model.{i}.block.1.", dim // 2 // c.compress, dim // 2, c.residual_kernel_size)
+        _conv_specs(sp, f"{pfx}model.{i}.block.3.", dim // 2, dim // 2 // c.compress, 1)
+        i += 1
+        mult //= 2
+    i += 1       # ELU
+    _conv_specs(sp, f"{pfx}model.{i}.", c.channels, c.n_filters, c.last_kernel_size)
+
+
+def codec_param_specs(c: CodecConfig) -> "OrderedDict[str, tuple]":
+    """name -> (shape, kind) for `WMEncodecModel.state_dict()` (encoder, decoder, wmdecoder, quantizer)."""
+    sp: "OrderedDict[str, tuple]" = OrderedDict()
+    _encoder_specs(sp, "encoder.", c)
+    _decoder_specs(sp, "decoder.", c)
+    _decoder_specs(sp, "wmdecoder.", c)
+    _encoder_specs(sp, "wmdecoder.skip_encoder.", c)
+    sp["wmdecoder.wm_embed.weight"] = ((2, c.dimension // 16), "emb")
+    _encoder_specs(sp, "wmdecoder.wm_encoder.", c)
+    e = c.dimension // 16
+    mult = 2 ** len(c.ratios)
+    _conv_specs(sp, "wmdecoder.wm_proj0.1.", c.dimension, c.dimension + e, 1, wn=False)
+    for j in (1, 2, 3):
+        mult //= 2
+        _conv_specs(sp, f"wmdecoder.wm_proj{j}.1.", mult * c.n_filters, mult * c.n_filters + e, 1, wn=False)
+    _conv_specs(sp, "wmdecoder.wm_predictor.1.", 2, c.dimension, 1, wn=False)
+    for q in range(c.n_q):
+        p = f"quantizer.vq.layers.{q}._codebook."
+        sp[p + "inited"] = ((1,), "one")
+        sp[p + "cluster_size"] = ((c.bins,), "zero")
+        sp[p + "embed"] = ((c.bins, c.dimension), f"scale:{1.0 / (q + 1):.6g}")
+        sp[p + "embed_avg"] = ((c.bins, c.dimension), f"scale:{1.0 / (q + 1):.6g}")
+    return sp
+
+
+def codec_state_dict(c: CodecConfig, seed: int = 0, device="cpu") -> "OrderedDict[str, torch.Tensor]":
+    sd = OrderedDict()
+    for name, (shape, kind) in codec_param_specs(c).items():
+        if kind == "wn_g":
+            sd[name] = 1.0 + 0.25 * uniform_pm1(name, shape[0], seed, device).view(*shape)
+        else:
+            sd[name] = make_tensor(name, shape, kind, seed, device)
+    return sd
