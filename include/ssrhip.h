@@ -33,7 +33,8 @@ typedef void* ssrhip_stream_t;
 
 int ssrhip_version(void);
 /* sizeof() of the ABI structs, for binding self-checks: 0 kv, 1 gemv_args, 2 attn_args, 3 embed_args,
- * 4 sampler_cfg, 5 sampler_state, 6 sample_args, 7 gemm_args, 8 lm_weights, 9 lm_dims, 10 lm_buffers, 11 prefill_args */
+ * 4 sampler_cfg, 5 sampler_state, 6 sample_args, 7 gemm_args, 8 lm_weights, 9 lm_dims, 10 lm_buffers, 11 prefill_args,
+ * 12 lstm_args */
 int ssrhip_sizeof(int which);
 const char* ssrhip_last_error(void);
 
@@ -57,7 +58,7 @@ typedef struct ssrhip_kv {
  * transformer.py:58-75 (LayerNorm, eps 1e-5) as prologue and the residual add (transformer.py:328-329).
  * ---------------------------------------------------------------------------------------------- */
 enum { SSRHIP_PRO_NONE = 0, SSRHIP_PRO_LAYERNORM = 1, SSRHIP_PRO_ATTN_COMBINE = 2 };
-enum { SSRHIP_ACT_NONE = 0, SSRHIP_ACT_RELU = 1, SSRHIP_ACT_GELU_ERF = 2 };
+enum { SSRHIP_ACT_NONE = 0, SSRHIP_ACT_RELU = 1, SSRHIP_ACT_GELU_ERF = 2, SSRHIP_ACT_ELU = 3 };
 enum { SSRHIP_EPI_STORE = 0, SSRHIP_EPI_RESIDUAL = 1, SSRHIP_EPI_QKV_APPEND = 2 };
 
 typedef struct ssrhip_gemv_args {
@@ -171,9 +172,52 @@ int ssrhip_sample(const ssrhip_sample_args* a, ssrhip_stream_t stream);
 typedef struct ssrhip_gemm_args {
   const float* A; const float* W; const float* bias; float* C;
   int32_t M, N, K, lda, ldc;
-  int32_t act, residual;   /* residual: C += ... */
+  int32_t act, residual;   /* residual: C += ... (in place) */
+  /* --- extensions used by the codec (all zero = plain GEMM) --- */
+  int32_t act_in;          /* SSRHIP_ACT_ELU: apply ELU(alpha=1) to A while staging it (conv input activation) */
+  const float* R; int32_t ldr;      /* R != NULL: C = epi(...) + R[m*ldr+n]  (SEANet residual block skip) */
+  int32_t batch;           /* grid.z; 0/1 = single problem */
+  int64_t strideA, strideC, strideR; /* per-batch element strides */
+  int32_t tm_c, tm_lo, tm_hi;       /* tm_c > 0: element (m,n) belongs to time row u = (m*N+n)/tm_c and is stored only
+                                       if tm_lo <= u < tm_hi (transposed-conv trimming, modules/conv.py:236-243) */
 } ssrhip_gemm_args;
 int ssrhip_gemm(const ssrhip_gemm_args* a, ssrhip_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Codec (watermarked Encodec) kernels. Activations are TIME-MAJOR fp32: one item = [rows][C] with C contiguous,
+ * so a Conv1d (kernel k, stride s) over a zero/reflect-padded buffer is a plain GEMM on a strided view:
+ * A row t = k consecutive time rows = k*C contiguous floats starting at padded row t*s (lda = s*C), W repacked to
+ * [Cout][k][Cin]; a ConvTranspose1d (k = 2s) is ONE GEMM with N = s*Cout (the s output phases side by side) and
+ * K = 2*Cin, trimmed by the time mask. replaces StreamableConv1d / StreamableConvTranspose1d
+ * (audiocraft/modules/conv.py:185-243) and SEANetResnetBlock (modules/seanet.py:16-60) via ssrhip_gemm.
+ * ---------------------------------------------------------------------------------------------- */
+/* first conv of SEANet (Cin == 1): out[b][t][co] = bias[co] + sum_kk w[co][kk] * x[b][t*stride + kk]  (x pre-padded) */
+int ssrhip_conv_cin1(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t T_out, int32_t k,
+                     int32_t stride, int32_t Cout, int64_t x_bstride, int64_t out_bstride, ssrhip_stream_t stream);
+/* reflect padding of a time-major buffer (conv.py:71-88): rows [0,padL) and [padL+T, padL+T+padR) mirror the interior */
+int ssrhip_pad_reflect(float* buf, int32_t B, int32_t T, int32_t padL, int32_t padR, int32_t C, int64_t bstride,
+                       ssrhip_stream_t stream);
+/* one LSTM layer over T steps (torch.nn.LSTM semantics, gates i,f,g,o; modules/lstm.py:10-25):
+ * gin[b][t][4C] = x_t W_ih^T + b_ih + b_hh (precomputed by ssrhip_gemm); h,c start at 0.
+ * out[b][t][C] = h_t (+ skip[b][t][C] when skip != NULL).  hbuf: [2][B][C], cbuf: [B][C], gates: [B][4C] scratch. */
+typedef struct ssrhip_lstm_args {
+  const float* gin; const float* w_hh; float* out; const float* skip;
+  float* hbuf; float* cbuf; float* gates;
+  int32_t B, T, C;
+  int64_t gin_bstride, out_bstride, skip_bstride;   /* element strides between items */
+} ssrhip_lstm_args;
+int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stream);
+/* residual vector quantisation (quantization/core_vq.py:164-179, 382-400): emb [B][T][D] time-major;
+ * codebooks [n_q][bins][D]; e2 [n_q][bins] = |e|^2; codes int32 [B][n_q][T] */
+int ssrhip_rvq_encode(const float* emb, const float* codebooks, const float* e2, int32_t* codes, int32_t B, int32_t T,
+                      int32_t D, int32_t n_q, int32_t bins, int64_t emb_bstride, ssrhip_stream_t stream);
+int ssrhip_rvq_decode(const int32_t* codes, const float* codebooks, float* out, int32_t B, int32_t T, int32_t D,
+                      int32_t n_q, int32_t bins, int64_t out_bstride, ssrhip_stream_t stream);
+/* watermark conditioning (modules/seanet.py:577-591): cat[b][t][0:C] = skip[b][t][:], cat[b][t][C:C+E] = table[label[b][t/rep]][:] */
+int ssrhip_wm_concat(const float* skip, const int32_t* labels, const float* table, float* cat, int32_t B, int32_t T,
+                     int32_t C, int32_t E, int32_t rep, int32_t n_labels, int64_t skip_bstride, int64_t cat_bstride,
+                     ssrhip_stream_t stream);
 
 /* LayerNorm over rows (transformer.py:58-75) */
 int ssrhip_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int32_t R, int32_t D,

@@ -19,7 +19,7 @@ MAX_CODEBOOKS = 4
 MAX_SILENCE = 8
 
 PRO_NONE, PRO_LAYERNORM, PRO_ATTN_COMBINE = 0, 1, 2
-ACT_NONE, ACT_RELU, ACT_GELU_ERF = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU_ERF, ACT_ELU = 0, 1, 2, 3
 EPI_STORE, EPI_RESIDUAL, EPI_QKV_APPEND = 0, 1, 2
 
 c_f32p = C.POINTER(C.c_float)
@@ -85,7 +85,17 @@ class SampleArgs(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldc", C.c_int32),
-                ("act", C.c_int32), ("residual", C.c_int32)]
+                ("act", C.c_int32), ("residual", C.c_int32),
+                ("act_in", C.c_int32), ("R", C.c_void_p), ("ldr", C.c_int32), ("batch", C.c_int32),
+                ("strideA", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
+                ("tm_c", C.c_int32), ("tm_lo", C.c_int32), ("tm_hi", C.c_int32)]
+
+
+class LstmArgs(C.Structure):
+    _fields_ = [("gin", C.c_void_p), ("w_hh", C.c_void_p), ("out", C.c_void_p), ("skip", C.c_void_p),
+                ("hbuf", C.c_void_p), ("cbuf", C.c_void_p), ("gates", C.c_void_p),
+                ("B", C.c_int32), ("T", C.c_int32), ("C", C.c_int32),
+                ("gin_bstride", C.c_int64), ("out_bstride", C.c_int64), ("skip_bstride", C.c_int64)]
 
 
 _PP = C.POINTER(C.c_void_p)
@@ -135,6 +145,12 @@ SYMBOLS = [
     ("ssrhip_embed", C.c_int, [C.POINTER(EmbedArgs), C.c_void_p]),
     ("ssrhip_sample", C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     ("ssrhip_gemm", C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    ("ssrhip_conv_cin1", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
+    ("ssrhip_pad_reflect", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    ("ssrhip_lstm_layer", C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),
+    ("ssrhip_rvq_encode", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    ("ssrhip_rvq_decode", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    ("ssrhip_wm_concat", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     ("ssrhip_layernorm", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("ssrhip_kv_scatter", C.c_int, [C.c_void_p, C.POINTER(KV), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("ssrhip_lm_create", C.c_int, [C.POINTER(LMDims), C.POINTER(LMWeights), C.POINTER(LMBuffers), C.POINTER(C.c_void_p)]),
@@ -145,7 +161,7 @@ SYMBOLS = [
 ]
 
 ABI_STRUCTS = [KV, GemvArgs, AttnArgs, EmbedArgs, SamplerCfg, SamplerState, SampleArgs, GemmArgs, LMWeights, LMDims,
-               LMBuffers, PrefillArgs]
+               LMBuffers, PrefillArgs, LstmArgs]
 
 _lib = None
 

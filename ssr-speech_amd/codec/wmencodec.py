@@ -1,0 +1,373 @@
+"""`WMEncodecModel` — drop-in for the reference's watermarked Encodec on the inference path
+(`audiocraft/audiocraft/models/wmencodec.py:324-386`: `encode`, `decode`, `wmdecode`, `detect_watermark`,
+`decode_latent`), built from a state-dict with the reference's key names. All arithmetic runs in libssrhip.so:
+the SEANet convolutions / transposed convolutions / residual blocks as fp32 MFMA GEMMs over time-major
+strided views (weight-norm folded and weights repacked once at load), the LSTM recurrence, RVQ search and
+dequantisation, the watermark-label conditioning as dedicated HIP kernels. PyTorch only allocates buffers.
+
+Layout: an activation is `[B][padL + T + padR][C]` fp32 (time-major, channels contiguous, halo rows zero or
+reflected) so that the im2col matrix of a Conv1d is a *view* (row t = k consecutive time rows).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Tuple
+
+import torch
+
+from .. import _lib
+from ..weights import CodecConfig
+
+
+def _extra_padding(length: int, k: int, s: int, pt: int) -> int:
+    """audiocraft/modules/conv.py:47-53."""
+    n_frames = (length - k + pt) / s + 1
+    return (math.ceil(n_frames) - 1) * s + (k - pt) - length
+
+
+class TM:
+    """Time-major activation buffer with halo rows."""
+
+    def __init__(self, B: int, T: int, Cc: int, padL: int, padR: int, device):
+        self.B, self.T, self.C, self.padL, self.padR = B, T, Cc, padL, padR
+        self.rows = padL + T + padR
+        self.data = torch.zeros(B, self.rows, Cc, dtype=torch.float32, device=device)
+
+    @property
+    def base(self) -> int:
+        return self.data.data_ptr()
+
+    @property
+    def interior(self) -> int:
+        return self.data.data_ptr() + 4 * self.padL * self.C
+
+    @property
+    def bstride(self) -> int:
+        return self.rows * self.C
+
+    def interior_view(self) -> torch.Tensor:
+        return self.data[:, self.padL: self.padL + self.T]
+
+
+def _fold_wn(sd, pfx: str, which: str) -> Tuple[torch.Tensor, torch.Tensor]:
+    """weight = g * v / ||v|| (old-style weight_norm, dim 0; conv.py:21-30) or a plain weight."""
+    k = f"{pfx}{which}.{which}."
+    if k + "weight" in sd:
+        return sd[k + "weight"], sd[k + "bias"]
+    return torch._weight_norm(sd[k + "weight_v"], sd[k + "weight_g"], 0), sd[k + "bias"]
+
+
+class _Conv:
+    def __init__(self, sd, pfx, stride, act_in, dev):
+        w, b = _fold_wn(sd, pfx, "conv")
+        self.Cout, self.Cin, self.k = w.shape
+        self.s = stride
+        self.act_in = act_in
+        self.W = w.permute(0, 2, 1).contiguous().view(self.Cout, self.k * self.Cin).to(dev)     # [Cout][k][Cin]
+        self.Wraw = w.contiguous().view(self.Cout, self.Cin * self.k).to(dev)                   # Cin == 1 path
+        self.b = b.contiguous().to(dev)
+        pt = self.k - self.s
+        self.pr = pt // 2
+        self.pl = pt - self.pr
+
+    def pads(self, T):
+        return self.pl, self.pr + _extra_padding(T, self.k, self.s, self.k - self.s)
+
+    def out_len(self, T):
+        pl, pr = self.pads(T)
+        return (T + pl + pr - self.k) // self.s + 1
+
+
+class _ConvTr:
+    def __init__(self, sd, pfx, stride, dev):
+        w, b = _fold_wn(sd, pfx, "convtr")          # [Cin][Cout][k]
+        self.Cin, self.Cout, self.k = w.shape
+        self.s = stride
+        assert self.k == 2 * stride, "SEANet uses kernel = 2*stride for its transposed convolutions"
+        s = stride
+        # W_all[(p, co)][0:Cin] multiplies in[q-1] (tap p+s), [Cin:2Cin] multiplies in[q] (tap p)
+        wa = torch.empty(s, self.Cout, 2 * self.Cin, dtype=torch.float32)
+        for p in range(s):
+            wa[p, :, : self.Cin] = w[:, :, p + s].t()
+            wa[p, :, self.Cin:] = w[:, :, p].t()
+        self.W = wa.view(s * self.Cout, 2 * self.Cin).contiguous().to(dev)
+        self.b = b.repeat(s).contiguous().to(dev)
+        pt = self.k - self.s
+        self.trim_r = pt // 2
+        self.trim_l = pt - self.trim_r
+
+
+class _Lstm:
+    def __init__(self, sd, pfx, layers, dev):
+        self.layers = []
+        for l in range(layers):
+            wih, whh = sd[pfx + f"lstm.weight_ih_l{l}"], sd[pfx + f"lstm.weight_hh_l{l}"]
+            bias = sd[pfx + f"lstm.bias_ih_l{l}"] + sd[pfx + f"lstm.bias_hh_l{l}"]
+            self.layers.append((wih.contiguous().to(dev), whh.contiguous().to(dev), bias.contiguous().to(dev)))
+        self.C = self.layers[0][1].shape[1]
+
+
+class _SeaNet:
+    """One nn.Sequential of the reference (SEANetEncoder.model / SEANetDecoder.model), as a list of fused nodes."""
+
+    def __init__(self, sd, pfx: str, cfg: CodecConfig, decoder: bool, dev):
+        self.cfg, self.dev = cfg, dev
+        self.nodes: List[tuple] = []     # (model index of the node's first module, kind, obj)
+        i = 0
+        if not decoder:                  # seanet.py:113-150
+            self.nodes.append((i, "conv", _Conv(sd, f"{pfx}model.{i}.", 1, 0, dev)))
+            i += 1
+            for r in reversed(cfg.ratios):
+                self.nodes.append((i, "res", (_Conv(sd, f"{pfx}model.{i}.block.1.", 1, 1, dev), _Conv(sd, f"{pfx}model.{i}.block.3.", 1, 1, dev))))
+                self.nodes.append((i + 1, "conv", _Conv(sd, f"{pfx}model.{i + 2}.", r, 1, dev)))      # ELU (i+1) folded in
+                i += 3
+            if cfg.lstm:
+                self.nodes.append((i, "lstm", _Lstm(sd, f"{pfx}model.{i}.", cfg.lstm, dev)))
+                i += 1
+            self.nodes.append((i, "conv", _Conv(sd, f"{pfx}model.{i + 1}.", 1, 1, dev)))
+        else:                            # seanet.py:209-254
+            self.nodes.append((i, "conv", _Conv(sd, f"{pfx}model.{i}.", 1, 0, dev)))
+            i += 1
+            if cfg.lstm:
+                self.nodes.append((i, "lstm", _Lstm(sd, f"{pfx}model.{i}.", cfg.lstm, dev)))
+                i += 1
+            for r in cfg.ratios:
+                self.nodes.append((i, "convtr", _ConvTr(sd, f"{pfx}model.{i + 1}.", r, dev)))      # ELU (i) folded in
+                self.nodes.append((i + 2, "res", (_Conv(sd, f"{pfx}model.{i + 2}.block.1.", 1, 1, dev), _Conv(sd, f"{pfx}model.{i + 2}.block.3.", 1, 1, dev))))
+                i += 3
+            self.nodes.append((i, "conv", _Conv(sd, f"{pfx}model.{i + 1}.", 1, 1, dev)))
+
+    def slice_nodes(self, lo: int, hi: Optional[int]):
+        return [n for n in self.nodes if n[0] >= lo and (hi is None or n[0] < hi)]
+
+
+class WMEncodecModel:
+    def __init__(self, cfg: CodecConfig, state_dict: dict, device):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ssr_speech_amd codec needs a ROCm GPU device; there is no CPU path in this package")
+        self.lib = _lib.lib()
+        sd = {k: v.detach().to(torch.float32).cpu() for k, v in state_dict.items()}
+        dev = self.device
+        self.encoder = _SeaNet(sd, "encoder.", cfg, False, dev)
+        self.decoder = _SeaNet(sd, "decoder.", cfg, True, dev)
+        self.has_wm = "wmdecoder.wm_embed.weight" in sd
+        if self.has_wm:
+            self.wmdecoder = _SeaNet(sd, "wmdecoder.", cfg, True, dev)
+            self.skip_encoder = _SeaNet(sd, "wmdecoder.skip_encoder.", cfg, False, dev)
+            self.wm_encoder = _SeaNet(sd, "wmdecoder.wm_encoder.", cfg, False, dev)
+            self.wm_proj = [_Conv(sd, f"wmdecoder.wm_proj{j}.1.", 1, 1, dev) for j in range(4)]
+            self.wm_predictor = _Conv(sd, "wmdecoder.wm_predictor.1.", 1, 1, dev)
+            w = sd["wmdecoder.wm_embed.weight"]                       # nn.Embedding(2, D/16, max_norm=True) (seanet.py:503)
+            norm = w.norm(p=2, dim=1, keepdim=True)
+            self.wm_table = torch.where(norm > 1.0, w * (1.0 / (norm + 1e-7)), w).contiguous().to(dev)
+        self.codebooks = torch.stack([sd[f"quantizer.vq.layers.{q}._codebook.embed"] for q in range(cfg.n_q)]).contiguous().to(dev)
+        self.e2 = self.codebooks.pow(2).sum(-1).contiguous()          # |e|^2 (core_vq.py:169)
+        self.sample_rate, self.channels, self.frame_rate = cfg.sample_rate, cfg.channels, cfg.frame_rate
+
+    # ------------------------------------------------------------------ low-level launches
+    def _s(self):
+        return _lib.stream_ptr()
+
+    def _gemm(self, A, W, bias, Cp, M, N, K, lda, ldc, act_in=0, R=0, ldr=0, batch=1, sA=0, sC=0, sR=0, tm=(0, 0, 0)):
+        a = _lib.GemmArgs()
+        a.A, a.W, a.bias, a.C = A, W.data_ptr(), (bias.data_ptr() if bias is not None else 0), Cp
+        a.M, a.N, a.K, a.lda, a.ldc = M, N, K, lda, ldc
+        a.act_in, a.R, a.ldr, a.batch = act_in, R, ldr, batch
+        a.strideA, a.strideC, a.strideR = sA, sC, sR
+        a.tm_c, a.tm_lo, a.tm_hi = tm
+        _lib.check(self.lib.ssrhip_gemm(C.byref(a), self._s()), "ssrhip_gemm")
+
+    def _fill_pads(self, buf: TM, structural_zero: bool = False):
+        if self.cfg.pad_mode == "reflect" and not structural_zero and (buf.padL + buf.padR) > 0:
+            if buf.T <= max(buf.padL, buf.padR):
+                raise NotImplementedError("reflect padding of an input shorter than the pad (conv.py:79-83 zero-extension) is not implemented")
+            _lib.check(self.lib.ssrhip_pad_reflect(buf.base, buf.B, buf.T, buf.padL, buf.padR, buf.C, buf.bstride, self._s()), "ssrhip_pad_reflect")
+        elif self.cfg.pad_mode not in ("constant", "reflect"):
+            raise ValueError(self.cfg.pad_mode)
+
+    def _need(self, node, T) -> Tuple[int, int, bool]:
+        """(padL, padR, structural) the node wants on its input of interior length T."""
+        if node is None:
+            return 0, 0, False
+        kind, obj = node[1], node[2]
+        if kind == "conv":
+            pl, pr = obj.pads(T)
+            return pl, pr, False
+        if kind == "res":
+            pl, pr = obj[0].pads(T)
+            return pl, pr, False
+        if kind == "convtr":
+            return 1, 1, True
+        return 0, 0, False
+
+    def _alloc_for(self, B, T, Cc, nxt) -> TM:
+        pl, pr, _ = self._need(nxt, T)
+        return TM(B, T, Cc, pl, pr, self.device)
+
+    # ------------------------------------------------------------------ nodes
+    def _conv(self, c: _Conv, x: TM, nxt, R: Optional[TM] = None) -> TM:
+        B = x.B
+        T_out = (x.T + x.padL + x.padR - c.k) // c.s + 1
+        out = self._alloc_for(B, T_out, c.Cout, nxt)
+        if c.Cin == 1:
+            assert c.act_in == 0
+            _lib.check(self.lib.ssrhip_conv_cin1(x.base, c.Wraw.data_ptr(), c.b.data_ptr(), out.interior, B, T_out, c.k, c.s, c.Cout,
+                                                 x.bstride, out.bstride, self._s()), "ssrhip_conv_cin1")
+        else:
+            self._gemm(x.base, c.W, c.b, out.interior, T_out, c.Cout, c.k * c.Cin, c.s * c.Cin, c.Cout, act_in=(_lib.ACT_ELU if c.act_in else 0),
+                       R=(R.interior if R is not None else 0), ldr=(R.C if R is not None else 0), batch=B, sA=x.bstride, sC=out.bstride,
+                       sR=(R.bstride if R is not None else 0))
+        self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
+        return out
+
+    def _convtr(self, c: _ConvTr, x: TM, nxt) -> TM:
+        assert x.padL == 1 and x.padR == 1
+        T_out = x.T * c.s
+        out = self._alloc_for(x.B, T_out, c.Cout, nxt)
+        Cp = out.interior - 4 * c.trim_l * c.Cout
+        self._gemm(x.base, c.W, c.b, Cp, x.T + 1, c.s * c.Cout, 2 * c.Cin, c.Cin, c.s * c.Cout, act_in=_lib.ACT_ELU, batch=x.B,
+                   sA=x.bstride, sC=out.bstride, tm=(c.Cout, c.trim_l, c.trim_l + T_out))
+        self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
+        return out
+
+    def _res(self, cs, x: TM, nxt) -> TM:
+        h = self._conv(cs[0], x, None)
+        return self._conv(cs[1], h, nxt, R=x)
+
+    def _lstm(self, L: _Lstm, x: TM, nxt) -> TM:
+        B, T, Cc = x.B, x.T, x.C
+        dev = self.device
+        assert x.padL == 0 and x.padR == 0
+        gin = torch.empty(B, T, 4 * Cc, dtype=torch.float32, device=dev)
+        hbuf = torch.empty(2, B, Cc, dtype=torch.float32, device=dev)
+        cbuf = torch.empty(B, Cc, dtype=torch.float32, device=dev)
+        gates = torch.empty(B, 4 * Cc, dtype=torch.float32, device=dev) if B > 4 else None
+        cur_ptr, cur_bs = x.interior, x.bstride
+        out = None
+        for l, (wih, whh, bias) in enumerate(L.layers):
+            last = l == len(L.layers) - 1
+            self._gemm(cur_ptr, wih, bias, gin.data_ptr(), T, 4 * Cc, Cc, Cc, 4 * Cc, batch=B, sA=cur_bs, sC=T * 4 * Cc)
+            out = self._alloc_for(B, T, Cc, nxt) if last else TM(B, T, Cc, 0, 0, dev)
+            a = _lib.LstmArgs()
+            a.gin, a.w_hh, a.out = gin.data_ptr(), whh.data_ptr(), out.interior
+            a.skip = x.interior if last else 0                         # y = lstm(x) + x (lstm.py:21-23)
+            a.hbuf, a.cbuf, a.gates = hbuf.data_ptr(), cbuf.data_ptr(), (gates.data_ptr() if gates is not None else 0)
+            a.B, a.T, a.C = B, T, Cc
+            a.gin_bstride, a.out_bstride, a.skip_bstride = T * 4 * Cc, out.bstride, x.bstride
+            _lib.check(self.lib.ssrhip_lstm_layer(C.byref(a), self._s()), "ssrhip_lstm_layer")
+            cur_ptr, cur_bs = out.interior, out.bstride
+        self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
+        self._keep = (gin, hbuf, cbuf, gates)
+        return out
+
+    def _run(self, nodes, x: TM, after=None) -> TM:
+        """Run consecutive nodes; `after` = the node that will consume the result (decides its halo)."""
+        for idx, node in enumerate(nodes):
+            nxt = nodes[idx + 1] if idx + 1 < len(nodes) else after
+            kind, obj = node[1], node[2]
+            if kind == "conv":
+                x = self._conv(obj, x, nxt)
+            elif kind == "convtr":
+                x = self._convtr(obj, x, nxt)
+            elif kind == "res":
+                x = self._res(obj, x, nxt)
+            elif kind == "lstm":
+                x = self._lstm(obj, x, nxt)
+        return x
+
+    def _input_tm(self, wav: torch.Tensor, first) -> TM:
+        """[B,1,T] -> time-major buffer with the first node's halo."""
+        assert wav.dim() == 3 and wav.shape[1] == self.channels == 1, wav.shape
+        B, _, T = wav.shape
+        x = self._alloc_for(B, T, 1, first)
+        x.data[:, x.padL: x.padL + T, 0] = wav[:, 0].to(self.device, torch.float32)
+        self._fill_pads(x)
+        return x
+
+    # ------------------------------------------------------------------ public API (wmencodec.py:324-386)
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor):
+        """-> (codes int64 [B,K,T'], scale=None (renormalize False), emb f32 [B,D,T'])."""
+        assert x.dim() == 3
+        inp = self._input_tm(x, self.encoder.nodes[0])
+        emb = self._run(self.encoder.nodes, inp)
+        B, T, D = emb.B, emb.T, emb.C
+        codes = torch.empty(B, self.cfg.n_q, T, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.ssrhip_rvq_encode(emb.interior, self.codebooks.data_ptr(), self.e2.data_ptr(), codes.data_ptr(), B, T, D,
+                                              self.cfg.n_q, self.cfg.bins, emb.bstride, self._s()), "ssrhip_rvq_encode")
+        return codes.to(torch.int64), None, emb.interior_view().transpose(1, 2).contiguous()
+
+    def _dequant(self, codes: torch.Tensor, nxt) -> TM:
+        assert codes.dim() == 3
+        B, K, T = codes.shape
+        c32 = codes.to(self.device, torch.int32).contiguous()
+        if T > 0 and (int(c32.max()) >= self.cfg.bins or int(c32.min()) < 0):
+            raise IndexError("index out of range in self")            # what F.embedding raises in the reference (core_vq.py:175)
+        out = self._alloc_for(B, T, self.cfg.dimension, nxt)
+        _lib.check(self.lib.ssrhip_rvq_decode(c32.data_ptr(), self.codebooks.data_ptr(), out.interior, B, T, self.cfg.dimension, K,
+                                              self.cfg.bins, out.bstride, self._s()), "ssrhip_rvq_decode")
+        self._fill_pads(out)
+        return out
+
+    @torch.no_grad()
+    def decode_latent(self, codes: torch.Tensor) -> torch.Tensor:
+        return self._dequant(codes, None).interior_view().transpose(1, 2).contiguous()
+
+    @torch.no_grad()
+    def decode(self, codes: torch.Tensor, scale=None) -> torch.Tensor:
+        assert scale is None, "renormalize=False codec: scale must be None (wmencodec.py:199-203)"
+        z = self._dequant(codes, self.decoder.nodes[0])
+        y = self._run(self.decoder.nodes, z)
+        return y.interior_view().transpose(1, 2).contiguous()
+
+    def _concat_proj(self, j: int, skip: TM, labels32: torch.Tensor, rep: int, x: TM, nxt) -> TM:
+        """wm_proj_j(ELU(cat(skip, wm_embed(labels upsampled)))) + x   (seanet.py:577-591)."""
+        c = self.wm_proj[j]
+        E = self.wm_table.shape[1]
+        assert skip.T == x.T and skip.C + E == c.Cin, (skip.T, x.T, skip.C, E, c.Cin)
+        cat = TM(skip.B, skip.T, skip.C + E, 0, 0, self.device)
+        _lib.check(self.lib.ssrhip_wm_concat(skip.interior, labels32.data_ptr(), self.wm_table.data_ptr(), cat.interior, skip.B, skip.T,
+                                             skip.C, E, rep, labels32.shape[1], skip.bstride, cat.bstride, self._s()), "ssrhip_wm_concat")
+        return self._conv(c, cat, nxt, R=x)
+
+    @torch.no_grad()
+    def wmdecode(self, codes: torch.Tensor, labels: torch.Tensor, wavform: torch.Tensor, scale=None, with_mark: bool = True):
+        """-> (wav [B,1,T], mark [B,T',2]) as wmencodec.py:358-375. `with_mark=False` skips the detector pass whose
+        output `AudioTokenizer.wmdecode` discards (data/tokenizer.py:133) and returns mark=None."""
+        assert scale is None and self.has_wm
+        r = list(self.cfg.ratios)
+        assert len(r) == 4, "the watermark decoder's slicing (seanet.py:560-591) is written for 4 ratios"
+        lab = labels.to(self.device, torch.int32).contiguous()
+        dec, senc = self.wmdecoder, self.skip_encoder
+        cuts = [(0, 4), (4, 7), (7, 10), (10, None)]
+        dn = [dec.slice_nodes(lo, hi) for lo, hi in cuts]
+        # skip features at 4 scales; every skip is consumed by a k=1 conv => no halo
+        z = self._run(senc.slice_nodes(0, 2), self._input_tm(wavform, senc.nodes[0]), after=senc.slice_nodes(2, 5)[0])
+        sk = []
+        for lo, hi in [(2, 5), (5, 8), (8, 11), (11, None)]:
+            nxt_nodes = senc.slice_nodes(hi, None) if hi is not None else []
+            z = self._run(senc.slice_nodes(lo, hi), z, after=(nxt_nodes[0] if nxt_nodes else None))
+            sk.append(z)
+        reps = [r[0] * r[1] * r[2], r[0] * r[1], r[0], 1]
+        x = self._dequant(codes, None)
+        for j in range(4):
+            skip, rep = sk[3 - j], reps[3 - j]
+            out = self._concat_proj(j, skip, lab, rep, x, dn[j][0])
+            x = self._run(dn[j], out, after=None)
+        wav = x.interior_view().transpose(1, 2).contiguous()
+        if not with_mark:
+            return wav, None
+        m = self._run(self.wm_encoder.nodes, self._input_tm(wav, self.wm_encoder.nodes[0]), after=None)
+        mk = self._conv(self.wm_predictor, m, None)
+        return wav, mk.interior_view().contiguous()
+
+    @torch.no_grad()
+    def detect_watermark(self, x: torch.Tensor) -> torch.Tensor:
+        """wmencodec.py:377-382, including its argmax over the LAST dim of [B,2,T'] (time)."""
+        assert x.dim() == 3
+        m = self._run(self.wm_encoder.nodes, self._input_tm(x, self.wm_encoder.nodes[0]), after=None)
+        mk = self._conv(self.wm_predictor, m, None).interior_view().transpose(1, 2)      # [B,2,T']
+        return torch.argmax(mk.squeeze(-1), dim=-1)

@@ -1,0 +1,295 @@
+// codec.hip — the watermarked-Encodec kernels that are not plain GEMMs (gfx950).
+//
+// Activations are time-major fp32 ([rows][C], C contiguous): convolutions and transposed convolutions run on
+// ssrhip_gemm over strided views (see include/ssrhip.h), so what is left here is
+//   * the first SEANet conv (C_in = 1, K = 7: too thin for a GEMM; pure HBM streaming, coalesced over C_out),
+//   * reflect padding of a padded buffer's halo rows,
+//   * the LSTM recurrence: per time step ONE kernel = recurrent GEMV (the 4 gate rows of a hidden unit per
+//     wave, h_{t-1} in registers) fused with the gate non-linearities and the optional skip add; W_hh
+//     (16.8 MB at C=1024) is re-read every step from L2/Infinity Cache,
+//   * residual vector quantisation: nearest codebook row per frame (block per frame, scores in the
+//     reference's arithmetic form, first-max tie rule) and the gather-sum dequantiser,
+//   * the watermark-label concat.
+#include <string.h>
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void conv_cin1_kernel(const float* x, const float* w, const float* bias, float* out, int T_out,
+                                                        int k, int stride, int Cout, long x_bstride, long out_bstride) {
+  // thread -> (t, co) with co fastest: coalesced stores; x reads are broadcast within a row of threads
+  const long total = (long)T_out * Cout;
+  const float* xb = x + (size_t)blockIdx.y * x_bstride;
+  float* ob = out + (size_t)blockIdx.y * out_bstride;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int t = (int)(i / Cout), co = (int)(i % Cout);
+    float acc = 0.f;
+    for (int kk = 0; kk < k; ++kk) acc = fmaf(w[co * k + kk], xb[(size_t)t * stride + kk], acc);
+    ob[i] = acc + bias[co];
+  }
+}
+
+__global__ __launch_bounds__(256) void pad_reflect_kernel(float* buf, int T, int padL, int padR, int C, long bstride) {
+  float* b = buf + (size_t)blockIdx.y * bstride;
+  const long total = (long)(padL + padR) * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int p = (int)(i / C), c = (int)(i % C);
+    int dst, src;
+    if (p < padL) { dst = p; src = padL + (padL - p); }                       // interior index (padL - p), edge excluded
+    else { const int r = p - padL; dst = padL + T + r; src = padL + (T - 2 - r); }
+    b[(size_t)dst * C + c] = b[(size_t)src * C + c];
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// One LSTM time step for B <= 4 items. Wave -> hidden unit j (4 gate rows j, C+j, 2C+j, 3C+j of W_hh).
+template <int B>
+__global__ __launch_bounds__(256) void lstm_step_kernel(const ssrhip_lstm_args a, int t, const float* hprev, float* hnext) {
+  constexpr int MAXC4 = 8;                       // C <= 2048
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = a.C;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= C) return;
+  const int nch = (C + 255) / 256;
+  float4 h[B][MAXC4];
+#pragma unroll
+  for (int b = 0; b < B; ++b)
+#pragma unroll
+    for (int i = 0; i < MAXC4; ++i) {
+      const int k = (i * 64 + lane) * 4;
+      h[b][i] = (i < nch && k < C) ? ld4(hprev + (size_t)b * C + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  float g[4][B];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float* wr = a.w_hh + ((size_t)q * C + j) * C;
+    float s[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) s[b] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC4; ++i) {
+      const int k = (i * 64 + lane) * 4;
+      if (i < nch && k < C) {
+        const float4 w = ld4(wr + k);
+#pragma unroll
+        for (int b = 0; b < B; ++b) s[b] = dot4(w, h[b][i], s[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) g[q][b] = wave_sum(s[b]);
+  }
+  if (lane < B) {
+    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+      if (lane == b) { gi = g[0][b]; gf = g[1][b]; gg = g[2][b]; go = g[3][b]; }
+    const int b = lane;
+    const float* gin = a.gin + (size_t)b * a.gin_bstride + (size_t)t * 4 * C;
+    gi += gin[j]; gf += gin[C + j]; gg += gin[2 * C + j]; go += gin[3 * C + j];
+    float* cc = a.cbuf + (size_t)b * C + j;
+    const float cprev = (t == 0) ? 0.f : *cc;
+    const float cn = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
+    const float hn = sigmoidf_(go) * tanhf(cn);
+    *cc = cn;
+    hnext[(size_t)b * C + j] = hn;
+    float o = hn;
+    if (a.skip) o += a.skip[(size_t)b * a.skip_bstride + (size_t)t * C + j];
+    a.out[(size_t)b * a.out_bstride + (size_t)t * C + j] = o;
+  }
+}
+
+// Gate math for the large-batch path (recurrent part computed by ssrhip_gemm into a.gates [B][4C]).
+__global__ __launch_bounds__(256) void lstm_gates_kernel(const ssrhip_lstm_args a, int t, float* hnext) {
+  const int C = a.C;
+  const long total = (long)a.B * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / C), j = (int)(i % C);
+    const float* gr = a.gates + (size_t)b * 4 * C;
+    const float* gin = a.gin + (size_t)b * a.gin_bstride + (size_t)t * 4 * C;
+    const float gi = gr[j] + gin[j], gf = gr[C + j] + gin[C + j], gg = gr[2 * C + j] + gin[2 * C + j], go = gr[3 * C + j] + gin[3 * C + j];
+    float* cc = a.cbuf + (size_t)b * C + j;
+    const float cprev = (t == 0) ? 0.f : *cc;
+    const float cn = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
+    const float hn = sigmoidf_(go) * tanhf(cn);
+    *cc = cn;
+    hnext[(size_t)b * C + j] = hn;
+    float o = hn;
+    if (a.skip) o += a.skip[(size_t)b * a.skip_bstride + (size_t)t * C + j];
+    a.out[(size_t)b * a.out_bstride + (size_t)t * C + j] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void zero_kernel(float* p, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0.f;
+}
+
+// RVQ encode: one workgroup per frame. score_j = -(|x|^2 - (2x).e_j + |e_j|^2) exactly as
+// EuclideanCodebook.quantize writes it (core_vq.py:164-172); argmax with the first-index tie rule of torch.max.
+__global__ __launch_bounds__(256) void rvq_encode_kernel(const float* emb, const float* cb, const float* e2, int* codes, int T, int D,
+                                                         int n_q, int bins, long emb_bstride) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* x = sm;                 // [D]
+  float* red = sm + D;           // [8]
+  int* redi = reinterpret_cast<int*>(red + 8);
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* src = emb + (size_t)b * emb_bstride + (size_t)t * D;
+  for (int d = tid; d < D; d += 256) x[d] = src[d];
+  __syncthreads();
+  for (int q = 0; q < n_q; ++q) {
+    float p = 0.f;
+    for (int d = tid; d < D; d += 256) p += x[d] * x[d];
+    p = wave_sum(p);
+    if (lane == 0) red[wave] = p;
+    __syncthreads();
+    const float x2 = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    const float* E = cb + (size_t)q * bins * D;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < bins; j += 256) {
+      const float* e = E + (size_t)j * D;
+      float dot = 0.f;
+      for (int d = 0; d < D; d += 4) {
+        const float4 ev = ld4(e + d);
+        const float4 xv = *reinterpret_cast<const float4*>(x + d);
+        dot = fmaf(2.0f * xv.x, ev.x, dot);
+        dot = fmaf(2.0f * xv.y, ev.y, dot);
+        dot = fmaf(2.0f * xv.z, ev.z, dot);
+        dot = fmaf(2.0f * xv.w, ev.w, dot);
+      }
+      const float sc = -((x2 - dot) + e2[(size_t)q * bins + j]);
+      if (sc > best) { best = sc; bi = j; }       // j ascending per thread: first max kept
+    }
+    const float wb = wave_max(best);
+    int wi = (best == wb) ? bi : 0x7fffffff;
+    wi = wave_min_i(wi);
+    if (lane == 0) { red[wave] = wb; redi[wave] = wi; }
+    __syncthreads();
+    float bb = red[0];
+    int ii = redi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (red[w] > bb || (red[w] == bb && redi[w] < ii)) { bb = red[w]; ii = redi[w]; }
+    if (tid == 0) codes[((size_t)b * n_q + q) * T + t] = ii;
+    const float* e = E + (size_t)ii * D;
+    __syncthreads();
+    for (int d = tid; d < D; d += 256) x[d] -= e[d];      // residual = residual - quantized (core_vq.py:389-390)
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(128) void rvq_decode_kernel(const int* codes, const float* cb, float* out, int T, int D, int n_q, int bins,
+                                                         long out_bstride) {
+  const int t = blockIdx.x, b = blockIdx.y;
+  for (int d = threadIdx.x; d < D; d += 128) {
+    float acc = 0.0f;                              // quantized_out = 0.0 + q0 + q1 + ... (core_vq.py:395-399)
+    for (int q = 0; q < n_q; ++q) {
+      const int c = codes[((size_t)b * n_q + q) * T + t];
+      acc += cb[((size_t)q * bins + c) * D + d];
+    }
+    out[(size_t)b * out_bstride + (size_t)t * D + d] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void wm_concat_kernel(const float* skip, const int* labels, const float* table, float* cat, int T, int C,
+                                                        int E, int rep, int n_labels, long skip_bstride, long cat_bstride) {
+  const int W = C + E;
+  const long total = (long)T * W;
+  const float* sb = skip + (size_t)blockIdx.y * skip_bstride;
+  float* cbp = cat + (size_t)blockIdx.y * cat_bstride;
+  const int* lb = labels + (size_t)blockIdx.y * n_labels;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int t = (int)(i / W), c = (int)(i % W);
+    cbp[i] = (c < C) ? sb[(size_t)t * C + c] : table[lb[t / rep] * E + (c - C)];
+  }
+}
+
+inline int nblocks(long total, int cap = 4096) {
+  long n = (total + 255) / 256;
+  return (int)(n < 1 ? 1 : (n > cap ? cap : n));
+}
+
+}  // namespace
+
+extern "C" int ssrhip_conv_cin1(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t T_out, int32_t k,
+                                int32_t stride, int32_t Cout, int64_t x_bstride, int64_t out_bstride, ssrhip_stream_t stream) {
+  SSR_REQUIRE(x && w && bias && out && B > 0 && T_out > 0 && k > 0 && stride > 0 && Cout > 0, "ssrhip_conv_cin1: bad argument");
+  dim3 grid(nblocks((long)T_out * Cout, 16384), B);
+  hipLaunchKernelGGL(conv_cin1_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, T_out, k, stride, Cout, (long)x_bstride, (long)out_bstride);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ssrhip_pad_reflect(float* buf, int32_t B, int32_t T, int32_t padL, int32_t padR, int32_t C, int64_t bstride, ssrhip_stream_t stream) {
+  SSR_REQUIRE(buf && B > 0 && T > 0 && C > 0 && padL >= 0 && padR >= 0, "ssrhip_pad_reflect: bad argument");
+  SSR_REQUIRE(T > padL && T > padR, "ssrhip_pad_reflect: reflect padding needs T (%d) > pads (%d,%d)", T, padL, padR);
+  if (padL + padR == 0) return 0;
+  dim3 grid(nblocks((long)(padL + padR) * C), B);
+  hipLaunchKernelGGL(pad_reflect_kernel, grid, dim3(256), 0, (hipStream_t)stream, buf, T, padL, padR, C, (long)bstride);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stream) {
+  SSR_REQUIRE(a && a->gin && a->w_hh && a->out && a->hbuf && a->cbuf, "ssrhip_lstm_layer: null argument");
+  SSR_REQUIRE(a->B > 0 && a->T > 0 && a->C > 0 && a->C % 4 == 0 && a->C <= 2048, "ssrhip_lstm_layer: need C %% 4 == 0, C <= 2048");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t hc = (size_t)a->B * a->C;
+  hipLaunchKernelGGL(zero_kernel, dim3(nblocks(2 * hc)), dim3(256), 0, s, a->hbuf, (long)(2 * hc));   // h_0 = 0
+  {
+    if (a->B <= 4) {
+      for (int t = 0; t < a->T; ++t) {
+        const float* hp = a->hbuf + (size_t)(t & 1) * hc;
+        float* hn = a->hbuf + (size_t)((t + 1) & 1) * hc;
+        dim3 grid((a->C + 3) / 4);
+        switch (a->B) {
+          case 1: hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, s, *a, t, hp, hn); break;
+          case 2: hipLaunchKernelGGL(lstm_step_kernel<2>, grid, dim3(256), 0, s, *a, t, hp, hn); break;
+          case 3: hipLaunchKernelGGL(lstm_step_kernel<3>, grid, dim3(256), 0, s, *a, t, hp, hn); break;
+          default: hipLaunchKernelGGL(lstm_step_kernel<4>, grid, dim3(256), 0, s, *a, t, hp, hn); break;
+        }
+      }
+    } else {
+      SSR_REQUIRE(a->gates, "ssrhip_lstm_layer: B > 4 needs the gates scratch buffer");
+      for (int t = 0; t < a->T; ++t) {
+        const float* hp = a->hbuf + (size_t)(t & 1) * hc;
+        float* hn = a->hbuf + (size_t)((t + 1) & 1) * hc;
+        ssrhip_gemm_args g;
+        memset(&g, 0, sizeof(g));
+        g.A = hp; g.W = a->w_hh; g.C = a->gates; g.M = a->B; g.N = 4 * a->C; g.K = a->C; g.lda = a->C; g.ldc = 4 * a->C;
+        if (int rc = ssrhip_gemm(&g, stream)) return rc;
+        hipLaunchKernelGGL(lstm_gates_kernel, dim3(nblocks((long)hc)), dim3(256), 0, s, *a, t, hn);
+      }
+    }
+  }
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ssrhip_rvq_encode(const float* emb, const float* codebooks, const float* e2, int32_t* codes, int32_t B, int32_t T,
+                                 int32_t D, int32_t n_q, int32_t bins, int64_t emb_bstride, ssrhip_stream_t stream) {
+  SSR_REQUIRE(emb && codebooks && e2 && codes && B > 0 && T > 0 && D > 0 && D % 4 == 0 && n_q > 0 && bins > 0, "ssrhip_rvq_encode: bad argument");
+  SSR_REQUIRE(B <= 65535, "ssrhip_rvq_encode: B too large");
+  const size_t smem = ((size_t)D + 16) * sizeof(float);
+  hipLaunchKernelGGL(rvq_encode_kernel, dim3(T, B), dim3(256), smem, (hipStream_t)stream, emb, codebooks, e2, codes, T, D, n_q, bins, (long)emb_bstride);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ssrhip_rvq_decode(const int32_t* codes, const float* codebooks, float* out, int32_t B, int32_t T, int32_t D, int32_t n_q,
+                                 int32_t bins, int64_t out_bstride, ssrhip_stream_t stream) {
+  SSR_REQUIRE(codes && codebooks && out && B > 0 && T > 0 && D > 0 && n_q > 0 && bins > 0 && B <= 65535, "ssrhip_rvq_decode: bad argument");
+  hipLaunchKernelGGL(rvq_decode_kernel, dim3(T, B), dim3(128), 0, (hipStream_t)stream, codes, codebooks, out, T, D, n_q, bins, (long)out_bstride);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ssrhip_wm_concat(const float* skip, const int32_t* labels, const float* table, float* cat, int32_t B, int32_t T, int32_t C,
+                                int32_t E, int32_t rep, int32_t n_labels, int64_t skip_bstride, int64_t cat_bstride, ssrhip_stream_t stream) {
+  SSR_REQUIRE(skip && labels && table && cat && B > 0 && T > 0 && C > 0 && E > 0 && rep > 0 && n_labels * rep >= T, "ssrhip_wm_concat: bad argument");
+  dim3 grid(nblocks((long)T * (C + E), 16384), B);
+  hipLaunchKernelGGL(wm_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, skip, labels, table, cat, T, C, E, rep, n_labels, (long)skip_bstride, (long)cat_bstride);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}

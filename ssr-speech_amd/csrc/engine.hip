@@ -38,6 +38,7 @@ extern "C" int ssrhip_sizeof(int which) {
     case 9: return sizeof(ssrhip_lm_dims);
     case 10: return sizeof(ssrhip_lm_buffers);
     case 11: return sizeof(ssrhip_prefill_args);
+    case 12: return sizeof(ssrhip_lstm_args);
     default: return -1;
   }
 }

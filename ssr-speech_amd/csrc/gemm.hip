@@ -23,9 +23,18 @@ __device__ __forceinline__ float act_fn(float v, int act) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a) {
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }   // nn.ELU(alpha=1)
+
+__global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
   __shared__ __attribute__((aligned(16))) float As[BM * LDSW];
   __shared__ __attribute__((aligned(16))) float Ws[BN * LDSW];
+  ssrhip_gemm_args a = a0;
+  {   // batched problems: grid.z
+    const size_t z = blockIdx.z;
+    a.A += z * (size_t)a.strideA;
+    a.C += z * (size_t)a.strideC;
+    if (a.R) a.R += z * (size_t)a.strideR;
+  }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
   const int lr = t >> 2, lc = (t & 3) * 4;            // loader: row, first k column
@@ -38,6 +47,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a) {
   auto gload = [&](int k0, float4& ra, float4& rw0, float4& rw1) {
     const bool kin = (k0 + lc) < K;
     ra = (kin && (m0 + lr) < M) ? ld4(a.A + (size_t)(m0 + lr) * a.lda + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.act_in == SSRHIP_ACT_ELU) { ra.x = elu1(ra.x); ra.y = elu1(ra.y); ra.z = elu1(ra.z); ra.w = elu1(ra.w); }
     rw0 = (kin && (n0 + lr) < N) ? ld4(a.W + (size_t)(n0 + lr) * K + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
     rw1 = (kin && (n0 + lr + 64) < N) ? ld4(a.W + (size_t)(n0 + lr + 64) * K + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
@@ -76,9 +86,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m < M) {
+          if (a.tm_c > 0) {   // transposed-conv trimming: rows of the full output outside [tm_lo, tm_hi) are not stored
+            const long u = ((long)m * N + n) / a.tm_c;
+            if (u < a.tm_lo || u >= a.tm_hi) continue;
+          }
           float v = act_fn(acc[mt][r] + bias, a.act);
           float* c = a.C + (size_t)m * a.ldc + n;
           if (a.residual) v += *c;
+          if (a.R) v += a.R[(size_t)m * a.ldr + n];
           *c = v;
         }
       }
@@ -137,7 +152,8 @@ __global__ __launch_bounds__(256) void kv_scatter_kernel(const float* qkv, const
 extern "C" int ssrhip_gemm(const ssrhip_gemm_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->A && a->W && a->C, "ssrhip_gemm: null argument");
   SSR_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 4 == 0 && a->lda % 4 == 0, "ssrhip_gemm: K and lda must be multiples of 4");
-  dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM);
+  SSR_REQUIRE(a->batch <= 65535 && (a->M + BM - 1) / BM <= 65535, "ssrhip_gemm: grid too large (M=%d batch=%d)", a->M, a->batch);
+  dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM, a->batch > 1 ? a->batch : 1);
   hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
   SSR_LAUNCH_CHECK();
   return 0;

@@ -196,7 +196,7 @@ def codec_config_full() -> CodecConfig:
 
 
 def codec_config_tiny() -> CodecConfig:
-    return CodecConfig(dimension=32, n_filters=8, ratios=(4, 3, 2, 2), bins=64)   # hop 48; the wm decoder needs 4 ratios
+    return CodecConfig(dimension=64, n_filters=8, ratios=(4, 3, 2, 2), bins=64)   # hop 48; the wm decoder needs 4 ratios; D/16 = 4 label channels
 
 
 def _conv_specs(sp, pfx, cout, cin, k, wn=True):

@@ -1,0 +1,99 @@
+"""GPU: the HIP codec (`ssr_speech_amd.codec.wmencodec.WMEncodecModel`, all arithmetic through the C-ABI) against the
+REFERENCE's golden vectors (tests/golden/codec_*.npz). Bars: fp32 activations within 2e-4 absolute of the reference
+(values are O(1); conv/LSTM chains of ~40 layers, different summation order); RVQ codes identical except where the
+reference's own top-1/top-2 distance margin is below 1e-4 (an fp32 tie)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ssr_speech_amd  # noqa: F401
+from ssr_speech_amd import weights as W
+from ssr_speech_amd.codec.wmencodec import WMEncodecModel
+from oracle import codec as OC
+
+pytestmark = pytest.mark.gpu
+ATOL = 2e-4
+CASES = sorted(os.path.basename(p)[6:-4] for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "codec_*.npz")))
+
+
+def load_case(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"codec_{name}.npz"))
+    c = [int(v) for v in g["cfg"]]
+    cfg = W.CodecConfig(dimension=c[0], n_filters=c[1], bins=c[2], n_q=c[3], ratios=tuple(c[4:]), pad_mode=str(g["pad_mode"]))
+    sd = W.codec_state_dict(cfg, seed=int(g["weight_seed"]))
+    return g, cfg, sd
+
+
+def code_margins(sd, cfg, emb, codes):
+    """top-1 minus top-2 score of every RVQ decision along the reference's own residual path."""
+    B, D, T = emb.shape
+    res = emb.clone()
+    out = torch.zeros(B, cfg.n_q, T)
+    for q in range(cfg.n_q):
+        E = sd[f"quantizer.vq.layers.{q}._codebook.embed"]
+        x = res.permute(0, 2, 1).reshape(-1, D)
+        dist = -(x.pow(2).sum(1, keepdim=True) - 2 * x @ E.t() + E.t().pow(2).sum(0, keepdim=True))
+        top2 = dist.topk(2, dim=-1).values
+        out[:, q] = (top2[:, 0] - top2[:, 1]).view(B, T)
+        res = res - torch.nn.functional.embedding(codes[:, q], E).permute(0, 2, 1)
+    return out
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_codec_matches_reference(golden_dir, name):
+    g, cfg, sd = load_case(golden_dir, name)
+    m = WMEncodecModel(cfg, sd, "cuda")
+    wav = torch.from_numpy(g["wav"])
+    codes, scale, emb = m.encode(wav.cuda())
+    assert scale is None and codes.dtype == torch.int64 and tuple(codes.shape) == g["codes"].shape
+    np.testing.assert_allclose(emb.cpu().numpy(), g["emb"], rtol=0, atol=ATOL)
+    ref_codes = torch.from_numpy(g["codes"])
+    diff = codes.cpu() != ref_codes
+    if diff.any():
+        marg = code_margins(sd, cfg, torch.from_numpy(g["emb"]), ref_codes)
+        # a flipped code changes the residual of the later codebooks of that frame: only the FIRST flip per frame is judged
+        first = diff.float().cumsum(1) == 1
+        assert (marg[diff & first] < 1e-4).all(), (int(diff.sum()), marg[diff & first])
+    dec = m.decode(ref_codes.cuda())
+    np.testing.assert_allclose(dec.cpu().numpy(), g["decoded"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(m.decode_latent(ref_codes.cuda()).cpu().numpy(), OC.rvq_decode(sd, ref_codes, cfg).numpy(), rtol=0, atol=1e-6)
+    out, mark = m.wmdecode(ref_codes.cuda(), torch.from_numpy(g["labels"]).cuda(), torch.from_numpy(g["wav_pad"]).cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), g["wmdecoded"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(mark.cpu().numpy(), g["mark"], rtol=0, atol=ATOL)
+    out2, none = m.wmdecode(ref_codes.cuda(), torch.from_numpy(g["labels"]).cuda(), torch.from_numpy(g["wav_pad"]).cuda(), with_mark=False)
+    assert none is None and torch.equal(out2, out)
+    det = m.detect_watermark(torch.from_numpy(g["wmdecoded"]).cuda())
+    assert tuple(det.shape) == g["detect"].shape
+
+
+def test_codec_roundtrip_shapes_and_errors():
+    cfg = W.codec_config_tiny()
+    sd = W.codec_state_dict(cfg, seed=3)
+    m = WMEncodecModel(cfg, sd, "cuda")
+    for n in (cfg.hop * 3, cfg.hop * 3 + 1, cfg.hop * 5 - 1):
+        codes, _, emb = m.encode(torch.randn(1, 1, n).cuda())
+        frames = -(-n // cfg.hop)
+        assert tuple(emb.shape) == (1, cfg.dimension, frames) and tuple(codes.shape) == (1, cfg.n_q, frames)
+        assert tuple(m.decode(codes).shape) == (1, 1, frames * cfg.hop)
+    with pytest.raises(IndexError):
+        m.decode(torch.full((1, cfg.n_q, 3), cfg.bins, dtype=torch.long).cuda())     # stray special token
+    with pytest.raises(AssertionError):
+        m.encode(torch.randn(1, 100).cuda())
+
+
+def test_lstm_large_batch_path_matches_small_batch_path():
+    """B > 4 switches the recurrence to GEMM + gate kernel; same clips must give the same result either way."""
+    cfg = W.codec_config_tiny()
+    sd = W.codec_state_dict(cfg, seed=4)
+    m = WMEncodecModel(cfg, sd, "cuda")
+    g = torch.Generator().manual_seed(0)
+    wav = (torch.randn(6, 1, cfg.hop * 7, generator=g) * 0.3).cuda()
+    c6, _, e6 = m.encode(wav)
+    c2, _, e2 = m.encode(wav[:2])
+    torch.testing.assert_close(e6[:2], e2, rtol=0, atol=2e-5)
+    d6 = m.decode(c6)
+    d2 = m.decode(c6[:2])
+    torch.testing.assert_close(d6[:2], d2, rtol=0, atol=2e-5)
