@@ -1,0 +1,227 @@
+"""`AudioTokenizer`, `tokenize_audio`, `TextTokenizer`, `tokenize_text` — the reference's `data/tokenizer.py:31-159`
+surface on top of the HIP codec. Audio I/O is a minimal RIFF/WAVE reader (torchaudio is not a dependency);
+text phonemisation needs the external `phonemizer`/espeak-ng stack exactly like the reference (out of scope here:
+any callable `tokenizer([text]) -> [[phonemes]]` can be passed instead).
+"""
+from __future__ import annotations
+
+import re
+import struct
+from typing import Any, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..codec.wmencodec import WMEncodecModel
+from ..weights import CodecConfig
+
+
+# ----------------------------------------------------------------------------- checkpoint / config reading
+def _cfg_get(cfg, dotted: str, default=None):
+    """Duck-typed read of an OmegaConf DictConfig / dict / namespace (omegaconf is not required)."""
+    cur = cfg
+    for part in dotted.split("."):
+        if cur is None:
+            return default
+        if isinstance(cur, dict):
+            cur = cur.get(part, None)
+        else:
+            try:
+                cur = getattr(cur, part)
+            except Exception:
+                try:
+                    cur = cur[part]
+                except Exception:
+                    return default
+    return default if cur is None else cur
+
+
+def codec_config_from_xp_cfg(cfg) -> CodecConfig:
+    """Fields the reference's builder reads (`audiocraft/models/builders.py:100-115`, `solvers/wmcompression.py:281-315`)."""
+    cm = _cfg_get(cfg, "compression_model", "wmencodec")
+    if cm != "wmencodec":
+        raise KeyError(f"Unexpected compression model {cm}")          # builders.py:114
+    ratios = _cfg_get(cfg, "seanet.ratios", [8, 5, 4, 2])
+    return CodecConfig(
+        channels=int(_cfg_get(cfg, "channels", 1)), dimension=int(_cfg_get(cfg, "seanet.dimension", 128)),
+        n_filters=int(_cfg_get(cfg, "seanet.n_filters", 64)), n_residual_layers=int(_cfg_get(cfg, "seanet.n_residual_layers", 1)),
+        ratios=tuple(int(r) for r in ratios), kernel_size=int(_cfg_get(cfg, "seanet.kernel_size", 7)),
+        residual_kernel_size=int(_cfg_get(cfg, "seanet.residual_kernel_size", 3)), last_kernel_size=int(_cfg_get(cfg, "seanet.last_kernel_size", 7)),
+        compress=int(_cfg_get(cfg, "seanet.compress", 2)), lstm=int(_cfg_get(cfg, "seanet.lstm", 2)),
+        pad_mode=str(_cfg_get(cfg, "seanet.pad_mode", "constant")), n_q=int(_cfg_get(cfg, "rvq.n_q", 4)), bins=int(_cfg_get(cfg, "rvq.bins", 2048)),
+        sample_rate=int(_cfg_get(cfg, "sample_rate", 16000)))
+
+
+def load_codec_checkpoint(path: str) -> Tuple[CodecConfig, dict]:
+    """Accepts the reference's layout {'xp.cfg': DictConfig, 'best_state': {'model': state_dict}} (unpickling it needs
+    `omegaconf` installed, as in the reference) and this repo's plain layout {'codec_config': dict, 'model': state_dict}."""
+    state = torch.load(path, "cpu", weights_only=False)
+    assert state is not None and "exported" not in state, "When loading an exported checkpoint, use the //pretrained/ prefix."  # wmcompression.py:303-304
+    if "xp.cfg" in state:
+        return codec_config_from_xp_cfg(state["xp.cfg"]), state["best_state"]["model"]
+    return CodecConfig(**state["codec_config"]), state["model"]
+
+
+# ----------------------------------------------------------------------------- audio I/O
+def read_wav(path: str, frame_offset: int = 0, num_frames: int = -1) -> Tuple[torch.Tensor, int]:
+    """Minimal RIFF/WAVE reader -> (float32 [channels, n] in [-1,1], sample_rate), like torchaudio.load(normalize=True).
+    PCM 8/16/32-bit and IEEE float32."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, raw = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", body[:16])
+            if tag == 0xFFFE and len(body) >= 26:
+                tag = struct.unpack("<H", body[24:26])[0]
+            fmt = (tag, ch, sr, bits)
+        elif cid == b"data":
+            raw = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or raw is None:
+        raise ValueError(f"{path}: missing fmt/data chunk")
+    tag, ch, sr, bits = fmt
+    if tag == 3 and bits == 32:
+        x = np.frombuffer(raw, dtype="<f4").astype(np.float32)
+    elif tag == 1 and bits == 16:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif tag == 1 and bits == 32:
+        x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif tag == 1 and bits == 8:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise ValueError(f"{path}: unsupported WAVE format tag={tag} bits={bits}")
+    x = x[: (len(x) // ch) * ch].reshape(-1, ch).T
+    if frame_offset > 0:
+        x = x[:, frame_offset:]
+    if num_frames is not None and num_frames >= 0:
+        x = x[:, :num_frames]
+    return torch.from_numpy(np.ascontiguousarray(x)), sr
+
+
+def write_wav(path: str, wav: torch.Tensor, sample_rate: int) -> None:
+    """float32 [channels, n] -> 16-bit PCM WAVE (what torchaudio.save writes by default for float input is float32;
+    16-bit keeps files small and portable)."""
+    x = wav.detach().cpu().to(torch.float32).clamp(-1, 1).numpy()
+    pcm = (x.T * 32767.0).round().astype("<i2").tobytes()
+    ch = x.shape[0]
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, ch, sample_rate, sample_rate * ch * 2, ch * 2, 16)
+    with open(path, "wb") as f:
+        f.write(hdr + b"data" + struct.pack("<I", len(pcm)) + pcm)
+
+
+def convert_audio(wav: torch.Tensor, sr: int, target_sr: int, target_channels: int) -> torch.Tensor:
+    """data/tokenizer.py:82-97."""
+    assert wav.shape[0] in [1, 2], "Audio must be mono or stereo."
+    if target_channels == 1:
+        wav = wav.mean(0, keepdim=True)
+    elif target_channels == 2:
+        *shape, _, length = wav.shape
+        wav = wav.expand(*shape, target_channels, length)
+    elif wav.shape[0] == 1:
+        wav = wav.expand(target_channels, -1)
+    if sr != target_sr:
+        try:
+            import torchaudio
+        except ImportError as e:
+            raise RuntimeError(f"resampling {sr} -> {target_sr} Hz needs torchaudio (reference data/tokenizer.py:96); "
+                               f"provide {target_sr} Hz audio") from e
+        wav = torchaudio.transforms.Resample(sr, target_sr)(wav)
+    return wav
+
+
+# ----------------------------------------------------------------------------- tokenizers
+class AudioTokenizer:
+    """EnCodec audio (data/tokenizer.py:99-138)."""
+
+    def __init__(self, device: Any = None, signature=None, *, config: Optional[CodecConfig] = None, state_dict: Optional[dict] = None) -> None:
+        if signature is not None:
+            config, state_dict = load_codec_checkpoint(signature)
+        if config is None or state_dict is None:
+            raise ValueError("AudioTokenizer needs `signature=<checkpoint path>` or (`config`, `state_dict`)")
+        if not device:
+            device = torch.device("cpu")
+            if torch.cuda.is_available():
+                device = torch.device("cuda:0")
+        self._device = torch.device(device)
+        self.codec = WMEncodecModel(config, state_dict, self._device)
+        self.sample_rate = self.codec.sample_rate
+        self.channels = self.codec.channels
+
+    @property
+    def device(self):
+        return self._device
+
+    def encode(self, wav: torch.Tensor):
+        return self.codec.encode(wav.to(self.device))
+
+    def decode(self, frames: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+        return self.codec.decode(frames, scale)
+
+    def wmdecode(self, frames: torch.Tensor, marks: torch.Tensor, wav: torch.Tensor, scale: torch.Tensor):
+        # the reference discards the detector output here (tokenizer.py:133): skip computing it
+        out, _ = self.codec.wmdecode(frames.to(self.device), marks.to(self.device), wav.to(self.device), scale, with_mark=False)
+        return out
+
+    def detect_watermark(self, wav: torch.Tensor):
+        return self.codec.detect_watermark(wav.to(self.device))
+
+
+def tokenize_audio(tokenizer: AudioTokenizer, audio_path: str, offset=-1, num_frames=-1, multiple=320):
+    """data/tokenizer.py:141-159: load, zero-pad to a multiple of `multiple`, convert, encode."""
+    if offset != -1 and num_frames != -1:
+        wav, sr = read_wav(audio_path, frame_offset=offset, num_frames=num_frames)
+    else:
+        wav, sr = read_wav(audio_path)
+    current_length = wav.shape[-1]
+    padding_length = (multiple - (current_length % multiple)) % multiple
+    if padding_length > 0:
+        wav = F.pad(wav, (0, padding_length), "constant", 0)
+    wav = convert_audio(wav, sr, tokenizer.sample_rate, tokenizer.channels)
+    wav = wav.unsqueeze(0)
+    with torch.no_grad():
+        encoded_frames, scale, emb = tokenizer.encode(wav)
+    return encoded_frames, scale, emb
+
+
+class TextTokenizer:
+    """Phonemize Text (data/tokenizer.py:31-80): thin wrapper over `phonemizer`'s espeak backend, which must be installed
+    (it is an external binary stack; not part of this package's scope)."""
+
+    def __init__(self, language="en-us", backend="espeak", separator=None, preserve_punctuation=True, punctuation_marks=None,
+                 with_stress=False, tie=False, language_switch="keep-flags", words_mismatch="ignore") -> None:
+        try:
+            from phonemizer.backend import EspeakBackend
+            from phonemizer.separator import Separator
+            from phonemizer.punctuation import Punctuation
+        except ImportError as e:
+            raise RuntimeError("TextTokenizer needs the `phonemizer` package and espeak-ng (reference data/tokenizer.py:8-10)") from e
+        self.separator = separator or Separator(word="_", syllable="-", phone="|")
+        self.backend = EspeakBackend(language, punctuation_marks=punctuation_marks or Punctuation.default_marks(),
+                                     preserve_punctuation=preserve_punctuation, with_stress=with_stress, tie=tie,
+                                     language_switch=language_switch, words_mismatch=words_mismatch)
+
+    def to_list(self, phonemized: str) -> List[str]:
+        fields = []
+        for word in phonemized.split(self.separator.word):
+            pp = re.findall(r"\w+|[^\w\s]", word, re.UNICODE)             # phones and punctuation marks (tokenizer.py:66)
+            fields.extend([p for p in pp if p != self.separator.phone] + [self.separator.word])
+        assert len("".join(fields[:-1])) == len(phonemized) - phonemized.count(self.separator.phone)
+        return fields[:-1]
+
+    def __call__(self, text, strip=True) -> List[List[str]]:
+        if isinstance(text, str):
+            text = [text]
+        phonemized = self.backend.phonemize(text, separator=self.separator, strip=strip, njobs=1)
+        return [self.to_list(p) for p in phonemized]
+
+
+def tokenize_text(tokenizer, text: str) -> List[str]:
+    """data/tokenizer.py:93-96."""
+    phonemes = tokenizer([text.strip()])
+    return phonemes[0]

@@ -1,0 +1,155 @@
+"""CLI with the reference's `inference_v2.py` argument surface (flags, types, defaults, choices: `inference_v2.py:158-188`)
+driving the HIP path. The reference derives the edit span with WhisperX ASR + forced alignment and espeak
+phonemisation (`inference_v2.py:216-327`), third-party models that are outside this package's scope; here the span is
+given explicitly (extra flags `--mask_start/--mask_end` in seconds, or `--prompt_end` for --tts) and the text goes
+through whatever phonemiser `TextTokenizer` finds (or `--phoneme_ids` directly).
+
+Outputs follow the reference: `{output_dir}/{savename}_new_seed{seed+num}.wav` (+ `_orig.wav`), one per `--sample_batch_size`.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+# (flag, argparse kwargs) — the reference's surface, in its order
+REFERENCE_FLAGS = [
+    ("--sub_amount", dict(type=float, default=0.12)),
+    ("--codec_audio_sr", dict(type=int, default=16000)),
+    ("--codec_sr", dict(type=int, default=50)),
+    ("--top_k", dict(type=int, default=0)),
+    ("--top_p", dict(type=float, default=0.8)),
+    ("--temperature", dict(type=int, default=1)),
+    ("--kvcache", dict(type=int, default=1)),
+    ("--seed", dict(type=int, default=1)),
+    ("--stop_repetition", dict(type=int, default=2)),
+    ("--sample_batch_size", dict(type=int, default=1)),
+    ("--cfg_coef", dict(type=float, default=1.5)),
+    ("--cfg_stride", dict(type=int, default=1)),
+    ("--aug_text", dict(action="store_true")),
+    ("--aug_context", dict(action="store_true")),
+    ("--use_watermark", dict(action="store_true")),
+    ("--tts", dict(action="store_true")),
+    ("--prompt_length", dict(type=int, default=3)),
+    ("--language", dict(type=str, choices=["en", "zh"])),
+    ("--model_path", dict(type=str, default=None)),
+    ("--codec_path", dict(type=str, default=None)),
+    ("--orig_audio", dict(type=str, default=None)),
+    ("--orig_transcript", dict(type=str, default=None)),
+    ("--target_transcript", dict(type=str, default=None)),
+    ("--temp_folder", dict(type=str, default=None)),
+    ("--output_dir", dict(type=str, default=None)),
+    ("--savename", dict(type=str, default=None)),
+    ("--whisper_model_name", dict(type=str, choices=["base.en", "base"], default="base.en")),
+]
+# additions of this package (span given explicitly instead of by ASR/alignment)
+EXTRA_FLAGS = [
+    ("--mask_start", dict(type=float, default=None, help="edit span start in seconds (speech editing)")),
+    ("--mask_end", dict(type=float, default=None, help="edit span end in seconds (speech editing)")),
+    ("--prompt_end", dict(type=float, default=None, help="--tts: cut the prompt audio at this time in seconds (default --prompt_length)")),
+    ("--phoneme_ids", dict(type=str, default=None, help="comma separated phoneme ids of the target transcript (skips espeak)")),
+    ("--prompt_phoneme_ids", dict(type=str, default=None, help="comma separated phoneme ids of the prompt transcript")),
+]
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="inference speech editing")
+    for flag, kw in REFERENCE_FLAGS + EXTRA_FLAGS:
+        p.add_argument(flag, **kw)
+    return p
+
+
+def parse_args(argv=None):
+    return build_parser().parse_args(argv)
+
+
+def seed_everything(seed: int):
+    """inference_v2.py:33-40."""
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+
+
+class _IdTokenizer:
+    """Stands in for the phonemiser when ids are given on the command line: yields the ids as 'phonemes'."""
+
+    def __init__(self, table):
+        self.table = table
+
+    def __call__(self, texts):
+        return [self.table[t.strip()] for t in texts]
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    seed_everything(args.seed)
+    from .data.tokenizer import AudioTokenizer, TextTokenizer, read_wav, write_wav
+    from .inference_scale import inference_one_sample
+    from .models.ssr import SSR_Speech
+
+    device = "cuda" if torch.cuda.is_available() else "cpu"
+    ckpt = torch.load(args.model_path, map_location="cpu", weights_only=False)      # inference_v2.py:197-204
+    model = SSR_Speech(ckpt["config"])
+    model.load_state_dict(ckpt["model"])
+    config = vars(model.args)
+    phn2num = ckpt["phn2num"]
+    model.to(device)
+    model.eval()
+    audio_tokenizer = AudioTokenizer(device=device, signature=args.codec_path)        # :205
+
+    start_time = time.time()
+    os.makedirs(args.output_dir, exist_ok=True)
+    wav, sr = read_wav(args.orig_audio)
+    if sr != args.codec_audio_sr:
+        raise RuntimeError(f"--orig_audio must be {args.codec_audio_sr} Hz (resampling is done by librosa in the reference, :216-219)")
+    audio_dur = wav.shape[-1] / sr
+    if args.tts:
+        cut = args.prompt_end if args.prompt_end is not None else float(args.prompt_length)
+        cut = min(cut, audio_dur)
+        n = int(cut * sr)
+        audio_fn = os.path.join(args.temp_folder or args.output_dir, f"{args.savename}_prompt.wav")
+        os.makedirs(os.path.dirname(audio_fn), exist_ok=True)
+        write_wav(audio_fn, wav[:, :n], sr)
+        frames = round(n / sr * args.codec_sr)
+        mask_interval = torch.LongTensor([[frames, frames]])                         # :320-326: empty span at the prompt's end
+        prompt_text = args.orig_transcript or ""
+        target_text = (prompt_text + " " + args.target_transcript).strip()           # :273
+    else:
+        if args.mask_start is None or args.mask_end is None:
+            raise SystemExit("speech editing without WhisperX needs --mask_start and --mask_end (seconds)")
+        audio_fn = args.orig_audio
+        s = max(args.mask_start - args.sub_amount, 0.0)                              # :307-312 (margins around the edited words)
+        e = min(args.mask_end + args.sub_amount, audio_dur)
+        mask_interval = torch.LongTensor([[round(s * args.codec_sr), round(e * args.codec_sr)]])
+        prompt_text = args.orig_transcript or ""
+        target_text = args.target_transcript
+
+    if args.phoneme_ids is not None:
+        inv = {v: k for k, v in phn2num.items()}
+        table = {target_text.strip(): [inv[int(i)] for i in args.phoneme_ids.split(",") if i.strip()]}
+        table[prompt_text.strip()] = [inv[int(i)] for i in (args.prompt_phoneme_ids or "").split(",") if i.strip()]
+        text_tokenizer = _IdTokenizer(table)
+    else:
+        text_tokenizer = TextTokenizer(backend="espeak", language="en-us" if args.language != "zh" else "cmn")
+    decode_config = {"top_k": args.top_k, "top_p": args.top_p, "temperature": args.temperature, "stop_repetition": args.stop_repetition,
+                     "kvcache": args.kvcache, "codec_audio_sr": args.codec_audio_sr, "codec_sr": args.codec_sr}
+    write_wav(os.path.join(args.output_dir, f"{args.savename}_orig.wav"), wav, sr)
+    for num in range(args.sample_batch_size):                                        # :331-358
+        seed_everything(args.seed + num)
+        new_audio = inference_one_sample(model, argparse.Namespace(**config), phn2num, text_tokenizer, audio_tokenizer, audio_fn,
+                                         prompt_text, target_text, mask_interval, args.cfg_coef, args.cfg_stride, args.aug_text,
+                                         args.aug_context, args.use_watermark, args.tts, device, decode_config)
+        out = os.path.join(args.output_dir, f"{args.savename}_new_seed{args.seed + num}.wav")
+        write_wav(out, new_audio[0].cpu(), args.codec_audio_sr)
+    print(f"Running time: {time.time() - start_time:.4f} s")                         # :360-363
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""GPU: the whole per-utterance path `inference_one_sample` (wav -> codes -> AR decode -> wav, incl. the watermark branch)
+on tiny LM + tiny codec, against the oracle run on the CPU with the same weights. LM tokens must be identical when the
+prompt codes agree; the output waveform within 5e-4 of the oracle's decode of the same tokens."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ssr_speech_amd  # noqa: F401
+from ssr_speech_amd import weights as W
+from ssr_speech_amd.data.tokenizer import AudioTokenizer, write_wav
+from ssr_speech_amd.inference_scale import inference_one_sample
+from ssr_speech_amd.models.ssr import SSR_Speech
+from oracle import codec as OC, lm as O
+
+pytestmark = pytest.mark.gpu
+
+
+class FakePhonemizer:
+    def __call__(self, texts):
+        return [[c for c in t if c != " "] for t in texts]
+
+
+@pytest.mark.parametrize("tts,use_watermark", [(True, False), (False, True), (True, True)])
+def test_inference_one_sample_matches_oracle(tmp_path, tts, use_watermark):
+    # small channels but the real hop (320): the reference's glue hard-codes 320-sample frames (inference_scale.py:66-86)
+    ccfg = W.CodecConfig(dimension=64, n_filters=8, ratios=(8, 5, 4, 2), bins=64)
+    csd = W.codec_state_dict(ccfg, seed=7)
+    args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
+    lsd = W.lm_state_dict(args, seed=8)
+    for k in range(4):   # a random-weight LM would emit special ids (>= vocab) that RVQ decode rejects, as in the reference: bias them away
+        lsd[f"predict_layer.{k}.2.bias"][64:] = -30.0
+    m = SSR_Speech(args)
+    m.load_state_dict(lsd)
+    m = m.to("cuda").eval()
+    tok = AudioTokenizer(device="cuda", config=ccfg, state_dict=csd)
+    g = torch.Generator().manual_seed(1)
+    n_frames = 20
+    wav = torch.randn(1, n_frames * 320 - 7, generator=g) * 0.2          # not a multiple of 320: exercises the padding rule
+    fn = str(tmp_path / "prompt.wav")
+    write_wav(fn, wav, 16000)
+    phn2num = {c: i for i, c in enumerate("abcdefghijklmnopqrstuvwxyz")}
+    prompt_text, target_text = "hello world", "hello world again"
+    mi = torch.LongTensor([[n_frames, n_frames]]) if tts else torch.LongTensor([[6, 11]])
+    decode_config = {"top_k": 1, "top_p": 1.0, "temperature": 1, "stop_repetition": 2, "kvcache": 1, "codec_audio_sr": 16000, "codec_sr": 50}
+    torch.manual_seed(5)
+    out = inference_one_sample(m, argparse.Namespace(**vars(args)), phn2num, FakePhonemizer(), tok, fn, prompt_text, target_text, mi,
+                               1.5, 2, True, False, use_watermark, tts, "cuda", decode_config)
+    # oracle: same steps on the CPU
+    import torch.nn.functional as F
+    from ssr_speech_amd.data.tokenizer import read_wav
+    from ssr_speech_amd.inference_scale import assemble_watermark_wav
+    w16, _ = read_wav(fn)
+    w16 = F.pad(w16, (0, (320 - w16.shape[-1] % 320) % 320))
+    codes, _, _ = OC.encode(csd, w16.unsqueeze(0), ccfg)
+    got_codes, _, _ = tok.encode(w16.unsqueeze(0))
+    assert (got_codes.cpu() != codes).float().mean() < 0.02            # the HIP codec's codes agree with the oracle's (fp ties aside)
+    x = torch.LongTensor([[phn2num[c] for c in target_text if c != " "]])
+    torch.manual_seed(5)
+    res, marks, masks, ori = O.inference(O.reference_params(lsd), args, x, got_codes.cpu().transpose(2, 1), mi.unsqueeze(0), top_k=1, top_p=1.0,
+                                         temperature=1, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=2, aug_text=True)
+    if use_watermark:
+        new_wav = assemble_watermark_wav(w16, res.shape[-1], masks, ori, 320)
+        ref_wav, _ = OC.wmdecode(csd, res, marks, new_wav.unsqueeze(0), ccfg)
+    else:
+        ref_wav = OC.decode(csd, res, ccfg)
+    if tts:
+        ref_wav = ref_wav[:, :, masks[0][1] * 320:]
+    assert out.shape == ref_wav.shape
+    np.testing.assert_allclose(out.cpu().numpy(), ref_wav.numpy(), rtol=0, atol=5e-4)

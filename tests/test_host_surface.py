@@ -1,0 +1,71 @@
+"""CPU: host-side surfaces that mirror the reference: CLI flags (golden parsed from the reference's inference_v2.py), WAV
+reader/writer, watermark wav assembly (inference_scale.py:67-78), checkpoint-config reading."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ssr_speech_amd  # noqa: F401
+from ssr_speech_amd import inference_v2 as CLI
+from ssr_speech_amd.data import tokenizer as TK
+from ssr_speech_amd.inference_scale import assemble_watermark_wav
+
+
+def test_cli_flag_surface_matches_reference(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "cli_flags.json")))
+    mine = {f: kw for f, kw in CLI.REFERENCE_FLAGS}
+    assert [r["flag"] for r in ref] == [f for f, _ in CLI.REFERENCE_FLAGS]
+    for r in ref:
+        kw = mine[r["flag"]]
+        assert (kw.get("action") == "store_true") == r["store_true"], r
+        if not r["store_true"]:
+            assert kw["type"].__name__ == r["type"], r
+            if "default" in r:
+                assert str(kw.get("default")) == r["default"], (r, kw)
+        if r["choices"]:
+            assert kw["choices"] == r["choices"]
+    a = CLI.parse_args(["--tts", "--top_k", "1", "--language", "en"])
+    assert a.tts and a.top_k == 1 and a.top_p == 0.8 and a.temperature == 1 and a.cfg_stride == 1 and a.stop_repetition == 2
+    with pytest.raises(SystemExit):
+        CLI.parse_args(["--language", "fr"])
+
+
+def test_wav_roundtrip_and_demo_like_formats(tmp_path):
+    x = torch.sin(torch.arange(4000) / 20.0).unsqueeze(0) * 0.5
+    p = str(tmp_path / "a.wav")
+    TK.write_wav(p, x, 16000)
+    y, sr = TK.read_wav(p)
+    assert sr == 16000 and y.shape == x.shape and float((y - x).abs().max()) < 1.0 / 32767 + 1e-6
+    y2, _ = TK.read_wav(p, frame_offset=100, num_frames=50)
+    assert torch.equal(y2, y[:, 100:150])
+    # float32 WAVE (format tag 3), as two of the reference's demo prompts are stored
+    import struct
+    raw = x.numpy().astype("<f4").tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 3, 1, 16000, 64000, 4, 32)
+    q = str(tmp_path / "f.wav")
+    open(q, "wb").write(hdr + b"data" + struct.pack("<I", len(raw)) + raw)
+    z, sr = TK.read_wav(q)
+    assert sr == 16000 and torch.equal(z, x)
+    assert TK.convert_audio(torch.cat([x, -x]), 16000, 16000, 1).abs().max() == 0
+
+
+def test_watermark_wav_assembly():
+    """Edit of frames [3,5) of a 8-frame clip replaced by 4 generated frames: kept audio moves, generated region is zero."""
+    hop = 4
+    wav = torch.arange(8 * hop, dtype=torch.float32).unsqueeze(0)
+    masks = [(0, 3), (7, 10)]          # kept intervals, new coordinates
+    ori = [(0, 3), (5, 8)]             # kept intervals, original coordinates
+    out = assemble_watermark_wav(wav, 10, masks, ori, hop)
+    assert out.shape == (1, 40)
+    assert torch.equal(out[0, :12], wav[0, :12]) and torch.equal(out[0, 28:40], wav[0, 20:32]) and out[0, 12:28].abs().sum() == 0
+
+
+def test_codec_config_from_duck_typed_cfg():
+    cfg = {"compression_model": "wmencodec", "sample_rate": 16000, "channels": 1,
+           "seanet": {"n_filters": 64, "dimension": 128, "ratios": [8, 5, 4, 2], "lstm": 2, "pad_mode": "reflect"}, "rvq": {"n_q": 4, "bins": 2048}}
+    c = TK.codec_config_from_xp_cfg(cfg)
+    assert c.ratios == (8, 5, 4, 2) and c.pad_mode == "reflect" and c.hop == 320 and c.frame_rate == 50
+    with pytest.raises(KeyError):
+        TK.codec_config_from_xp_cfg({"compression_model": "encodec"})
