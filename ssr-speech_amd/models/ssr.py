@@ -212,3 +212,78 @@ class SSR_Speech(nn.Module):
         marks_t = torch.from_numpy(marks).unsqueeze(0)          # CPU tensor, as the reference (ssr.py:805)
         logging.info(f"ssr_speech_amd: generated {st.n_steps} steps")
         return res_t, marks_t, masks, nmi_out
+
+    # ------------------------------------------------------------------ batched decode (new capability)
+    @torch.no_grad()
+    def inference_batch(self, utterances, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0, stop_repetition: int = -1,
+                        silence_tokens=(1388, 1898, 131), cfg_coef: float = 1.5, cfg_stride: int = 1, aug_text: bool = False,
+                        seed: int = 0, first_index: int = 0, group: Optional[int] = None, use_graph: bool = True):
+        """Several independent utterances decoded in lock-step so that one pass over the weights serves all of them
+        (the reference is strictly batch-1: `assert y.shape[0] == 1`, ssr.py:559, and loops `--sample_batch_size`
+        sequentially, inference_v2.py:331-333).
+
+        utterances: list of dicts {x: LongTensor[1,L], y: LongTensor[1,T,K], mask_interval: LongTensor[1,M,2]}.
+        Parity contract: result i == `inference()` of utterance i alone after `torch.manual_seed(seed + first_index + i)`
+        (per-utterance RNG streams, independent of grouping and of the DP world size).
+        Returns a list of the same 4-tuples `inference` returns."""
+        K = self.args.n_codebooks
+        assert cfg_coef >= 1.0, cfg_coef
+        rows = 2 if aug_text else 1
+        if group is None:
+            group = 4 // rows                      # rows per engine are limited to 4 in this build
+        assert group * rows in (1, 2, 4), (group, rows)
+        dev = self.device
+        results = [None] * len(utterances)
+        greedy = top_k == 1
+        for g0 in range(0, len(utterances), group):
+            chunk = utterances[g0: g0 + group]
+            n_u = len(chunk)
+            while n_u * rows not in (1, 2, 4):     # e.g. 3 utterances x 1 row: pad the group with a copy of the last one
+                chunk = chunk + [chunk[-1]]
+                n_u += 1
+            text_rows, audio_cols, knobs, metas, noises = [], [], [], [], []
+            cap_max, seq_max = 1, 1
+            for j, u in enumerate(chunk):
+                gi = first_index + g0 + min(j, len(utterances) - g0 - 1)
+                torch.manual_seed(seed + gi)       # same stream as a batch-1 run of this utterance
+                x_np = u["x"].detach().cpu().numpy().astype(np.int64)
+                L = x_np.shape[1]
+                text_rows.append(x_np[0])
+                if aug_text:
+                    text_rows.append(torch.randint(0, self.n_text_tokens, (1, L)).numpy().astype(np.int64)[0])     # ssr.py:574
+                y_np = u["y"][0].transpose(1, 0).detach().cpu().numpy().astype(np.int64)
+                mi = u["mask_interval"][0].detach().cpu().numpy().astype(np.int64)
+                cated, mask_position, num_task, nmi = LY.build_layout(y_np, mi, self.args)
+                T0 = cated.shape[1]
+                cap = max(10 * L + 2 - T0, 1) + num_task * (K + 1)
+                cap_max, seq_max = max(cap_max, cap), max(seq_max, L + T0 + cap + 8)
+                audio_cols.append(cated)
+                knobs.append(DecodeKnobs(top_k=top_k, top_p=top_p, temperature=temperature, stop_repetition=stop_repetition,
+                                         silence_tokens=tuple(int(s) for s in silence_tokens), cfg_coef=cfg_coef, cfg_stride=cfg_stride,
+                                         use_cfg=bool(aug_text), text_len=L, n_spans=num_task, seed=seed + gi))
+                metas.append((y_np, nmi, num_task, cap))
+                if not greedy:
+                    nz = torch.empty(cap, K, self.n_audio_tokens[0], dtype=torch.float32)
+                    for s_ in range(cap):
+                        nz[s_].exponential_(1)     # the Exp(1) tensors torch.multinomial would draw, in order
+                    noises.append(nz)
+            eng = self._get_engine(n_u, bool(aug_text), seq_max, cap_max)
+            noise_dev = None
+            if not greedy:
+                nzall = torch.ones(n_u, eng.max_steps, K, eng.a.card, dtype=torch.float32)
+                for j, nz in enumerate(noises):
+                    nzall[j, : nz.shape[0]] = nz
+                noise_dev = nzall.to(dev)
+            eng.start(text_rows, audio_cols, knobs, noise=noise_dev)
+            states = eng.run_to_completion(chunk=16, use_graph=use_graph, max_total=cap_max)
+            for j in range(min(n_u, len(utterances) - g0)):
+                st = states[j]
+                if st.done != 1:
+                    raise RuntimeError(f"utterance {g0 + j} did not finish within {cap_max} steps (done={st.done})")
+                y_np, nmi, num_task, _ = metas[j]
+                gen = eng.generated[j, : st.n_steps].cpu().numpy().astype(np.int64)
+                ends = [0] + [st.span_end[i] for i in range(num_task)]
+                spans = [gen[ends[i]:ends[i + 1]] for i in range(num_task)]
+                res, marks, masks, nmi_out = LY.assemble(y_np, spans, nmi, self.args)
+                results[g0 + j] = (torch.from_numpy(res).unsqueeze(0).to(dev), torch.from_numpy(marks).unsqueeze(0), masks, nmi_out)
+        return results

@@ -156,3 +156,26 @@ def test_full_830m_greedy_steps_match_oracle_on_cpu():
     err = np.abs(last - ref_log[steps - 1]).max()
     print(f"830M: max |logit diff| at step {steps}: {err:.2e} (logit std {ref_log[steps-1][np.abs(ref_log[steps-1])<1e3].std():.2f})")
     assert err < 5e-4
+
+
+@pytest.mark.parametrize("aug_text,greedy", [(True, True), (False, True), (True, False), (False, False)])
+def test_inference_batch_rows_equal_batch1_runs(aug_text, greedy):
+    """New capability (the reference is batch-1 only): utterances of DIFFERENT text / prompt lengths decoded in lock-step.
+    Row i must equal a batch-1 `inference()` of utterance i seeded with seed+i."""
+    args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
+    m = _model(args, 21)
+    g = torch.Generator().manual_seed(3)
+    utts = []
+    for (L, T) in [(9, 14), (13, 22), (6, 10)] if not aug_text else [(9, 14), (13, 22), (6, 10)]:
+        utts.append(dict(x=torch.randint(0, 30, (1, L), generator=g), y=torch.randint(0, 64, (1, T, 4), generator=g),
+                         mask_interval=torch.LongTensor([[[T, T]]])))
+    utts[1]["mask_interval"] = torch.LongTensor([[[5, 9]]])            # one of them is an edit, the others TTS
+    kw = dict(top_k=1, top_p=1.0) if greedy else dict(top_k=12, top_p=0.9)
+    kw.update(temperature=1.0, stop_repetition=2, silence_tokens=[3, 7, 11], cfg_coef=1.5, cfg_stride=2, aug_text=aug_text)
+    batch = m.inference_batch(utts, seed=100, **kw)
+    for i, u in enumerate(utts):
+        torch.manual_seed(100 + i)
+        L = u["x"].shape[1]
+        one = m.inference(u["x"].cuda(), torch.LongTensor([L]), u["x"].cuda(), torch.LongTensor([L]), u["y"].cuda(), u["y"].cuda(),
+                          u["mask_interval"].cuda(), kvcache=1, **kw)
+        assert torch.equal(batch[i][0], one[0]) and torch.equal(batch[i][1], one[1]) and batch[i][2] == one[2] and batch[i][3] == one[3], i
