@@ -27,6 +27,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+TRAFFIC_BYTES_PER_GEMV_LAUNCH = 50.6e6   # measured with PMC counters, see profiles/r01_pmc_fetch_size.md (not re-measured live)
 
 
 def synth_inputs(args_lm, rank, L=130, N=160):
@@ -183,13 +184,38 @@ def main():
             "per_gpu_value": round(value / world, 1),
             "decode_rtf_10s": round((500 * ms_per_step / 1000) / 10.0, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r01_pmc_*.md), gfx950 x2 correction
+                         # for wide reads applied: 50.5 MB read + 0.1 MB written per GEMV launch vs 49.85 MB algorithmic
+                         "traffic": TRAFFIC_BYTES_PER_GEMV_LAUNCH if (arena.D == 2048 and arena.L == 16) else None,
                          "kernel": "gemv_kernel<2> (fused LN/combine + GEMV + bias/act/residual)",
                          "bytes_per_launch": int(bytes_per_launch), "launches_per_step": n_gemv, "us_per_launch": round(gemv_us, 3),
                          "step_level": {"bytes_per_step": int(arena.nbytes_per_step() + kv_bytes), "achieved": round(step_gbs, 1),
                                         "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
                          "event_timed_us_per_launch": per_shape},
         }
+        # ---- RTF of a whole 10 s zero-shot TTS on this GPU: prefill + 500 decode steps + wmencodec decode of the 500 new frames
+        try:
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            eng.start([x[0].numpy(), unc[0].numpy()], [cated], [kn], noise=None)
+            torch.cuda.synchronize()
+            prefill_ms = 1000 * (time.perf_counter() - p0)
+            from ssr_speech_amd.codec.wmencodec import WMEncodecModel
+            ccfg = W.codec_config_full()
+            codec = WMEncodecModel(ccfg, W.codec_state_dict(ccfg, seed=0), dev)
+            codes = torch.randint(0, 2048, (1, 4, 500), device=dev)
+            codec.decode(codes)
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            wav = codec.decode(codes)
+            torch.cuda.synchronize()
+            codec_ms = 1000 * (time.perf_counter() - c0)
+            out["rtf_10s_tts"] = {"prefill_ms": round(prefill_ms, 2), "decode_ms": round(500 * ms_per_step, 2), "codec_decode_ms": round(codec_ms, 2),
+                                  "rtf": round((prefill_ms + 500 * ms_per_step + codec_ms) / 10000.0, 4),
+                                  "note": f"prefill of {2 * (L + T0)} rows (host layout + H2D included), 500 frames = 10 s, SEANet+LSTM decode of {tuple(wav.shape)}"}
+        except Exception as e:  # the headline metric must not depend on this extra
+            out["rtf_10s_tts"] = {"error": repr(e)}
         if allgather_ms is not None:
             out["allgather_ms"] = round(allgather_ms, 3)
         if world == 1 and not a.no_cpu_baseline:

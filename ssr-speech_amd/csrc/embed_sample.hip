@@ -67,37 +67,112 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   return x;
 }
 
-// count / mass of the wave's keys above a threshold: 4 independent per-lane chains (the kernel runs one wave
-// per SIMD, so dependent-issue latency, not throughput, is what costs), then one DPP wave reduction.
-__device__ __forceinline__ int count_gt(const uint32_t (&key)[MAXE], uint32_t cand) {
-  int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+// ---- exact selection without a sort: 4-pass radix select (8 bits per pass) on the order-preserving integer image of
+// the logits. Each wave (= one codebook) owns a 256-bin histogram in LDS, filled with LDS atomics — integer counts for
+// top-k, 2^-40 fixed-point probability mass for top-p, so the sums are exact integers: order-independent, hence
+// bit-reproducible although atomics are used. Per pass: 34 ds_add per lane + one 64-lane suffix scan.
+constexpr int NCC = 8, NCM = 4;   // histogram copies: counts (u32), mass (u64); both fit the same 8 KiB per wave
+__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+template <class T>
+__device__ __forceinline__ T suffix_excl(T v, int lane) {   // sum of v over lanes > lane
+  T inc = v;
 #pragma unroll
-  for (int e = 0; e + 3 < MAXE; e += 4) {
-    c0 += key[e] > cand; c1 += key[e + 1] > cand; c2 += key[e + 2] > cand; c3 += key[e + 3] > cand;
+  for (int o = 1; o < 64; o <<= 1) {
+    const T t = __shfl_down(inc, o, 64);
+    if (lane + o < 64) inc += t;
   }
-#pragma unroll
-  for (int e = MAXE & ~3; e < MAXE; ++e) c0 += key[e] > cand;
-  // float-typed reduction is exact here: counts <= 2176 < 2^24
-  return (int)wave_sum((float)((c0 + c1) + (c2 + c3)));
+  return inc - v;
 }
-__device__ __forceinline__ float mass_gt(const uint32_t (&key)[MAXE], const float (&p)[MAXE], uint32_t cand) {
-  float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+
+// key of the kk-th largest valid key (valid keys are != 0)
+__device__ __forceinline__ uint32_t radix_kth(const uint32_t (&key)[MAXE], int kk, unsigned* hc, int lane) {
+  uint32_t prefix = 0, mask = 0;
+  unsigned need = (unsigned)kk;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    // NCC lane-group-private copies of the histogram: logits cluster in a few float exponents, so the high digits put
+    // most lanes of a ds_add on the same bin; private copies cut that serialisation NCC-fold
 #pragma unroll
-  for (int e = 0; e + 3 < MAXE; e += 4) {
-    m0 += (key[e] > cand) ? p[e] : 0.f;
-    m1 += (key[e + 1] > cand) ? p[e + 1] : 0.f;
-    m2 += (key[e + 2] > cand) ? p[e + 2] : 0.f;
-    m3 += (key[e + 3] > cand) ? p[e + 3] : 0.f;
+    for (int j = 0; j < 4 * NCC; ++j) hc[j * 64 + lane] = 0u;
+    lds_fence();
+    unsigned* mine = hc + (lane & (NCC - 1)) * 256;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e)
+      if (key[e] != 0u && (key[e] & mask) == prefix) atomicAdd(&mine[(key[e] >> shift) & 255u], 1u);
+    lds_fence();
+    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+    for (int cpy = 0; cpy < NCC; ++cpy) {
+      const uint4 v = *reinterpret_cast<const uint4*>(hc + cpy * 256 + lane * 4);
+      c0 += v.x; c1 += v.y; c2 += v.z; c3 += v.w;
+    }
+    const unsigned a3 = suffix_excl<unsigned>(c0 + c1 + c2 + c3, lane);      // count in bins above bin 4*lane+3
+    const unsigned a2 = a3 + c3, a1 = a2 + c2, a0 = a1 + c1;
+    int found = -1;
+    unsigned above = 0;
+    if (need > a3 && need <= a3 + c3) { found = 3; above = a3; }
+    else if (need > a2 && need <= a2 + c2) { found = 2; above = a2; }
+    else if (need > a1 && need <= a1 + c1) { found = 1; above = a1; }
+    else if (need > a0 && need <= a0 + c0) { found = 0; above = a0; }
+    const unsigned long long bal = __ballot(found >= 0);
+    const int src = __builtin_amdgcn_readfirstlane(bal ? (int)__builtin_ctzll(bal) : 0);
+    const unsigned bin = (unsigned)__shfl(lane * 4 + found, src, 64);
+    need -= (unsigned)__shfl((int)above, src, 64);
+    prefix |= bin << shift;
+    mask |= 255u << shift;
+    lds_fence();
   }
+  return prefix;
+}
+
+// smallest key t* with mass(keys > t*) <= lim; 0 if even the whole mass is <= lim (keep everything)
+__device__ __forceinline__ uint32_t radix_mass(const uint32_t (&key)[MAXE], const float (&p)[MAXE], float lim, unsigned long long* hm, int lane) {
+  const float SC = 1099511627776.0f;                       // 2^40
+  const unsigned long long limfx = (unsigned long long)((double)lim * (double)SC);
+  uint32_t prefix = 0, mask = 0;
+  unsigned long long base = 0;                              // mass of keys above the current prefix bucket
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
 #pragma unroll
-  for (int e = MAXE & ~3; e < MAXE; ++e) m0 += (key[e] > cand) ? p[e] : 0.f;
-  return wave_sum((m0 + m1) + (m2 + m3));
+    for (int j = 0; j < 4 * NCM; ++j) hm[j * 64 + lane] = 0ull;
+    lds_fence();
+    unsigned long long* mine = hm + (lane & (NCM - 1)) * 256;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e)
+      if (p[e] > 0.f && (key[e] & mask) == prefix) atomicAdd(&mine[(key[e] >> shift) & 255u], (unsigned long long)(p[e] * SC));
+    lds_fence();
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+    for (int cpy = 0; cpy < NCM; ++cpy) {
+      c0 += hm[cpy * 256 + lane * 4]; c1 += hm[cpy * 256 + lane * 4 + 1]; c2 += hm[cpy * 256 + lane * 4 + 2]; c3 += hm[cpy * 256 + lane * 4 + 3];
+    }
+    const unsigned long long a3 = base + suffix_excl<unsigned long long>(c0 + c1 + c2 + c3, lane);
+    const unsigned long long a2 = a3 + c3, a1 = a2 + c2, a0 = a1 + c1;
+    // the bucket where the running mass (from the top) first exceeds lim: above <= lim < above + c
+    int found = -1;
+    unsigned long long above = 0;
+    if (a3 <= limfx && limfx < a3 + c3) { found = 3; above = a3; }
+    else if (a2 <= limfx && limfx < a2 + c2) { found = 2; above = a2; }
+    else if (a1 <= limfx && limfx < a1 + c1) { found = 1; above = a1; }
+    else if (a0 <= limfx && limfx < a0 + c0) { found = 0; above = a0; }
+    const unsigned long long bal = __ballot(found >= 0);
+    if (bal == 0ull) return 0u;                             // total mass <= lim: nothing is removed
+    const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(bal));
+    const unsigned bin = (unsigned)__shfl(lane * 4 + found, src, 64);
+    base = (unsigned long long)__shfl((long long)above, src, 64);
+    prefix |= bin << shift;
+    mask |= 255u << shift;
+    lds_fence();
+  }
+  return prefix;
 }
 
 __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a) {
   __shared__ int sh_sample[4];
   __shared__ int sh_argmax0;
   __shared__ int sh_next[SSRHIP_MAX_CODEBOOKS + 2];   // next tokens, next audio pos, live flag
+  __shared__ __attribute__((aligned(16))) unsigned long long sh_hist[4][NCM * 256];   // per-codebook radix histograms (8 KiB each; reused as u32 x NCC)
   const int u = blockIdx.x;
   const ssrhip_sampler_cfg& c = a.cfg[u];
   ssrhip_sampler_state& st = a.state[u];
@@ -206,21 +281,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
       mx = wave_max(mx);
     }
     uint32_t key[MAXE];
-    uint32_t kmin = 0xffffffffu;
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      key[e] = ((e * 64 + lane) < card && e < ne) ? okey(l[e]) : 0u;   // 0 = below every real key
-      kmin = min(kmin, key[e] ? key[e] : 0xffffffffu);
-    }
+    for (int e = 0; e < MAXE; ++e) key[e] = ((e * 64 + lane) < card && e < ne) ? okey(l[e]) : 0u;   // 0 = padding, below every real key
     const uint32_t kmax = okey(mx);
-    // smallest real key of the wave (unsigned min via the order-preserving trick on ints)
-    int kmin_i = (int)(kmin ^ 0x80000000u);
-    kmin_i = wave_min_i(kmin_i);
-    kmin = (uint32_t)kmin_i ^ 0x80000000u;
-    // bisection only needs the bits below the highest bit in which kmin and kmax differ
-    const int hibit = (kmax == kmin) ? -1 : (31 - __clz((int)(kmax ^ kmin)));
-    const uint32_t lowmask = (hibit < 0) ? 0u : ((hibit >= 31) ? 0xffffffffu : ((2u << hibit) - 1u));
-    const uint32_t prefix = kmax & ~lowmask;                                        // common high bits
     STAMP(2);
     // ---- top-k (:38-44): keep logits >= k-th largest value (ties kept)
     uint32_t thr = 0;   // keep keys >= thr
@@ -229,20 +292,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
       if (kk == 1) {
         thr = kmax;
       } else if (kk < card) {
-        uint32_t t = prefix;   // largest key with count(keys > t) > kk-1, or prefix-1 if none
-        bool any = false;
-        {  // is count(keys > prefix) > kk-1 ? (otherwise the threshold sits at/below prefix: keep all >= kmin)
-          any = count_gt(key, prefix) > kk - 1;
-        }
-        if (any) {
-          for (int bit = hibit; bit >= 0; --bit) {
-            const uint32_t cand = t | (1u << bit);
-            if (count_gt(key, cand) > kk - 1) t = cand;
-          }
-          thr = t + 1;
-        } else {
-          thr = kmin;   // count(keys > prefix) <= kk-1: only keys == prefix may be cut; prefix==kmin here
-        }
+        thr = radix_kth(key, kk, reinterpret_cast<unsigned*>(sh_hist[k]), lane);
       }
     }
     STAMP(3);
@@ -258,13 +308,9 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
     if (c_topp < 1.0f) {
       // smallest key t* with mass(keys > t*) <= top_p * Z ; keep keys >= t*
       const float lim = c_topp * Z;
-      if (mass_gt(key, p, prefix) > lim) {
-        uint32_t t = prefix;
-        for (int bit = hibit; bit >= 0; --bit) {
-          const uint32_t cand = t | (1u << bit);
-          if (mass_gt(key, p, cand) > lim) t = cand;
-        }
-        thr = max(thr, t + 1);
+      const uint32_t tp = radix_mass(key, p, lim, sh_hist[k], lane);
+      if (tp > thr) {
+        thr = tp;
 #pragma unroll
         for (int e = 0; e < MAXE; ++e) p[e] = (key[e] >= thr) ? p[e] : 0.f;
       }

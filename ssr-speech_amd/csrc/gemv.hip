@@ -17,6 +17,7 @@
 //     LDS only shares the prologue result between the 4 waves and adds the K-slices of one row;
 //   * wave reductions are DPP/permlane (no ds_bpermute).
 // Replaces F.linear (+LayerNorm / ReLU / GELU / residual) of the reference: see include/ssrhip.h.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -366,6 +367,7 @@ void launch_b(const GemvK& p, dim3 grid, size_t smem, hipStream_t s) {
 }
 
 int g_num_cu = 0;
+int g_blocks_per_cu = 2;   // measured (tools/gemv_bench.hip): 2 workgroups/CU stream 67 MB in 12.5 us, 3 in 12.6, 4 in 13.1, 8 in 14.2
 
 }  // namespace
 
@@ -379,6 +381,7 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
     int dev = 0, cu = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) g_num_cu = cu;
     else g_num_cu = 256;
+    if (const char* e = getenv("SSRHIP_GEMV_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 3) g_blocks_per_cu = v; }   // tuning knob
   }
   GemvK p;
   p.a = *a;
@@ -388,7 +391,7 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(p.nch <= MAXCH, "ssrhip_gemv: slice too long");
   const int n_rg = 4 / p.nslice;
   // resident grid: <= 3 workgroups per CU in total (over all groups); rows dealt round-robin to wave-groups
-  int max_blocks_x = (3 * g_num_cu) / a->groups;
+  int max_blocks_x = (g_blocks_per_cu * g_num_cu) / a->groups;
   if (max_blocks_x < 1) max_blocks_x = 1;
   // exactly `max_blocks_x` workgroups (every CU gets the same share) unless there are fewer rows than wave-groups
   int blocks_x = (a->N + n_rg - 1) / n_rg;
