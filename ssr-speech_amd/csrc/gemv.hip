@@ -367,7 +367,8 @@ void launch_b(const GemvK& p, dim3 grid, size_t smem, hipStream_t s) {
 }
 
 int g_num_cu = 0;
-int g_blocks_per_cu = 2;   // measured (tools/gemv_bench.hip): 2 workgroups/CU stream 67 MB in 12.5 us, 3 in 12.6, 4 in 13.1, 8 in 14.2
+int g_blocks_per_cu = 3;   // A/B in the real (dependent-launch) decode step: 1 -> 1.536, 2 -> 1.109, 3 -> 1.065 ms/step. (Independent
+                          // back-to-back launches, tools/gemv_bench.hip, prefer 2: 12.5 us vs 12.6 for 67 MB; the chain wants the faster ramp.)
 
 }  // namespace
 
