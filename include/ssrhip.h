@@ -247,6 +247,8 @@ typedef struct ssrhip_lm_weights {      /* device pointers; per-layer arrays hav
 
 typedef struct ssrhip_lm_dims {
   int32_t d_model, n_head, n_layer, d_ffn, n_codebooks, card, head_hidden, n_text, max_pos;
+  int32_t ln_folded;   /* 1: the LayerNorm affine (gamma, beta) of norm1/norm2/decoder.norm is already folded into in_proj/ffn1/head1
+                          (W' = W diag(gamma), b' = b + W beta); ln*_w / ln*_b then hold ones / zeros (used by the prefill LayerNorm) */
 } ssrhip_lm_dims;
 
 typedef struct ssrhip_lm_buffers {      /* caller-allocated device workspaces */

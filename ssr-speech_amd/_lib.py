@@ -114,7 +114,7 @@ class LMWeights(C.Structure):
 class LMDims(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_head", C.c_int32), ("n_layer", C.c_int32), ("d_ffn", C.c_int32),
                 ("n_codebooks", C.c_int32), ("card", C.c_int32), ("head_hidden", C.c_int32), ("n_text", C.c_int32),
-                ("max_pos", C.c_int32)]
+                ("max_pos", C.c_int32), ("ln_folded", C.c_int32)]
 
 
 class LMBuffers(C.Structure):

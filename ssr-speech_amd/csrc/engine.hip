@@ -97,7 +97,8 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.W = w.in_proj_w[l]; g.bias = w.in_proj_b[l]; g.x = b.x; g.y = b.q;
     g.B = B; g.N = 3 * D; g.K = D; g.groups = 1; g.x_stride = D; g.y_stride = D;
     g.pro = SSRHIP_PRO_LAYERNORM; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_QKV_APPEND;
-    g.ln_w = w.ln1_w[l]; g.ln_b = w.ln1_b[l]; g.ln_eps = 1e-5f;
+    if (!d.ln_folded) { g.ln_w = w.ln1_w[l]; g.ln_b = w.ln1_b[l]; }
+    g.ln_eps = 1e-5f;
     g.kv = b.kv; g.layer = l; g.kv_pos = b.kv_pos;
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
 
@@ -122,7 +123,8 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.W = w.ffn1_w[l]; g.bias = w.ffn1_b[l]; g.x = b.x; g.y = b.h;
     g.B = B; g.N = d.d_ffn; g.K = D; g.groups = 1; g.x_stride = D; g.y_stride = d.d_ffn;
     g.pro = SSRHIP_PRO_LAYERNORM; g.act = SSRHIP_ACT_RELU; g.epi = SSRHIP_EPI_STORE;
-    g.ln_w = w.ln2_w[l]; g.ln_b = w.ln2_b[l]; g.ln_eps = 1e-5f;
+    if (!d.ln_folded) { g.ln_w = w.ln2_w[l]; g.ln_b = w.ln2_b[l]; }
+    g.ln_eps = 1e-5f;
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
 
     // FFN2 + residual
@@ -139,7 +141,8 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.W = w.head1_w; g.bias = w.head1_b; g.x = b.x; g.y = b.h;
     g.B = B; g.N = K * Hh; g.K = D; g.groups = 1; g.x_stride = D; g.y_stride = K * Hh;
     g.pro = SSRHIP_PRO_LAYERNORM; g.act = SSRHIP_ACT_GELU_ERF; g.epi = SSRHIP_EPI_STORE;
-    g.ln_w = w.lnf_w; g.ln_b = w.lnf_b; g.ln_eps = 1e-5f;
+    if (!d.ln_folded) { g.ln_w = w.lnf_w; g.ln_b = w.lnf_b; }
+    g.ln_eps = 1e-5f;
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
     // second Linear of each head: K groups
     memset(&g, 0, sizeof(g));

@@ -68,19 +68,32 @@ class LMWeightsArena:
         self.alpha_text = float(sd["text_positional_embedding.alpha"].reshape(-1)[0])
         self.alpha_audio = float(sd["audio_positional_embedding.alpha"].reshape(-1)[0])
         self.pe = sine_pe_table(max_pos, self.D).to(**f32).contiguous()
+        # LayerNorm's affine part is folded into the Linear that follows it (one-time repack at load):
+        #   Linear(LN(x)) = W (gamma * xhat + beta) + b = (W diag(gamma)) xhat + (b + W beta),  xhat = (x - mean) * rstd
+        # so the decode GEMV only standardises x (in registers, no gamma/beta traffic); ln*_w / ln*_b become ones / zeros.
+        self.ln_folded = True
+        ones, zeros = torch.ones(self.D, **f32), torch.zeros(self.D, **f32)
+
+        def fold(wk, bk, gk, bek):
+            Wm, bm, gam, bet = g(wk), g(bk), g(gk), g(bek)
+            return (Wm * gam.unsqueeze(0)).contiguous(), (bm.double() + Wm.double() @ bet.double()).to(torch.float32).contiguous()
+
         self.layers = []
         for l in range(self.L):
             p = f"decoder.layers.{l}."
+            in_w, in_b = fold(p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias", p + "norm1.weight", p + "norm1.bias")
+            f1_w, f1_b = fold(p + "linear1.weight", p + "linear1.bias", p + "norm2.weight", p + "norm2.bias")
             self.layers.append(dict(
-                ln1_w=g(p + "norm1.weight"), ln1_b=g(p + "norm1.bias"),
-                in_proj_w=g(p + "self_attn.in_proj_weight"), in_proj_b=g(p + "self_attn.in_proj_bias"),
+                ln1_w=ones, ln1_b=zeros, in_proj_w=in_w, in_proj_b=in_b,
                 out_proj_w=g(p + "self_attn.out_proj.weight"), out_proj_b=g(p + "self_attn.out_proj.bias"),
-                ln2_w=g(p + "norm2.weight"), ln2_b=g(p + "norm2.bias"),
-                ffn1_w=g(p + "linear1.weight"), ffn1_b=g(p + "linear1.bias"),
+                ln2_w=ones, ln2_b=zeros, ffn1_w=f1_w, ffn1_b=f1_b,
                 ffn2_w=g(p + "linear2.weight"), ffn2_b=g(p + "linear2.bias")))
-        self.lnf_w, self.lnf_b = g("decoder.norm.weight"), g("decoder.norm.bias")
-        self.head1_w = torch.cat([g(f"predict_layer.{k}.0.weight") for k in range(self.K)], 0).contiguous()
-        self.head1_b = torch.cat([g(f"predict_layer.{k}.0.bias") for k in range(self.K)], 0).contiguous()
+        self.lnf_w, self.lnf_b = ones, zeros
+        gam, bet = g("decoder.norm.weight"), g("decoder.norm.bias")
+        h1w = torch.cat([g(f"predict_layer.{k}.0.weight") for k in range(self.K)], 0)
+        h1b = torch.cat([g(f"predict_layer.{k}.0.bias") for k in range(self.K)], 0)
+        self.head1_w = (h1w * gam.unsqueeze(0)).contiguous()
+        self.head1_b = (h1b.double() + h1w.double() @ bet.double()).to(torch.float32).contiguous()
         self.head2_w = torch.stack([g(f"predict_layer.{k}.2.weight") for k in range(self.K)]).contiguous()
         self.head2_b = torch.stack([g(f"predict_layer.{k}.2.bias") for k in range(self.K)]).contiguous()
 
@@ -88,7 +101,7 @@ class LMWeightsArena:
         """Algorithmic weight bytes one decode step must stream."""
         n = 0
         for lay in self.layers:
-            n += sum(t.numel() for t in lay.values())
+            n += sum(t.numel() for k, t in lay.items())     # incl. the (now constant) LayerNorm vectors, as SURVEY §8d counts them
         n += self.lnf_w.numel() + self.lnf_b.numel()
         n += self.head1_w.numel() + self.head1_b.numel() + self.head2_w.numel() + self.head2_b.numel()
         n += (self.K + 1) * self.D  # K embedding rows + one pe row
@@ -110,7 +123,7 @@ class LMWeightsArena:
         return w
 
     def dims(self):
-        return _lib.LMDims(self.D, self.H, self.L, self.F, self.K, self.card, self.Hh, self.n_text, self.max_pos)
+        return _lib.LMDims(self.D, self.H, self.L, self.F, self.K, self.card, self.Hh, self.n_text, self.max_pos, int(self.ln_folded))
 
 
 class DecodeEngine:

@@ -87,5 +87,14 @@ int main() {
     printf("blocks %4d | touch rf2 nt %6.2f (%.2f) | fma rf2 nt %6.2f (%.2f) | fma rf2 plain %6.2f (%.2f) | fma rf4 nt %6.2f (%.2f) | fma rf1 nt %6.2f (%.2f) | fma rf3 nt %6.2f (%.2f)\n",
            g, a, mb / a, b, mb / b, c, mb / c, d, mb / d, e, mb / e, f, mb / f);
   }
+  // Infinity-Cache residency: the same 67 MB buffer every launch (fits the 256 MiB MALL) vs 16 different buffers
+  {
+    std::vector<float*> one(1, Ws[0]), two(2);
+    two[0] = Ws[0]; two[1] = Ws[1];
+    for (int g : {512, 768}) {
+      float a = run<2, true, true>(one, x, y, N, g, 200), b = run<2, false, true>(one, x, y, N, g, 200), c = run<2, true, true>(two, x, y, N, g, 200), d = run<2, true, false>(one, x, y, N, g, 200);
+      printf("MALL-resident, blocks %d: fma rf2 nt 1 buffer %6.2f (%.2f TB/s) | plain loads %6.2f (%.2f) | 2 buffers (134 MB) nt %6.2f (%.2f) | touch-only %6.2f (%.2f)\n", g, a, mb / a, b, mb / b, c, mb / c, d, mb / d);
+    }
+  }
   return 0;
 }
