@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void embed_kernel(const ssrhip_embed_args a) {
   embed_row(a, r, a.kind ? a.kind[r] : 1, a.pos[r], a.tok + (size_t)r * SSRHIP_MAX_CODEBOOKS, threadIdx.x, 256);
 }
 
-constexpr int MAXE = 34;   // logits per lane: card <= 64*34 = 2176
+constexpr int MAXE = 9;     // logits per lane: 4 waves per codebook -> card <= 4*64*9 = 2304
+constexpr int WPC = 4;      // waves per codebook
+constexpr int SAMPLE_THREADS = 64 * WPC * SSRHIP_MAX_CODEBOOKS;   // 1024
 
 #ifdef SSR_SAMPLE_PROFILE   // tools/sampler_bench.hip: phase time stamps (shader clock) of wave 0
 __device__ unsigned long long g_sample_prof[16];
@@ -67,13 +69,6 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   return x;
 }
 
-// ---- exact selection without a sort: 4-pass radix select (8 bits per pass) on the order-preserving integer image of
-// the logits. Each wave (= one codebook) owns a 256-bin histogram in LDS, filled with LDS atomics — integer counts for
-// top-k, 2^-40 fixed-point probability mass for top-p, so the sums are exact integers: order-independent, hence
-// bit-reproducible although atomics are used. Per pass: 34 ds_add per lane + one 64-lane suffix scan.
-constexpr int NCC = 8, NCM = 4;   // histogram copies: counts (u32), mass (u64); both fit the same 8 KiB per wave
-__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-
 template <class T>
 __device__ __forceinline__ T suffix_excl(T v, int lane) {   // sum of v over lanes > lane
   T inc = v;
@@ -85,278 +80,262 @@ __device__ __forceinline__ T suffix_excl(T v, int lane) {   // sum of v over lan
   return inc - v;
 }
 
-// key of the kk-th largest valid key (valid keys are != 0)
-__device__ __forceinline__ uint32_t radix_kth(const uint32_t (&key)[MAXE], int kk, unsigned* hc, int lane) {
-  uint32_t prefix = 0, mask = 0;
-  unsigned need = (unsigned)kk;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    // NCC lane-group-private copies of the histogram: logits cluster in a few float exponents, so the high digits put
-    // most lanes of a ds_add on the same bin; private copies cut that serialisation NCC-fold
-#pragma unroll
-    for (int j = 0; j < 4 * NCC; ++j) hc[j * 64 + lane] = 0u;
-    lds_fence();
-    unsigned* mine = hc + (lane & (NCC - 1)) * 256;
-#pragma unroll
-    for (int e = 0; e < MAXE; ++e)
-      if (key[e] != 0u && (key[e] & mask) == prefix) atomicAdd(&mine[(key[e] >> shift) & 255u], 1u);
-    lds_fence();
-    unsigned c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll
-    for (int cpy = 0; cpy < NCC; ++cpy) {
-      const uint4 v = *reinterpret_cast<const uint4*>(hc + cpy * 256 + lane * 4);
-      c0 += v.x; c1 += v.y; c2 += v.z; c3 += v.w;
-    }
-    const unsigned a3 = suffix_excl<unsigned>(c0 + c1 + c2 + c3, lane);      // count in bins above bin 4*lane+3
-    const unsigned a2 = a3 + c3, a1 = a2 + c2, a0 = a1 + c1;
-    int found = -1;
-    unsigned above = 0;
-    if (need > a3 && need <= a3 + c3) { found = 3; above = a3; }
-    else if (need > a2 && need <= a2 + c2) { found = 2; above = a2; }
-    else if (need > a1 && need <= a1 + c1) { found = 1; above = a1; }
-    else if (need > a0 && need <= a0 + c0) { found = 0; above = a0; }
-    const unsigned long long bal = __ballot(found >= 0);
-    const int src = __builtin_amdgcn_readfirstlane(bal ? (int)__builtin_ctzll(bal) : 0);
-    const unsigned bin = (unsigned)__shfl(lane * 4 + found, src, 64);
-    need -= (unsigned)__shfl((int)above, src, 64);
-    prefix |= bin << shift;
-    mask |= 255u << shift;
-    lds_fence();
-  }
-  return prefix;
-}
+// Exact selection without a sort: 4-pass radix select (8 bits per pass) on the order-preserving integer image of the
+// logits. The WPC waves of a codebook each fill their own 256-bin histogram in LDS with LDS atomics (integer counts
+// for top-k, 2^-40 fixed-point probability mass for top-p: exact integer sums, order-independent => bit-reproducible);
+// after a workgroup barrier the codebook's first wave adds the WPC copies, scans the 256 bins from the top and
+// publishes (bin, remainder) for the next pass. All 16 waves take part in every barrier.
+struct SelShared {
+  unsigned long long hist[SSRHIP_MAX_CODEBOOKS][WPC][256];   // counts alias this as unsigned [..][256]
+  unsigned long long carry[SSRHIP_MAX_CODEBOOKS];            // count still needed / mass above the current bucket
+  unsigned bin[SSRHIP_MAX_CODEBOOKS];
+  int found[SSRHIP_MAX_CODEBOOKS];
+};
 
-// smallest key t* with mass(keys > t*) <= lim; 0 if even the whole mass is <= lim (keep everything)
-__device__ __forceinline__ uint32_t radix_mass(const uint32_t (&key)[MAXE], const float (&p)[MAXE], float lim, unsigned long long* hm, int lane) {
-  const float SC = 1099511627776.0f;                       // 2^40
+// MODE 0: key of the kk-th largest valid key (valid keys != 0).  MODE 1: smallest key t with mass(keys > t) <= lim (0: keep all).
+template <int MODE>
+__device__ __forceinline__ uint32_t radix_select(const uint32_t (&key)[MAXE], const float (&p)[MAXE], unsigned kk, float lim, bool active,
+                                                 SelShared& sh, int k, int sub, int lane) {
+  const float SC = 1099511627776.0f;   // 2^40
   const unsigned long long limfx = (unsigned long long)((double)lim * (double)SC);
   uint32_t prefix = 0, mask = 0;
-  unsigned long long base = 0;                              // mass of keys above the current prefix bucket
+  unsigned long long carry = (MODE == 0) ? (unsigned long long)kk : 0ull;
+  bool keep_all = false;
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
+    unsigned long long* mine64 = sh.hist[k][sub];
+    unsigned* mine32 = reinterpret_cast<unsigned*>(mine64);
+    if (MODE == 0) { for (int j = lane; j < 256; j += 64) mine32[j] = 0u; }
+    else { for (int j = lane; j < 256; j += 64) mine64[j] = 0ull; }
+    __syncthreads();
+    if (active && !keep_all) {
 #pragma unroll
-    for (int j = 0; j < 4 * NCM; ++j) hm[j * 64 + lane] = 0ull;
-    lds_fence();
-    unsigned long long* mine = hm + (lane & (NCM - 1)) * 256;
-#pragma unroll
-    for (int e = 0; e < MAXE; ++e)
-      if (p[e] > 0.f && (key[e] & mask) == prefix) atomicAdd(&mine[(key[e] >> shift) & 255u], (unsigned long long)(p[e] * SC));
-    lds_fence();
-    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-#pragma unroll
-    for (int cpy = 0; cpy < NCM; ++cpy) {
-      c0 += hm[cpy * 256 + lane * 4]; c1 += hm[cpy * 256 + lane * 4 + 1]; c2 += hm[cpy * 256 + lane * 4 + 2]; c3 += hm[cpy * 256 + lane * 4 + 3];
+      for (int e = 0; e < MAXE; ++e) {
+        const bool in = (MODE == 0) ? (key[e] != 0u) : (p[e] > 0.f);
+        if (in && (key[e] & mask) == prefix) {
+          if (MODE == 0) atomicAdd(&mine32[(key[e] >> shift) & 255u], 1u);
+          else atomicAdd(&mine64[(key[e] >> shift) & 255u], (unsigned long long)(p[e] * SC));
+        }
+      }
     }
-    const unsigned long long a3 = base + suffix_excl<unsigned long long>(c0 + c1 + c2 + c3, lane);
-    const unsigned long long a2 = a3 + c3, a1 = a2 + c2, a0 = a1 + c1;
-    // the bucket where the running mass (from the top) first exceeds lim: above <= lim < above + c
-    int found = -1;
-    unsigned long long above = 0;
-    if (a3 <= limfx && limfx < a3 + c3) { found = 3; above = a3; }
-    else if (a2 <= limfx && limfx < a2 + c2) { found = 2; above = a2; }
-    else if (a1 <= limfx && limfx < a1 + c1) { found = 1; above = a1; }
-    else if (a0 <= limfx && limfx < a0 + c0) { found = 0; above = a0; }
-    const unsigned long long bal = __ballot(found >= 0);
-    if (bal == 0ull) return 0u;                             // total mass <= lim: nothing is removed
-    const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(bal));
-    const unsigned bin = (unsigned)__shfl(lane * 4 + found, src, 64);
-    base = (unsigned long long)__shfl((long long)above, src, 64);
-    prefix |= bin << shift;
-    mask |= 255u << shift;
-    lds_fence();
+    __syncthreads();
+    if (sub == 0 && active && !keep_all) {          // this codebook's scanning wave: bins 4*lane .. 4*lane+3
+      unsigned long long c[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+      for (int w = 0; w < WPC; ++w)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          c[j] += (MODE == 0) ? (unsigned long long)reinterpret_cast<unsigned*>(sh.hist[k][w])[lane * 4 + j] : sh.hist[k][w][lane * 4 + j];
+      const unsigned long long base = (MODE == 0) ? 0ull : carry;
+      const unsigned long long a3 = base + suffix_excl<unsigned long long>(c[0] + c[1] + c[2] + c[3], lane);
+      const unsigned long long a2 = a3 + c[3], a1 = a2 + c[2], a0 = a1 + c[1];
+      int f = -1;
+      unsigned long long above = 0;
+      if (MODE == 0) {       // need-th largest falls into the bucket with above < need <= above + c
+        if (carry > a3 && carry <= a3 + c[3]) { f = 3; above = a3; }
+        else if (carry > a2 && carry <= a2 + c[2]) { f = 2; above = a2; }
+        else if (carry > a1 && carry <= a1 + c[1]) { f = 1; above = a1; }
+        else if (carry > a0 && carry <= a0 + c[0]) { f = 0; above = a0; }
+      } else {               // running mass from the top first exceeds lim in the bucket with above <= lim < above + c
+        if (a3 <= limfx && limfx < a3 + c[3]) { f = 3; above = a3; }
+        else if (a2 <= limfx && limfx < a2 + c[2]) { f = 2; above = a2; }
+        else if (a1 <= limfx && limfx < a1 + c[1]) { f = 1; above = a1; }
+        else if (a0 <= limfx && limfx < a0 + c[0]) { f = 0; above = a0; }
+      }
+      const unsigned long long bal = __ballot(f >= 0);
+      if (lane == 0) sh.found[k] = bal ? 1 : 0;
+      if (f >= 0) {          // exactly one lane
+        sh.bin[k] = (unsigned)(lane * 4 + f);
+        sh.carry[k] = (MODE == 0) ? (carry - above) : above;
+      }
+    }
+    __syncthreads();
+    if (active && !keep_all) {
+      if (!sh.found[k]) keep_all = true;           // MODE 1 only: the whole mass is <= lim
+      else {
+        prefix |= sh.bin[k] << shift;
+        mask |= 255u << shift;
+        carry = sh.carry[k];
+      }
+    }
   }
-  return prefix;
+  return keep_all ? 0u : prefix;
 }
 
-__global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a) {
-  __shared__ int sh_sample[4];
+__global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(const ssrhip_sample_args a) {
+  __shared__ SelShared sel;
+  __shared__ float sh_f[SSRHIP_MAX_CODEBOOKS][WPC];
+  __shared__ int sh_i[SSRHIP_MAX_CODEBOOKS][WPC];
+  __shared__ int sh_sample[SSRHIP_MAX_CODEBOOKS];
   __shared__ int sh_argmax0;
   __shared__ int sh_next[SSRHIP_MAX_CODEBOOKS + 2];   // next tokens, next audio pos, live flag
-  __shared__ __attribute__((aligned(16))) unsigned long long sh_hist[4][NCM * 256];   // per-codebook radix histograms (8 KiB each; reused as u32 x NCC)
   const int u = blockIdx.x;
   const ssrhip_sampler_cfg& c = a.cfg[u];
   ssrhip_sampler_state& st = a.state[u];
-  if (st.done) return;
-  const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+  if (st.done) return;                                 // uniform for the whole workgroup
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = wave / WPC, sub = wave % WPC;
   const int K = a.K, card = a.card;
-  const int ne = (card + 63) / 64;
+  const bool active = k < K;
   const int rows = c.use_cfg ? 2 : 1;
   const int row0 = u * rows;
-  // snapshot of the state (all waves read before thread 0 mutates it after the barrier)
+  // snapshot of the state (every wave reads it before thread 0 mutates it, after the barriers below)
   const int num_gen = st.num_gen, num_eog = st.num_eog, cfg_tag = st.num_cfg_tag;
   const int prev_token = st.prev_token, consec = st.consec_silence;
   const int step = st.n_steps;
-
-  // cfg fields are copied to registers once: the dbg_logits stores below may alias `c` as far as the
-  // compiler knows, which would otherwise force a scalar reload of every field after every store
+  // cfg fields into registers once
   const int c_eos = c.eos, c_sos = c.sos, c_mts = c.mts, c_mts_end = c.mts + c.max_n_spans;
   const int c_empty = c.empty_token, c_eog = c.eog, c_topk = c.top_k, c_stoprep = c.stop_repetition;
   const float c_topp = c.top_p, c_temp = c.temperature, c_coef = c.cfg_coef, c_om = c.cfg_one_minus;
   const int c_maxsteps = c.max_steps, c_nsil = c.n_silence;
   const uint32_t c_seedlo = c.seed_lo, c_seedhi = c.seed_hi;
-
   STAMP(0);
-  if (k < K) {
-    const float* lc = a.logits + ((size_t)row0 * K + k) * card;
-    const float* lu = lc + (size_t)K * card;
-    const bool guided = c.use_cfg && (cfg_tag == c.cfg_stride);
-    bool penal = false;     // silence-repetition penalty applies to logits[0][prev_token] (:726-730)
-    if (k == 0 && num_eog == 0 && c_stoprep > 0 && consec > c_stoprep)
-      for (int s = 0; s < c_nsil; ++s) penal |= (c.silence[s] == prev_token);
-    const float npen = (float)(consec - (c_stoprep - 1));
-    const bool force_empty = (num_gen < K - 1) && (k > num_gen);     // :705-707
-    const bool cut_eog_empty = (num_eog > 0) && (k > num_eog);       // :710-712
-    const bool cut_eog = (num_eog == 0) && (k >= 1);                 // :722-723
-    float* dbg = a.dbg_logits ? a.dbg_logits + ((size_t)u * K + k) * card : nullptr;
-    // CFG combine + special-token edits of one logit, branch-free
-    auto edit = [&](int i, float vc, float vu) -> float {
-      float v = guided ? __fadd_rn(__fmul_rn(c_coef, vc), __fmul_rn(c_om, vu)) : vc;
-      const bool special = (i == c_eos) | (i == c_sos) | ((i >= c_mts) & (i < c_mts_end));
-      v = special ? -10000.f : v;
-      v = (force_empty & (i == c_empty)) ? 10000.f : v;
-      v = (cut_eog_empty & ((i == c_eog) | (i == c_empty))) ? -10000.f : v;
-      v = (cut_eog & (i == c_eog)) ? -10000.f : v;
-      return v;
-    };
-    // the one penalised entry is computed up front (one IEEE division per wave, not per element)
-    int pen_idx = -1;
-    float pen_val = 0.f;
-    if (penal && prev_token >= 0 && prev_token < card) {
-      const float v = edit(prev_token, lc[prev_token], guided ? lu[prev_token] : 0.f);
-      pen_val = (v < 0.f) ? __fmul_rn(v, npen) : __fdiv_rn(v, npen);
-      pen_idx = prev_token;
-    }
-    // all loads first (no store in between: the optional dbg store could alias them and would serialise
-    // 2x34 dependent L2 round trips), then the edits, then the optional debug dump
-    float l[MAXE], lun[MAXE];
+
+  // ---- CFG combine (:690-696) + edits (:699-730); element e of this lane is index e*256 + sub*64 + lane
+  const int kc = active ? k : 0;
+  const float* lc = a.logits + ((size_t)row0 * K + kc) * card;
+  const float* lu = lc + (size_t)K * card;
+  const bool guided = c.use_cfg && (cfg_tag == c.cfg_stride);
+  bool penal = false;     // silence-repetition penalty applies to logits[0][prev_token] (:726-730)
+  if (k == 0 && num_eog == 0 && c_stoprep > 0 && consec > c_stoprep)
+    for (int s = 0; s < c_nsil; ++s) penal |= (c.silence[s] == prev_token);
+  const float npen = (float)(consec - (c_stoprep - 1));
+  const bool force_empty = (num_gen < K - 1) && (k > num_gen);     // :705-707
+  const bool cut_eog_empty = (num_eog > 0) && (k > num_eog);       // :710-712
+  const bool cut_eog = (num_eog == 0) && (k >= 1);                 // :722-723
+  float l[MAXE], lun[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int i = e * 256 + sub * 64 + lane;
+    const int ic = (i < card) ? i : 0;
+    l[e] = lc[ic];
+    lun[e] = guided ? lu[ic] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    const int i = e * 256 + sub * 64 + lane;
+    float v = guided ? __fadd_rn(__fmul_rn(c_coef, l[e]), __fmul_rn(c_om, lun[e])) : l[e];
+    const bool special = (i == c_eos) | (i == c_sos) | ((i >= c_mts) & (i < c_mts_end));
+    v = special ? -10000.f : v;
+    v = (force_empty & (i == c_empty)) ? 10000.f : v;
+    v = (cut_eog_empty & ((i == c_eog) | (i == c_empty))) ? -10000.f : v;
+    v = (cut_eog & (i == c_eog)) ? -10000.f : v;
+    if (penal && i == prev_token) v = (v < 0.f) ? __fmul_rn(v, npen) : __fdiv_rn(v, npen);
+    l[e] = (active && i < card) ? v : -INFINITY;
+  }
+  if (a.dbg_logits && active) {
+    float* dbg = a.dbg_logits + ((size_t)u * K + k) * card;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
-      const int i = e * 64 + lane;
-      const int ic = ((e < ne) && (i < card)) ? i : 0;
-      l[e] = lc[ic];
-      lun[e] = guided ? lu[ic] : 0.f;
+      const int i = e * 256 + sub * 64 + lane;
+      if (i < card) dbg[i] = l[e];
     }
-    // every edited index lies in [empty_token, mts_end) (8 consecutive ids) or is the penalised token:
-    // only the (wave-uniform) element groups that contain them run the select chain
-    const int sp_lo = min(min(c_empty, c_eog), min(min(c_eos, c_sos), c_mts)) >> 6;
-    const int sp_hi = (max(max(c_empty, c_eog), max(max(c_eos, c_sos), c_mts_end - 1))) >> 6;
-    const int pen_e = pen_idx >> 6;     // -1 when there is no penalty
+  }
+  STAMP(1);
+  // ---- max / argmax of the edited logits (first index on ties), needed for the stop rule :739
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) mx = fmaxf(mx, l[e]);
+  mx = wave_max(mx);
+  int am = 0x7fffffff;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) if (l[e] == mx) am = min(am, e * 256 + sub * 64 + lane);
+  am = wave_min_i(am);
+  if (lane == 0 && active) { sh_f[k][sub] = mx; sh_i[k][sub] = am; }
+  __syncthreads();
+  if (active) {
+    float m2 = sh_f[k][0];
+    int a2 = sh_i[k][0];
+#pragma unroll
+    for (int w = 1; w < WPC; ++w)
+      if (sh_f[k][w] > m2 || (sh_f[k][w] == m2 && sh_i[k][w] < a2)) { m2 = sh_f[k][w]; a2 = sh_i[k][w]; }
+    mx = m2;
+    am = a2;
+  }
+  __syncthreads();
+  // ---- temperature (:80-81): true division, like the reference
+  if (c_temp != 1.0f) {
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) l[e] = __fdiv_rn(l[e], c_temp);
+    float m3 = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) m3 = fmaxf(m3, l[e]);
+    m3 = wave_max(m3);
+    if (lane == 0 && active) sh_f[k][sub] = m3;
+    __syncthreads();
+    if (active) mx = fmaxf(fmaxf(sh_f[k][0], sh_f[k][1]), fmaxf(sh_f[k][2], sh_f[k][3]));
+    __syncthreads();
+  }
+  uint32_t key[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) key[e] = (active && (e * 256 + sub * 64 + lane) < card) ? okey(l[e]) : 0u;   // 0 = padding
+  const uint32_t kmax = okey(mx);
+  float p[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) p[e] = 0.f;
+  STAMP(2);
+  // ---- top-k (:38-44): keep logits >= k-th largest value (ties kept)
+  uint32_t thr = 0;   // keep keys >= thr
+  if (c_topk > 0) {   // uniform
+    const int kk = min(max(c_topk, 1), card);
+    if (kk == 1) thr = kmax;
+    else if (kk < card) thr = radix_select<0>(key, p, (unsigned)kk, 0.f, active, sel, kc, sub, lane);
+  }
+  STAMP(3);
+  // ---- softmax numerators over the kept set, then top-p (:46-67)
+  float Z = 0.f;
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) {
+    p[e] = (key[e] != 0u && key[e] >= thr) ? __expf(l[e] - mx) : 0.f;
+    Z += p[e];
+  }
+  Z = wave_sum(Z);
+  if (lane == 0 && active) sh_f[k][sub] = Z;
+  __syncthreads();
+  if (active) Z = (sh_f[k][0] + sh_f[k][1]) + (sh_f[k][2] + sh_f[k][3]);
+  __syncthreads();
+  if (c_topp < 1.0f) {   // uniform
+    const uint32_t tp = radix_select<1>(key, p, 0u, c_topp * Z, active, sel, kc, sub, lane);
+    if (tp > thr) {
+      thr = tp;
+#pragma unroll
+      for (int e = 0; e < MAXE; ++e) p[e] = (key[e] >= thr) ? p[e] : 0.f;
+    }
+  }
+  STAMP(4);
+  // ---- multinomial(softmax, 1) == argmax(prob / q), q ~ Exp(1)   (torch CPU fast path; :85).
+  // The positive normaliser does not change the argmax, so it is dropped.
+  {
+    const float* nz = a.noise ? a.noise + (((size_t)u * c_maxsteps + step) * K + kc) * card : nullptr;
+    const uint32_t sd = hash32(c_seedlo + (uint32_t)step * 0x9E3779B1u) ^ hash32(c_seedhi + (uint32_t)kc * 0x85EBCA6Bu + 0x632BE5ABu);
+    float best = -1.f;
+    int bi = 0x7fffffff;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
-      const int i = e * 64 + lane;
-      const bool valid = (e < ne) && (i < card);
-      float v;
-      if ((e >= sp_lo && e <= sp_hi) || e == pen_e) {           // wave-uniform
-        v = edit(i, l[e], lun[e]);
-        v = (i == pen_idx) ? pen_val : v;
-      } else {
-        v = guided ? __fadd_rn(__fmul_rn(c_coef, l[e]), __fmul_rn(c_om, lun[e])) : l[e];
-      }
-      l[e] = valid ? v : -INFINITY;
-    }
-    if (dbg) {
-#pragma unroll
-      for (int e = 0; e < MAXE; ++e) {
-        const int i = e * 64 + lane;
-        if ((e < ne) && (i < card)) dbg[i] = l[e];
-      }
-    }
-    STAMP(1);
-    // ---- argmax of the edited logits (first index on ties), needed for the stop rule :739
-    float mx = -INFINITY;
-#pragma unroll
-    for (int e = 0; e < MAXE; ++e) mx = fmaxf(mx, l[e]);
-    mx = wave_max(mx);
-    int am = 0x7fffffff;
-#pragma unroll
-    for (int e = 0; e < MAXE; ++e) if (l[e] == mx) am = min(am, e * 64 + lane);
-    am = wave_min_i(am);
-    // ---- temperature (:80-81): true division, like the reference
-    if (c_temp != 1.0f) {
-#pragma unroll
-      for (int e = 0; e < MAXE; ++e) l[e] = __fdiv_rn(l[e], c_temp);
-      mx = -INFINITY;
-#pragma unroll
-      for (int e = 0; e < MAXE; ++e) mx = fmaxf(mx, l[e]);
-      mx = wave_max(mx);
-    }
-    uint32_t key[MAXE];
-#pragma unroll
-    for (int e = 0; e < MAXE; ++e) key[e] = ((e * 64 + lane) < card && e < ne) ? okey(l[e]) : 0u;   // 0 = padding, below every real key
-    const uint32_t kmax = okey(mx);
-    STAMP(2);
-    // ---- top-k (:38-44): keep logits >= k-th largest value (ties kept)
-    uint32_t thr = 0;   // keep keys >= thr
-    if (c_topk > 0) {
-      const int kk = min(max(c_topk, 1), card);
-      if (kk == 1) {
-        thr = kmax;
-      } else if (kk < card) {
-        thr = radix_kth(key, kk, reinterpret_cast<unsigned*>(sh_hist[k]), lane);
-      }
-    }
-    STAMP(3);
-    // ---- softmax numerators over the kept set, then top-p (:46-67)
-    float p[MAXE];
-    float Z = 0.f;
-#pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      p[e] = (key[e] != 0u && key[e] >= thr) ? __expf(l[e] - mx) : 0.f;
-      Z += p[e];
-    }
-    Z = wave_sum(Z);
-    if (c_topp < 1.0f) {
-      // smallest key t* with mass(keys > t*) <= top_p * Z ; keep keys >= t*
-      const float lim = c_topp * Z;
-      const uint32_t tp = radix_mass(key, p, lim, sh_hist[k], lane);
-      if (tp > thr) {
-        thr = tp;
-#pragma unroll
-        for (int e = 0; e < MAXE; ++e) p[e] = (key[e] >= thr) ? p[e] : 0.f;
-      }
-    }
-    STAMP(4);
-    // ---- multinomial(softmax, 1) == argmax(prob / q), q ~ Exp(1)   (torch CPU fast path; :85).
-    // The positive normaliser does not change the argmax, so it is dropped.
-    const float* nz = a.noise ? a.noise + (((size_t)u * c_maxsteps + step) * K + k) * card : nullptr;
-    const uint32_t sd = hash32(c_seedlo + (uint32_t)step * 0x9E3779B1u) ^ hash32(c_seedhi + (uint32_t)k * 0x85EBCA6Bu + 0x632BE5ABu);
-    float sc[MAXE];
-#pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      const int i = e * 64 + lane;
+      const int i = e * 256 + sub * 64 + lane;
       float q;
-      if (nz) q = nz[(key[e] != 0u) ? i : 0];                         // wave-uniform branch
+      if (nz) q = nz[(key[e] != 0u) ? i : 0];                       // wave-uniform branch
       else {
         const uint32_t hsh = hash32(sd + (uint32_t)i * 0x9E3779B1u);
         q = fmaxf(-__logf(((float)(hsh >> 8) + 1.0f) * (1.0f / 16777216.0f)), 1e-30f);
       }
-      sc[e] = (p[e] > 0.f) ? __fdividef(p[e], q) : -1.f;
+      const float sc = (p[e] > 0.f) ? __fdividef(p[e], q) : -1.f;
+      const bool better = sc > best;                                 // e ascending => lowest index wins ties within the lane
+      best = better ? sc : best;
+      bi = better ? i : bi;
     }
-    // per-lane best (lowest element index wins ties): 4 independent chains, then merged in index order
-    float bs[4] = {-1.f, -1.f, -1.f, -1.f};
-    int be[4] = {0, 1, 2, 3};
+    const float wb = wave_max(best);
+    bi = (best == wb) ? bi : 0x7fffffff;
+    bi = wave_min_i(bi);
+    if (lane == 0 && active) { sh_f[k][sub] = wb; sh_i[k][sub] = bi; }
+    __syncthreads();
+    if (active && sub == 0 && lane == 0) {
+      float b2 = sh_f[k][0];
+      int i2 = sh_i[k][0];
 #pragma unroll
-    for (int e = 0; e < MAXE; ++e) {
-      const bool better = sc[e] > bs[e & 3];
-      bs[e & 3] = better ? sc[e] : bs[e & 3];
-      be[e & 3] = better ? e : be[e & 3];
-    }
-    float best = bs[0];
-    int beste = be[0];
-#pragma unroll
-    for (int j = 1; j < 4; ++j) {
-      const bool better = bs[j] > best || (bs[j] == best && be[j] < beste);
-      best = better ? bs[j] : best;
-      beste = better ? be[j] : beste;
-    }
-    int bi = beste * 64 + lane;
-    {
-      const float wb = wave_max(best);
-      bi = (best == wb) ? bi : 0x7fffffff;
-      bi = wave_min_i(bi);
-    }
-    if (lane == 0) {
-      sh_sample[k] = bi;
+      for (int w = 1; w < WPC; ++w)
+        if (sh_f[k][w] > b2 || (sh_f[k][w] == b2 && sh_i[k][w] < i2)) { b2 = sh_f[k][w]; i2 = sh_i[k][w]; }
+      sh_sample[k] = i2;
       if (k == 0) sh_argmax0 = am;
     }
   }
@@ -420,7 +399,7 @@ __global__ __launch_bounds__(256) void sample_kernel(const ssrhip_sample_args a)
   if (a.embed.out) {
     __syncthreads();
     if (sh_next[SSRHIP_MAX_CODEBOOKS + 1]) {
-      for (int rr = 0; rr < rows; ++rr) embed_row(a.embed, row0 + rr, 1, sh_next[SSRHIP_MAX_CODEBOOKS], sh_next, threadIdx.x, 256);
+      for (int rr = 0; rr < rows; ++rr) embed_row(a.embed, row0 + rr, 1, sh_next[SSRHIP_MAX_CODEBOOKS], sh_next, threadIdx.x, SAMPLE_THREADS);
     }
   }
   STAMP(8);
@@ -441,10 +420,10 @@ extern "C" int ssrhip_sample(const ssrhip_sample_args* a, ssrhip_stream_t stream
   SSR_REQUIRE(a && a->logits && a->cfg && a->state && a->generated && a->next_tok && a->next_pos && a->kv_pos && a->row_len,
               "ssrhip_sample: null argument");
   SSR_REQUIRE(a->K >= 1 && a->K <= SSRHIP_MAX_CODEBOOKS, "ssrhip_sample: K=%d", a->K);
-  SSR_REQUIRE(a->card > 0 && a->card <= 64 * MAXE, "ssrhip_sample: card=%d exceeds %d", a->card, 64 * MAXE);
+  SSR_REQUIRE(a->card > 0 && a->card <= 64 * WPC * MAXE, "ssrhip_sample: card=%d exceeds %d", a->card, 64 * WPC * MAXE);
   if (a->embed.out) SSR_REQUIRE(a->embed.audio_emb && a->embed.pe && a->embed.D % 4 == 0 && a->embed.K == a->K && a->embed.card == a->card,
                                 "ssrhip_sample: fused embed needs audio_emb, pe, matching K/card");
-  hipLaunchKernelGGL(sample_kernel, dim3(a->n_utt), dim3(256), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(sample_kernel, dim3(a->n_utt), dim3(SAMPLE_THREADS), 0, (hipStream_t)stream, *a);
   SSR_LAUNCH_CHECK();
   return 0;
 }

@@ -538,6 +538,18 @@ __global__ __launch_bounds__(256, (B <= 2 && PRO != SSRHIP_PRO_ATTN_COMBINE) ? 3
       if (lane == b) { kvb[0] = kb; kvb[1] = vb; }
     }
   }
+  // split-K (FFN2): the threads that will add the slices and finalise a row fetch that row's bias / residual now
+  RowEpi efin = {0.f, 0.f};
+  int nfin = -1, bfin = 0;
+  if (p.nslice > 1) {
+    const int tt = min(t, n_rg * MAX_IT * B - 1);
+    bfin = tt % B;
+    const int i2 = (tt / B) % MAX_IT, rg2 = tt / (B * MAX_IT);
+    nfin = (blockIdx.x * n_rg + rg2) + i2 * p.groups_x;
+    const int nc = min(nfin, N - 1);
+    efin.bias = a.bias ? a.bias[(size_t)g * N + nc] : 0.f;
+    efin.resid = (a.epi == SSRHIP_EPI_RESIDUAL) ? a.y[(size_t)bfin * a.y_stride + (size_t)g * N + nc] : 0.f;
+  }
   // ---- 3. prologue math (under the rows' latency)
   if constexpr (PRO == SSRHIP_PRO_LAYERNORM) {
     float* red = smem;                               // aliases `part`: not live yet
@@ -663,18 +675,12 @@ __global__ __launch_bounds__(256, (B <= 2 && PRO != SSRHIP_PRO_ATTN_COMBINE) ? 3
   }
   if (p.nslice > 1) {
     __syncthreads();
-    if (t < n_rg * MAX_IT * B) {
-      const int b = t % B, i2 = (t / B) % MAX_IT, rg2 = t / (B * MAX_IT);
-      const int nn = (blockIdx.x * n_rg + rg2) + i2 * p.groups_x;
-      if (nn < N) {
-        float v = 0.f;
-        for (int s = 0; s < p.nslice; ++s) v += part[((rg2 * p.nslice + s) * MAX_IT + i2) * B + b];
-        RowEpi e;
-        e.bias = a.bias ? a.bias[(size_t)g * N + nn] : 0.f;
-        e.resid = (a.epi == SSRHIP_EPI_RESIDUAL) ? a.y[(size_t)b * a.y_stride + (size_t)g * N + nn] : 0.f;
-        float* kv2[2] = {nullptr, nullptr};
-        finalize(p, g, nn, b, v, e, kv2);
-      }
+    if (t < n_rg * MAX_IT * B && nfin < N) {
+      const int i2 = (t / B) % MAX_IT, rg2 = t / (B * MAX_IT);
+      float v = 0.f;
+      for (int s = 0; s < p.nslice; ++s) v += part[((rg2 * p.nslice + s) * MAX_IT + i2) * B + bfin];
+      float* kv2[2] = {nullptr, nullptr};
+      finalize(p, g, nfin, bfin, v, efin, kv2);
     }
   }
 }
