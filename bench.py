@@ -157,13 +157,21 @@ def main():
         ms_per_step = 1000 * elapsed / a.steps
         tokens_per_step = 4 * world                      # K=4 codebooks x 1 frame x one utterance per GPU
         value = tokens_per_step * a.steps / elapsed
-        # ---- roofline of the dominant kernel (weight-streaming GEMV): event-timed per launch, eager
+        # ---- roofline of the dominant kernel (weight-streaming GEMV). Two HIP-event measurements on the launch stream:
+        #  * per-slot: an event pair around every launch of eager steps (per-shape view; carries ~3 us event overhead each);
+        #  * category: the 66 GEMV launches of a step replayed as a hipGraph between ONE event pair -> the average launch
+        #    duration as the product runs it; this is what `achieved` uses and what rocprofv3's durations must agree with.
         slots = eng.time_kernels(8)
         gemv_slots = [us for kind, us in slots if kind == "gemv"]
         n_gemv = len(gemv_slots)
         w_bytes = arena.nbytes_per_step() - 4 * (arena.K + 1) * arena.D      # GEMV-streamed bytes (embedding rows excluded)
         bytes_per_launch = w_bytes / n_gemv
-        gemv_us = sum(gemv_slots) / n_gemv
+        gemv_us_eager = sum(gemv_slots) / n_gemv
+        gemv_us, n_cat = eng.time_category("gemv", 50)
+        attn_us, _ = eng.time_category("attn", 50)
+        room = min(eng.max_steps - int(eng.states()[0].n_steps), eng.max_seq - int(L + T0 + eng.states()[0].n_steps)) - 8
+        samp_us = eng.time_category("sample", min(50, room) - 3)[0] if room >= 10 else float("nan")   # the sampler advances the state
+        assert n_cat == n_gemv
         achieved = bytes_per_launch / (gemv_us * 1e-6) / 1e9
         # per-shape view of one layer (slots 0..4 = QKV, attention, out-proj, FFN1, FFN2 of layer 0.., averaged over layers)
         nl = arena.L
@@ -188,8 +196,10 @@ def main():
                          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r01_pmc_*.md), gfx950 x2 correction
                          # for wide reads applied: 50.5 MB read + 0.1 MB written per GEMV launch vs 49.85 MB algorithmic
                          "traffic": TRAFFIC_BYTES_PER_GEMV_LAUNCH if (arena.D == 2048 and arena.L == 16) else None,
-                         "kernel": "gemv_kernel<2> (fused LN/combine + GEMV + bias/act/residual)",
+                         "kernel": "gemv_fast_kernel<2,*> (fused LN/combine + GEMV + bias/act/residual), all 66 launches of a step",
                          "bytes_per_launch": int(bytes_per_launch), "launches_per_step": n_gemv, "us_per_launch": round(gemv_us, 3),
+                         "us_per_launch_eager_event_pair": round(gemv_us_eager, 3),
+                         "other_kernels_us_per_launch": {"attn_decode": round(attn_us, 3), "sample+embed": round(samp_us, 3)},
                          "step_level": {"bytes_per_step": int(arena.nbytes_per_step() + kv_bytes), "achieved": round(step_gbs, 1),
                                         "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
                          "event_timed_us_per_launch": per_shape},

@@ -286,6 +286,15 @@ int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ssrhip_stream
  * returns the number of slots (<= n_out) or a negative error. */
 int ssrhip_lm_time_steps(ssrhip_lm* lm, int32_t n_steps, ssrhip_stream_t stream, float* out_us, int32_t* out_kind, int32_t n_out);
 
+/* Launch duration of ONE kernel category inside a decode step, measured the way the product runs it: the launches of
+ * `category` (0 gemv | 1 attention | 2 sampler) of one step are captured into a hipGraph (the others are left out), the
+ * graph is replayed `n_replays` times between one hipEvent pair on `stream`, and the elapsed time is divided by the number
+ * of launches. No per-launch event overhead, so the figure agrees with rocprofv3's kernel durations (+ the ~0.1 us
+ * in-graph gap). The decode state is NOT advanced and the hidden-state buffers are left with garbage: call
+ * ssrhip_lm_prefill (DecodeEngine.start) again before decoding. */
+int ssrhip_lm_time_category(ssrhip_lm* lm, int32_t category, int32_t n_replays, ssrhip_stream_t stream, float* out_us_per_launch,
+                            int32_t* out_launches_per_step);
+
 #ifdef __cplusplus
 }
 #endif

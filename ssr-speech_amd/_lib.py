@@ -158,6 +158,7 @@ SYMBOLS = [
     ("ssrhip_lm_decode", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("ssrhip_lm_prefill", C.c_int, [C.c_void_p, C.POINTER(PrefillArgs), C.c_void_p]),
     ("ssrhip_lm_time_steps", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, c_f32p, c_i32p, C.c_int32]),
+    ("ssrhip_lm_time_category", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, c_f32p, c_i32p]),
 ]
 
 ABI_STRUCTS = [KV, GemvArgs, AttnArgs, EmbedArgs, SamplerCfg, SamplerState, SampleArgs, GemmArgs, LMWeights, LMDims,

@@ -62,12 +62,16 @@ struct Timer {   // optional per-launch event timing: one accumulator per launch
   hipStream_t s = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int slot = 0;
+  int only = -1;          // >= 0: enqueue only launches of this category (graph-chained category timing)
+  int n_enq = 0;
   std::vector<float> ms;
   std::vector<int> kind;
 };
 
 #define STEP_CALL(cat, call)                                    \
   do {                                                          \
+    if (tm && tm->only >= 0 && tm->only != (cat)) break;        \
+    if (tm) tm->n_enq += 1;                                     \
     if (tm && tm->on) hipEventRecord(tm->e0, tm->s);            \
     int _rc = (call);                                           \
     if (_rc) return _rc;                                        \
@@ -236,6 +240,44 @@ extern "C" int ssrhip_lm_time_steps(ssrhip_lm* lm, int32_t n_steps, ssrhip_strea
   SSR_REQUIRE(n <= n_out, "ssrhip_lm_time_steps: %d slots > n_out=%d", n, n_out);
   for (int i = 0; i < n; ++i) { out_us[i] = 1000.f * tm.ms[i] / n_steps; out_kind[i] = tm.kind[i]; }
   return n;
+}
+
+extern "C" int ssrhip_lm_time_category(ssrhip_lm* lm, int32_t category, int32_t n_replays, ssrhip_stream_t stream, float* out_us_per_launch,
+                                       int32_t* out_launches_per_step) {
+  SSR_REQUIRE(lm && category >= 0 && category <= CAT_SAMPLE && n_replays > 0 && out_us_per_launch && out_launches_per_step,
+              "ssrhip_lm_time_category: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  Timer tm;
+  tm.only = category;
+  hipStream_t cap = nullptr;
+  SSR_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+  SSR_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+  int rc = enqueue_step(lm, cap, &tm);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(cap, &g);
+  hipGraphExec_t ex = nullptr;
+  if (!rc && e == hipSuccess) e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  float ms = 0.f;
+  if (!rc && e == hipSuccess) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipGraphLaunch(ex, s);
+    hipEventRecord(e0, s);
+    for (int i = 0; i < n_replays; ++i) hipGraphLaunch(ex, s);
+    hipEventRecord(e1, s);
+    e = hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+  if (ex) hipGraphExecDestroy(ex);
+  if (g) hipGraphDestroy(g);
+  hipStreamDestroy(cap);
+  if (rc) return rc;
+  if (e != hipSuccess) { ssrhip_set_error("ssrhip_lm_time_category: %s", hipGetErrorString(e)); return -2; }
+  SSR_REQUIRE(tm.n_enq > 0, "ssrhip_lm_time_category: no launches in category %d", category);
+  *out_launches_per_step = tm.n_enq;
+  *out_us_per_launch = 1000.f * ms / ((float)n_replays * (float)tm.n_enq);
+  return 0;
 }
 
 extern "C" int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ssrhip_stream_t stream) {

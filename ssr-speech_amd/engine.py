@@ -325,3 +325,12 @@ class DecodeEngine:
             _lib.check(n, "ssrhip_lm_time_steps")
         names = ("gemv", "attn", "sample")
         return [(names[kind[i]], float(us[i])) for i in range(n)]
+
+    def time_category(self, kind: str, n_replays: int = 50):
+        """(avg_us_per_launch, launches_per_step) of one kernel category, graph-chained (no per-launch event overhead).
+        Leaves the hidden-state buffers dirty: `start()` again before decoding."""
+        us = C.c_float()
+        n = C.c_int32()
+        _lib.check(self.lib.ssrhip_lm_time_category(self._ctx, ("gemv", "attn", "sample").index(kind), int(n_replays),
+                                                    _lib.stream_ptr(), C.byref(us), C.byref(n)), "ssrhip_lm_time_category")
+        return float(us.value), int(n.value)
