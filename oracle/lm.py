@@ -362,9 +362,10 @@ def assemble(y: Tensor, generated: List[List[Tensor]], non_mask_intervals, args)
 def inference(sd: Dict[str, Tensor], args, x: Tensor, y: Tensor, mask_interval: Tensor, *, top_k=-100, top_p=1.0,
               temperature=1.0, stop_repetition=-1, kvcache=1, silence_tokens=(1388, 1898, 131), cfg_coef=1.5,
               cfg_stride=1, aug_text=False, max_steps: Optional[int] = None, noise_fn=None, trace: Optional[dict] = None,
-              uncond_x: Optional[Tensor] = None):
-    """models/ssr.py:504-812 with aug_context=False, cfg_pretrained=False (the only values reachable from
-    inference_scale.py:43-59). x [1,L] int64, y [1,T,K] int64, mask_interval [1,M,2].
+              uncond_x: Optional[Tensor] = None, prompt_x: Optional[Tensor] = None, prompt: Optional[Tensor] = None,
+              aug_context=False, cfg_pretrained=False):
+    """models/ssr.py:504-812. x [1,L] int64, y [1,T,K] int64, mask_interval [1,M,2]; `prompt_x` [1,Lp] / `prompt` [1,Tp,K]
+    are only read when `aug_context` is on (:578-594; inference_scale.py:43-59 never sets it, nor `cfg_pretrained`).
 
     `max_steps` (test/bench only) stops the while-loop early; `trace` collects per-step logits/timings;
     `noise_fn(step)->Tensor[K,card]` supplies recorded Exp(1) noise; `uncond_x` overrides the CFG random text
@@ -377,10 +378,24 @@ def inference(sd: Dict[str, Tensor], args, x: Tensor, y: Tensor, mask_interval: 
     y = y.transpose(2, 1)
     assert y.shape[0] == 1 and y.shape[1] == K
     assert mask_interval.shape == torch.Size((1, mask_interval.shape[1], 2))
-    if aug_text:
+    # :563-568 — the context is only prepended when the masked spans are short (< 2 s at 50 Hz)
+    context_len = sum(int(item[1] - item[0]) for item in mask_interval[0])
+    aug_context = bool(aug_context and context_len < 2 * 50)
+    out_len = 0
+    if aug_context:                                                                   # :578-594
+        assert prompt is not None and prompt_x is not None
+        prompt = prompt.transpose(2, 1)
+        assert prompt.shape[0] == 1 and prompt.shape[1] == K
+        out_len = prompt.shape[2]
+        y = torch.cat([prompt, y], dim=-1)
+        x = torch.cat([prompt_x, x], dim=1)
+        mask_interval = mask_interval + out_len                                       # :607-608
+    if aug_text:                                                                      # :571-577 / :582-588
         y = y.repeat(2, 1, 1)
-        if uncond_x is None:
-            uncond_x = torch.randint(0, n_text_tokens, (1, x.shape[1]))               # :574
+        if cfg_pretrained:
+            uncond_x = torch.full((1, x.shape[1]), args.text_vocab_size - 1, dtype=torch.long)
+        elif uncond_x is None:
+            uncond_x = torch.randint(0, n_text_tokens, (1, x.shape[1]))               # :574 / :585
         x = torch.cat([x, uncond_x], dim=0)
     B = x.shape[0]
     x_len = x.shape[-1]
@@ -395,6 +410,8 @@ def inference(sd: Dict[str, Tensor], args, x: Tensor, y: Tensor, mask_interval: 
         cated_y = cated_y.repeat(1, 1, 2)
     embedded_y = embed_y(sd, cated_y, K)
     x_padding_mask = torch.full((B, x_len), False)
+    if aug_text and cfg_pretrained:
+        x_padding_mask[1:, 1:] = True                                                 # :631-634
     past = torch.ones([args.num_decoder_layers, 2, B], dtype=torch.float32) if kvcache else None
     emb_inds = list(range(args.mts, args.mts + args.max_n_spans))
     generated = []
@@ -442,4 +459,10 @@ def inference(sd: Dict[str, Tensor], args, x: Tensor, y: Tensor, mask_interval: 
                 s_emb = s_emb.repeat(2, 1, 1)
             embedded_y = torch.cat([embedded_y, s_emb], dim=1)
         generated.append(cur)
-    return assemble(y, generated, non_mask_intervals, args)
+    res, marks, masks, nmi_out = assemble(y, generated, non_mask_intervals, args)
+    if aug_context:                                                                   # :806-810
+        res = res[:, :, out_len:]
+        marks = marks[:, out_len:]
+        masks = [(a - out_len, b - out_len) for a, b in masks]
+        nmi_out = [(a - out_len, b - out_len) for a, b in nmi_out]
+    return res, marks, masks, nmi_out

@@ -48,15 +48,35 @@ LM_CASES = [
 ]
 
 
-def make_lm():
+_G = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5)
+LM_CTX_CASES = [
+    # aug_context (prompt_x/prompt prepended, ssr.py:563-594,607-608,806-810) and cfg_pretrained (:576,:631-634)
+    # name, cfg, L, T, mask_interval, kwargs, seed, (Lp, Tp) of the separate prompt
+    ("ctx_tts_greedy_nocfg", dict(), 9, 14, [[14, 14]], dict(_G, cfg_stride=1, aug_text=False, aug_context=True), 31, (5, 8)),
+    ("ctx_tts_greedy_cfg2", dict(), 9, 14, [[14, 14]], dict(_G, cfg_stride=2, aug_text=True, aug_context=True), 32, (6, 9)),
+    ("ctx_edit_greedy_cfg1", dict(), 10, 26, [[8, 15]], dict(_G, cfg_stride=1, aug_text=True, aug_context=True), 33, (4, 7)),
+    ("ctx_ignored_long_span", dict(), 10, 130, [[10, 115]], dict(_G, cfg_stride=1, aug_text=True, aug_context=True), 34, (4, 7)),
+    ("cfgpre_tts_greedy", dict(), 11, 18, [[18, 18]], dict(_G, cfg_stride=1, aug_text=True, cfg_pretrained=True), 35, (3, 5)),
+    ("cfgpre_ctx_sample", dict(), 9, 16, [[16, 16]], dict(_G, top_k=8, top_p=0.9, cfg_stride=2, aug_text=True, aug_context=True, cfg_pretrained=True), 36, (5, 6)),
+]
+
+
+def make_lm(cases=None):
     ssr = ref_import.import_lm()
     out = {}
-    for name, cfg, L, T, mi, kw, seed in LM_CASES:
+    for case in (cases or LM_CASES):
+        name, cfg, L, T, mi, kw, seed = case[:7]
+        LpTp = case[7] if len(case) > 7 else None
         args = W.lm_args_tiny(**cfg)
         m, sd = _ref_model(ssr, args, seed=seed)
         g = torch.Generator().manual_seed(seed)
         x = torch.randint(0, args.text_vocab_size, (1, L), generator=g)
         y = torch.randint(0, args.audio_vocab_size, (1, T, args.n_codebooks), generator=g)
+        if LpTp is not None:
+            prompt_x = torch.randint(0, args.text_vocab_size, (1, LpTp[0]), generator=g)
+            prompt = torch.randint(0, args.audio_vocab_size, (1, LpTp[1], args.n_codebooks), generator=g)
+        else:
+            prompt_x, prompt = x, y
         if "sample" in name:  # make silence tokens reachable in the tiny vocab
             kw = dict(kw, silence_tokens=[3, 7, 11])
         mask_interval = torch.LongTensor([mi])
@@ -78,21 +98,23 @@ def make_lm():
         ssr.topk_sampling = spy
         try:
             torch.manual_seed(seed)
-            if kw.get("aug_text"):
+            ctx_on = bool(kw.get("aug_context")) and sum(b - a for a, b in mi) < 100
+            if kw.get("aug_text") and not kw.get("cfg_pretrained"):
                 st = torch.get_rng_state()
-                uncond = torch.randint(0, args.text_vocab_size + 1, (1, L))
+                uncond = torch.randint(0, args.text_vocab_size + 1, (1, L + (prompt_x.shape[1] if ctx_on else 0)))
                 torch.set_rng_state(st)
             else:
                 uncond = torch.zeros(1, 0, dtype=torch.long)
             with torch.no_grad():
-                res, marks, masks, nmi = m.inference(x, torch.LongTensor([L]), x, torch.LongTensor([L]), y, y, mask_interval, **kw)
+                res, marks, masks, nmi = m.inference(x, torch.LongTensor([L]), prompt_x, torch.LongTensor([prompt_x.shape[1]]), y, prompt,
+                                                     mask_interval, **kw)
         finally:
             ssr.topk_sampling = orig
         kwn = {f"kw_{k}": np.asarray(v) for k, v in kw.items()}
         out[name] = dict(
             cfg=np.asarray([getattr(args, k) for k in ("d_model", "nhead", "num_decoder_layers", "audio_vocab_size")]),
             weight_seed=np.asarray(seed), torch_seed=np.asarray(seed), x=x.numpy(), y=y.numpy(), mask_interval=mask_interval.numpy(),
-            uncond_x=uncond.numpy(), res=res.numpy(), marks=marks.numpy(), masks=np.asarray(masks), non_mask_intervals=np.asarray(nmi),
+            prompt_x=prompt_x.numpy(), prompt=prompt.numpy(), uncond_x=uncond.numpy(), res=res.numpy(), marks=marks.numpy(), masks=np.asarray(masks), non_mask_intervals=np.asarray(nmi),
             step_logits=torch.stack(rec["logits"]).numpy(), step_samples=torch.stack(rec["samples"]).numpy(),
             step_noise=torch.stack(rec["noise"]).numpy(), torch_version=np.asarray(torch.__version__), **kwn)
         print(f"  lm/{name}: res {tuple(res.shape)} steps {len(rec['logits'])}")
@@ -173,6 +195,8 @@ if __name__ == "__main__":
         make_sampler()
     if "lm" in which:
         make_lm()
+    if "lm_ctx" in which or "lm" in which:
+        make_lm(LM_CTX_CASES)
     if "codec" in which:
         from oracle import make_golden_codec
         make_golden_codec.main(GOLD)

@@ -157,21 +157,36 @@ class SSR_Speech(nn.Module):
         assert y.shape[0] == 1 and y.shape[1] == K, y.shape
         assert prompt.shape[0] == 1 and prompt.shape[1] == K, prompt.shape
         assert mask_interval.shape == torch.Size((1, mask_interval.shape[1], 2)), mask_interval
-        if aug_context or cfg_pretrained:
-            # models/ssr.py:563-594: not reachable from inference_scale.py; SURVEY §8f N3 ("next" row)
-            raise NotImplementedError("aug_context / cfg_pretrained are not implemented in ssr_speech_amd yet")
+        # ssr.py:563-568: the context is prepended only when the masked spans are short (< 2 s at 50 Hz)
+        context_len = int(sum(int(item[1] - item[0]) for item in mask_interval[0]))
+        aug_context = bool(aug_context and context_len < 2 * 50)
 
         dev = self.device
         x_np = x.detach().cpu().numpy().astype(np.int64)
+        y_np = y[0].detach().cpu().numpy().astype(np.int64)
+        mi = mask_interval[0].detach().cpu().numpy().astype(np.int64)
+        out_len = 0
+        if aug_context:
+            # ssr.py:578-594, 607-608: [prompt text ‖ text], [prompt codes ‖ codes], spans shifted by the prompt length
+            assert prompt_x.ndim == 2, prompt_x.shape
+            out_len = int(prompt.shape[2])
+            x_np = np.concatenate([prompt_x.detach().cpu().numpy().astype(np.int64), x_np], axis=1)
+            y_np = np.concatenate([prompt[0].detach().cpu().numpy().astype(np.int64), y_np], axis=1)
+            mi = mi + out_len
         L = x_np.shape[1]
         text_rows = [x_np[0]]
         if aug_text:
-            if uncond_x is None:
-                # drawn from the global CPU generator, before any sampling draw — exactly ssr.py:574
-                uncond_x = torch.randint(0, self.n_text_tokens, (1, L))
-            text_rows.append(uncond_x.detach().cpu().numpy().astype(np.int64)[0])
-        y_np = y[0].detach().cpu().numpy().astype(np.int64)
-        mi = mask_interval[0].detach().cpu().numpy().astype(np.int64)
+            if cfg_pretrained:
+                # ssr.py:576/587 + :631-634: the unconditional row is `text_vocab_size-1` repeated L times with text keys 1..L-1
+                # padded out for every query. Those positions are then attended by nothing and their own outputs are dropped
+                # (:275-276), and text / audio positions are embedded independently (:599-600, :662), so the row is exactly
+                # the length-1 text [text_vocab_size-1] — the engine's rows carry their own text length.
+                text_rows.append(np.asarray([int(self.args.text_vocab_size) - 1], dtype=np.int64))
+            else:
+                if uncond_x is None:
+                    # drawn from the global CPU generator, before any sampling draw — exactly ssr.py:574/585
+                    uncond_x = torch.randint(0, self.n_text_tokens, (1, L))
+                text_rows.append(uncond_x.detach().cpu().numpy().astype(np.int64)[0])
         cated, mask_position, num_task, nmi = LY.build_layout(y_np, mi, self.args)
         T0 = cated.shape[1]
         # upper bound on steps: every span stops at the latest when y_len > 10*L (ssr.py:739) + K eog steps
@@ -208,8 +223,12 @@ class SSR_Speech(nn.Module):
         ends = [0] + [st.span_end[i] for i in range(num_task)]
         spans = [gen[ends[i]:ends[i + 1]] for i in range(num_task)]
         res, marks, masks, nmi_out = LY.assemble(y_np, spans, nmi, self.args)
-        res_t = torch.from_numpy(res).unsqueeze(0).to(dev)
-        marks_t = torch.from_numpy(marks).unsqueeze(0)          # CPU tensor, as the reference (ssr.py:805)
+        if aug_context:                                         # ssr.py:806-810
+            res, marks = res[:, out_len:], marks[out_len:]
+            masks = [(a - out_len, b - out_len) for a, b in masks]
+            nmi_out = [(a - out_len, b - out_len) for a, b in nmi_out]
+        res_t = torch.from_numpy(np.ascontiguousarray(res)).unsqueeze(0).to(dev)
+        marks_t = torch.from_numpy(np.ascontiguousarray(marks)).unsqueeze(0)          # CPU tensor, as the reference (ssr.py:805)
         logging.info(f"ssr_speech_amd: generated {st.n_steps} steps")
         return res_t, marks_t, masks, nmi_out
 

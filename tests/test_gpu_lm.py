@@ -46,11 +46,14 @@ def test_inference_tokens_match_reference(golden_dir, name):
     x = torch.from_numpy(g["x"]).cuda()
     y = torch.from_numpy(g["y"]).cuda()
     extra = {}
-    if kw.get("aug_text"):
+    if kw.get("aug_text") and not kw.get("cfg_pretrained"):
         extra["uncond_x"] = torch.from_numpy(g["uncond_x"])
     if "sample" in name:
         extra["noise"] = torch.from_numpy(g["step_noise"])
-    res, marks, masks, nmi = m.inference(x, torch.LongTensor([L]).cuda(), x, torch.LongTensor([L]).cuda(), y, y,
+    # aug_context / cfg_pretrained cases carry a separate prompt; the older ones passed x / y twice
+    px = torch.from_numpy(g["prompt_x"]).cuda() if "prompt_x" in g.files else x
+    py = torch.from_numpy(g["prompt"]).cuda() if "prompt" in g.files else y
+    res, marks, masks, nmi = m.inference(x, torch.LongTensor([L]).cuda(), px, torch.LongTensor([px.shape[1]]).cuda(), y, py,
                                          torch.from_numpy(g["mask_interval"]).cuda(), **kw, **extra)
     assert res.dtype == torch.int64 and res.device.type == "cuda" and marks.device.type == "cpu"
     assert m.last_run["steps"] == g["step_samples"].shape[0]
@@ -60,7 +63,7 @@ def test_inference_tokens_match_reference(golden_dir, name):
     assert np.array_equal(np.asarray(nmi), g["non_mask_intervals"])
 
 
-@pytest.mark.parametrize("name", ["tts_greedy_cfg5", "edit_2span_greedy", "tts_greedy_hd128", "tts_sample_topp_temp"])
+@pytest.mark.parametrize("name", ["tts_greedy_cfg5", "edit_2span_greedy", "tts_greedy_hd128", "tts_sample_topp_temp", "cfgpre_tts_greedy"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_per_step_logits_match_reference(golden_dir, name, use_graph):
     """Step the engine one decode step at a time and compare the logits it hands to the sampler
@@ -74,7 +77,10 @@ def test_per_step_logits_match_reference(golden_dir, name, use_graph):
     eng = DecodeEngine(arena, 1, bool(kw["aug_text"]), 1024, 256, debug_logits=True)
     y = g["y"][0].T
     cated, mp, num_task, nmi = LY.build_layout(y, g["mask_interval"][0], args)
-    rows = [g["x"][0]] + ([g["uncond_x"][0]] if kw["aug_text"] else [])
+    if kw.get("cfg_pretrained"):      # ssr.py:576,631-634 == an unconditional row whose text is the single id text_vocab_size-1
+        rows = [g["x"][0], np.asarray([args.text_vocab_size - 1])]
+    else:
+        rows = [g["x"][0]] + ([g["uncond_x"][0]] if kw["aug_text"] else [])
     kn = DecodeKnobs(top_k=kw["top_k"], top_p=kw["top_p"], temperature=kw["temperature"], stop_repetition=kw["stop_repetition"],
                      silence_tokens=tuple(kw.get("silence_tokens", (1388, 1898, 131))), cfg_coef=kw["cfg_coef"], cfg_stride=kw["cfg_stride"],
                      use_cfg=bool(kw["aug_text"]), text_len=g["x"].shape[1], n_spans=num_task)
