@@ -77,6 +77,86 @@ def test_gemv_grouped_heads(L):
     torch.testing.assert_close(dy.cpu(), ref, rtol=2e-5, atol=2e-5)
 
 
+# ------------------------------------------------------------------------------------------ GEMV, 5..16 rows (MFMA path)
+@pytest.mark.parametrize("B", [5, 8, 16])
+@pytest.mark.parametrize("N,K", [(512, 2048), (96, 8192), (100, 1024), (77, 128), (2056, 1024), (130, 4096), (48, 16)])
+@pytest.mark.parametrize("pro,act,epi", [(0, 0, 0), (1, 1, 0), (1, 2, 0), (0, 0, 1)])
+def test_gemv_mfma_rows_matches_torch(L, B, N, K, pro, act, epi):
+    """B > 4 rows go to gemv_mfma.hip (v_mfma_f32_16x16x4_f32); LayerNorm gamma/beta must be folded by the caller."""
+    if pro == 1 and K > 4096:
+        pytest.skip("LayerNorm prologue is only used with K = d_model")
+    g = torch.Generator().manual_seed(B * 1000 + N + K + pro + act + epi)
+    Wt = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    x = torch.randn(B, K, generator=g) * 1.5 + 0.3
+    lw, lb = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    y0 = torch.randn(B, N, generator=g)
+    xin = F.layer_norm(x, (K,), lw, lb, 1e-5) if pro == 1 else x
+    ref = F.linear(xin, Wt, bias)
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    ref = y0 + ref if epi == 1 else ref
+    if pro == 1:      # what LMWeightsArena does at load time
+        Wf = (Wt.double() * lw.double()[None, :]).float()
+        bf = (bias.double() + Wt.double() @ lb.double()).float()
+    else:
+        Wf, bf = Wt, bias
+    dW, db, dx, dy = dev(Wf), dev(bf), dev(x), dev(y0.clone())
+    a = _lib.GemvArgs()
+    a.W, a.bias, a.x, a.y = dW.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr()
+    a.B, a.N, a.K, a.groups, a.x_stride, a.y_stride = B, N, K, 1, K, N
+    a.pro, a.act, a.epi = pro, act, epi
+    a.ln_eps = 1e-5
+    _lib.check(L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()))
+    sync()
+    torch.testing.assert_close(dy.cpu(), ref, rtol=3e-5, atol=3e-5)
+
+
+def test_gemv_mfma_grouped_heads_and_qkv_append(L):
+    g = torch.Generator().manual_seed(4)
+    G, B, N, K = 4, 11, 72, 1024
+    Wt = torch.randn(G, N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(G, N, generator=g)
+    x = torch.randn(B, G, K, generator=g)
+    ref = torch.stack([F.linear(x[:, k], Wt[k], bias[k]) for k in range(G)], 1)
+    dW, db, dx = dev(Wt), dev(bias), dev(x)
+    dy = torch.zeros(B, G, N, device="cuda")
+    a = _lib.GemvArgs()
+    a.W, a.bias, a.x, a.y = dW.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr()
+    a.B, a.N, a.K, a.groups, a.x_stride, a.y_stride = B, N, K, G, G * K, G * N
+    _lib.check(L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()))
+    sync()
+    torch.testing.assert_close(dy.cpu(), ref, rtol=3e-5, atol=3e-5)
+    # QKV append, 16 rows at different cache positions
+    B, D, H, hd, n_layer, max_pages, layer = 16, 256, 4, 64, 2, 3, 1
+    pool, table = _make_cache(B, max_pages, n_layer, H, hd, g)
+    Wt = torch.randn(3 * D, D, generator=g) / math.sqrt(D)
+    bias = torch.randn(3 * D, generator=g)
+    x = torch.randn(B, D, generator=g)
+    pos = torch.randint(0, max_pages * _lib.PAGE, (B,), generator=g).to(torch.int32)
+    ref = F.linear(F.layer_norm(x, (D,), None, None, 1e-5), Wt, bias)
+    dpool, dtable, dW, db, dx, dpos = dev(pool), dev(table), dev(Wt), dev(bias), dev(x), dev(pos)
+    dq = torch.zeros(B, D, device="cuda")
+    a = _lib.GemvArgs()
+    a.W, a.bias, a.x, a.y = dW.data_ptr(), db.data_ptr(), dx.data_ptr(), dq.data_ptr()
+    a.B, a.N, a.K, a.groups, a.x_stride, a.y_stride = B, 3 * D, D, 1, D, D
+    a.pro, a.act, a.epi, a.ln_eps = _lib.PRO_LAYERNORM, 0, _lib.EPI_QKV_APPEND, 1e-5
+    a.kv = _lib.KV(dpool.data_ptr(), dtable.data_ptr(), max_pages, n_layer, H, hd)
+    a.layer, a.kv_pos = layer, dpos.data_ptr()
+    _lib.check(L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()))
+    sync()
+    torch.testing.assert_close(dq.cpu(), ref[:, :D], rtol=3e-5, atol=3e-5)
+    newpool = dpool.cpu()
+    mask = torch.ones_like(pool, dtype=torch.bool)
+    for b in range(B):
+        p = int(pos[b])
+        page = int(table[b, p // _lib.PAGE])
+        for which in (0, 1):
+            got = newpool[page, layer, which, :, p % _lib.PAGE, :].reshape(-1)
+            torch.testing.assert_close(got, ref[b, (1 + which) * D:(2 + which) * D], rtol=3e-5, atol=3e-5)
+        mask[page, layer, :, :, p % _lib.PAGE, :] = False
+    assert torch.equal(newpool[mask], pool[mask])
+
+
 # ------------------------------------------------------------------------------------------ attention
 def _make_cache(n_seq, max_pages, n_layer, H, hd, g):
     n_pages = n_seq * max_pages

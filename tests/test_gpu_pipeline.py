@@ -70,3 +70,42 @@ def test_inference_one_sample_matches_oracle(tmp_path, tts, use_watermark):
         ref_wav = ref_wav[:, :, masks[0][1] * 320:]
     assert out.shape == ref_wav.shape
     np.testing.assert_allclose(out.cpu().numpy(), ref_wav.numpy(), rtol=0, atol=5e-4)
+
+
+def test_encode_driver_writes_reference_format(tmp_path, monkeypatch):
+    """SURVEY §8f N2 (`data/encode.py`): ragged clips, zero-padded batches, one K-line txt per segment truncated to
+    round(duration*50) frames; codes equal the oracle's encode of the same padded batch; WORLD_SIZE=2 shards are disjoint."""
+    import json
+    from ssr_speech_amd.data import encode as ENC
+    ccfg = W.CodecConfig(dimension=64, n_filters=8, ratios=(8, 5, 4, 2), bins=64)
+    csd = W.codec_state_dict(ccfg, seed=11)
+    ckpt = str(tmp_path / "codec.th")
+    torch.save({"codec_config": {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(ccfg).items()}, "model": csd}, ckpt)
+    g = torch.Generator().manual_seed(2)
+    lens = [4000, 6400, 5123, 3200, 7777]
+    items = []
+    for i, n in enumerate(lens):
+        fn = str(tmp_path / f"clip{i}.wav")
+        write_wav(fn, torch.randn(1, n, generator=g) * 0.2, 16000)
+        items.append({"segment_id": f"seg{i}", "wav": fn})
+    man = str(tmp_path / "manifest.json")
+    json.dump(items, open(man, "w"))
+    argv = ["--json_path", man, "--save_dir", str(tmp_path / "out"), "--dataset_name", "ds", "--encodec_model_path", ckpt, "--batch_size", "2"]
+    for rank in (0, 1):
+        monkeypatch.setenv("RANK", str(rank))
+        monkeypatch.setenv("WORLD_SIZE", "2")
+        monkeypatch.setenv("LOCAL_RANK", "0")
+        assert ENC.main(argv) == 0
+        n_files = len(os.listdir(tmp_path / "out" / "ds" / "wmencodec"))
+        assert n_files == (3 if rank == 0 else 5)                       # rank 0: items 0..2, rank 1: items 3..4
+    # oracle on the same zero-padded batches (rank 0: [0,1],[2]; rank 1: [3,4])
+    for batch in ([0, 1], [2], [3, 4]):
+        clips = [ENC.load_clip(items[i]["wav"], 16000)[0] for i in batch]
+        ref_codes, _, _ = OC.encode(csd, ENC.pad_batch(clips), ccfg)
+        for j, i in enumerate(batch):
+            got = ENC.read_codes_txt(str(tmp_path / "out" / "ds" / "wmencodec" / f"seg{i}.txt"))
+            T = round(lens[i] / 16000 * 50)
+            assert got.shape == (4, T), (i, got.shape)
+            assert (got != ref_codes[j, :, :T].numpy()).mean() < 0.02, i      # fp near-ties aside (same bar as above)
+    raw = open(tmp_path / "out" / "ds" / "wmencodec" / "seg0.txt").read()
+    assert raw.count("\n") == 3 and not raw.endswith("\n")

@@ -69,3 +69,24 @@ def test_codec_config_from_duck_typed_cfg():
     assert c.ratios == (8, 5, 4, 2) and c.pad_mode == "reflect" and c.hop == 320 and c.frame_rate == 50
     with pytest.raises(KeyError):
         TK.codec_config_from_xp_cfg({"compression_model": "encodec"})
+
+
+def test_encode_driver_flags_and_txt_format(golden_dir, tmp_path):
+    """`data/encode.py` flag surface (reference :5-19) and its on-disk code format (:53-57, :103-108)."""
+    from ssr_speech_amd.data import encode as ENC
+    ref = json.load(open(os.path.join(golden_dir, "encode_flags.json")))
+    a = ENC.parse_args([])
+    assert sorted(vars(a)) == sorted(r["flag"][2:] for r in ref)
+    for r in ref:
+        assert str(getattr(a, r["flag"][2:])) == r["default"], r
+        assert type(getattr(ENC.parse_args([r["flag"], "7"]), r["flag"][2:])).__name__ == r["type"], r
+    codes = [[1, 22, 333], [4, 5, 6], [7, 8, 9], [2047, 0, 1]]
+    fn = str(tmp_path / "seg.txt")
+    ENC.write_array_to_txt_file(codes, fn)
+    assert open(fn).read() == "1 22 333\n4 5 6\n7 8 9\n2047 0 1"          # K lines, no trailing newline
+    assert np.array_equal(ENC.read_codes_txt(fn), np.asarray(codes))
+    b = ENC.pad_batch([torch.ones(5), torch.ones(9) * 2, torch.ones(1) * 3])
+    assert b.shape == (3, 1, 9) and b[0, 0, 5:].abs().sum() == 0 and b[1].sum() == 18 and b[2, 0, 0] == 3
+    TK.write_wav(str(tmp_path / "c.wav"), torch.zeros(1, 1234), 16000)
+    clip, dur = ENC.load_clip(str(tmp_path / "c.wav"), 16000)
+    assert clip.shape == (1234,) and dur == 1234 / 16000 and round(dur * 50) == 4
