@@ -15,6 +15,7 @@ Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the weight-stre
 `cpu_baseline` (the oracle = CPU restatement of the reference, timed on this box's host cores, bounded sample).
 """
 import argparse
+import dataclasses
 import json
 import os
 import sys
@@ -86,6 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--utts", type=int, default=1, help="utterances decoded in lock-step per GPU (default 1 = the headline configuration)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,13 +116,18 @@ def main():
     cated, _, num_task, _ = LY.build_layout(y[0].T.numpy(), np.asarray([[N, N]]), args_lm)
     T0 = cated.shape[1]
     assert T0 + 1 + total <= 10 * L, "bench would hit the reference's length cap (10*L): lower --steps"
-    eng = DecodeEngine(arena, 1, True, ((L + T0 + total + 8 + 1023) // 1024) * 1024, ((total + 255) // 256) * 256)
+    U = a.utts          # utterances decoded in lock-step on this GPU (1 = the headline configuration; 8 = SURVEY §8d config 4)
+    eng = DecodeEngine(arena, U, True, ((L + T0 + total + 8 + 1023) // 1024) * 1024, ((total + 255) // 256) * 256)
     kn = DecodeKnobs(top_k=40, top_p=0.8, temperature=1.0, stop_repetition=2, cfg_coef=1.5, cfg_stride=5, use_cfg=True,
                      text_len=L, n_spans=num_task, seed=2024 + rank)
+    text_rows = []
+    for u in range(U):          # utterance u > 0: same shapes, its own text ids
+        xu, _, uu = (x, y, unc) if u == 0 else synth_inputs(args_lm, rank * 64 + u)
+        text_rows += [xu[0].numpy(), uu[0].numpy()]
     seed_try = 0
     while True:
-        kn.seed = 2024 + rank + 1000 * seed_try
-        eng.start([x[0].numpy(), unc[0].numpy()], [cated], [kn], noise=None)
+        kns = [dataclasses.replace(kn, seed=2024 + rank * 64 + u + 1000 * seed_try) for u in range(U)]
+        eng.start(text_rows, [cated] * U, kns, noise=None)
         torch.cuda.synchronize()
         eng.decode(a.warmup, use_graph=not a.no_graph)
         torch.cuda.synchronize()
@@ -133,7 +140,7 @@ def main():
             dist.barrier()
         t1 = time.perf_counter()
         st = eng.states()[0]
-        if st.n_steps == total or seed_try >= 3:
+        if all(s_.n_steps == total for s_ in eng.states()) or seed_try >= 3:
             break
         seed_try += 1           # the sampler drew <eog> inside the timed region: different stream, same workload
     elapsed = t1 - t0
@@ -155,7 +162,7 @@ def main():
 
     if rank == 0:
         ms_per_step = 1000 * elapsed / a.steps
-        tokens_per_step = 4 * world                      # K=4 codebooks x 1 frame x one utterance per GPU
+        tokens_per_step = 4 * world * U                  # K=4 codebooks x 1 frame x U utterances per GPU
         value = tokens_per_step * a.steps / elapsed
         # ---- roofline of the dominant kernel (weight-streaming GEMV). Two HIP-event measurements on the launch stream:
         #  * per-slot: an event pair around every launch of eager steps (per-shape view; carries ~3 us event overhead each);
@@ -175,20 +182,22 @@ def main():
         achieved = bytes_per_launch / (gemv_us * 1e-6) / 1e9
         # per-shape view of one layer (slots 0..4 = QKV, attention, out-proj, FFN1, FFN2 of layer 0.., averaged over layers)
         nl = arena.L
-        shape_names = ["ln1+qkv", "attn", "combine+out_proj", "ln2+ffn1", "ffn2"]
-        per_shape = {shape_names[j]: round(sum(slots[l * 5 + j][1] for l in range(nl)) / nl, 3) for j in range(5)}
-        per_shape.update({"lnf+head1": round(slots[nl * 5][1], 3), "head2": round(slots[nl * 5 + 1][1], 3), "sample+embed": round(slots[nl * 5 + 2][1], 3)})
+        shape_names = ["ln1+qkv", "attn", "combine+out_proj", "ln2+ffn1", "ffn2"] if 2 * U <= 4 else \
+                      ["ln1+qkv", "attn", "combine", "out_proj", "ln2+ffn1", "ffn2"]       # > 4 rows: the combine is its own launch
+        ns = len(shape_names)
+        per_shape = {shape_names[j]: round(sum(slots[l * ns + j][1] for l in range(nl)) / nl, 3) for j in range(ns)}
+        per_shape.update({"lnf+head1": round(slots[nl * ns][1], 3), "head2": round(slots[nl * ns + 1][1], 3), "sample+embed": round(slots[nl * ns + 2][1], 3)})
         S_mid = L + T0 + a.warmup + a.steps // 2
-        kv_bytes = 262144 * 2 * S_mid * (arena.L / 16) * (arena.D / 2048)
+        kv_bytes = 262144 * 2 * U * S_mid * (arena.L / 16) * (arena.D / 2048)
         step_gbs = (arena.nbytes_per_step() + kv_bytes) / (ms_per_step * 1e-3) / 1e9
         out = {
             "metric": "codec-tokens/sec/GPU (AR decode) + RTF for 10 s TTS, English 830M",
             "value": round(value, 1), "unit": "codec-tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "English-830M-shape zero-shot TTS decode, cfg_stride=5, top_k=40/top_p=0.8 sampling, batch=1 (2 CFG rows) per GPU; "
+            "config": {"workload": f"English-830M-shape zero-shot TTS decode, cfg_stride=5, top_k=40/top_p=0.8 sampling, batch={U} ({2 * U} CFG rows) per GPU; "
                                    f"L={L} phonemes, {N}-frame prompt, context {L + T0 + a.warmup}..{L + T0 + total}",
-                       "utterances_per_gpu": 1, "rows": 2, "graph": not a.no_graph, "steps_completed": int(st.n_steps)},
+                       "utterances_per_gpu": U, "rows": 2 * U, "graph": not a.no_graph, "steps_completed": int(st.n_steps)},
             "per_gpu_value": round(value / world, 1),
             "decode_rtf_10s": round((500 * ms_per_step / 1000) / 10.0, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -206,6 +215,8 @@ def main():
         }
         # ---- RTF of a whole 10 s zero-shot TTS on this GPU: prefill + 500 decode steps + wmencodec decode of the 500 new frames
         try:
+            if U != 1:
+                raise RuntimeError("reported for --utts 1 only")
             torch.cuda.synchronize()
             p0 = time.perf_counter()
             eng.start([x[0].numpy(), unc[0].numpy()], [cated], [kn], noise=None)
@@ -228,7 +239,7 @@ def main():
             out["rtf_10s_tts"] = {"error": repr(e)}
         if allgather_ms is not None:
             out["allgather_ms"] = round(allgather_ms, 3)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and U == 1:
             out["cpu_baseline"] = cpu_baseline(args_lm, sd, x, y, unc)
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)

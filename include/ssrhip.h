@@ -75,7 +75,16 @@ typedef struct ssrhip_gemv_args {
   const int32_t* row_len;                                        /* [B] keys visible to each row */
   /* EPI_QKV_APPEND: N == 3K; q -> y, k/v -> cache at position kv_pos[b] of sequence b */
   ssrhip_kv kv; int32_t layer; const int32_t* kv_pos;
+  /* 5..16 rows only (matrix-core path): activations in the 16-column tiled layout SSRHIP_TILED(b,k) below instead of
+   * row-major [B][stride]; x_stride / y_stride are ignored for a tiled operand. QKV_APPEND's q output is always row-major. */
+  int32_t x_tiled, y_tiled;
 } ssrhip_gemv_args;
+
+/* 16-column tiled activation layout used between the kernels of the 5..16-row decode step: element (row b, feature k) of a
+ * [<=16][K] activation lives at float index ((k/4)*16 + b)*4 + k%4, i.e. 4 consecutive features of the 16 rows are 256
+ * contiguous bytes — exactly what one 64-lane MFMA B-operand load wants (a whole KiB per wave instruction). Buffer size is
+ * always 16*K floats. */
+#define SSRHIP_TILED(b, k) ((((size_t)(k) >> 2) * 16 + (size_t)(b)) * 4 + ((k) & 3))
 
 int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream);
 
@@ -95,6 +104,7 @@ typedef struct ssrhip_attn_args {
   int32_t R, max_splits;   /* max_splits >= ceil(max(row_len)/SSRHIP_PAGE) */
   float scale;             /* 1/sqrt(head_dim) */
   float* part_o; float* part_ml;
+  int32_t out_tiled;       /* ssrhip_attn_combine only: write `out` in the SSRHIP_TILED layout (R <= 16) */
 } ssrhip_attn_args;
 
 int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t stream);
@@ -116,6 +126,7 @@ typedef struct ssrhip_embed_args {
   const int32_t* kind;     /* [R] or NULL (all audio) */
   int32_t R, D, K, card;
   float* out;              /* [R][D] */
+  int32_t out_tiled;       /* write `out` in the SSRHIP_TILED layout (R <= 16) */
 } ssrhip_embed_args;
 
 int ssrhip_embed(const ssrhip_embed_args* a, ssrhip_stream_t stream);

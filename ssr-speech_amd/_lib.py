@@ -43,20 +43,22 @@ class GemvArgs(C.Structure):
                 ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("ln_eps", C.c_float),
                 ("part_o", C.c_void_p), ("part_ml", C.c_void_p), ("max_splits", C.c_int32),
                 ("row_len", C.c_void_p),
-                ("kv", KV), ("layer", C.c_int32), ("kv_pos", C.c_void_p)]
+                ("kv", KV), ("layer", C.c_int32), ("kv_pos", C.c_void_p),
+                ("x_tiled", C.c_int32), ("y_tiled", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("q_stride", C.c_int32), ("kv", KV), ("layer", C.c_int32),
                 ("row_seq", C.c_void_p), ("row_len", C.c_void_p), ("R", C.c_int32), ("max_splits", C.c_int32),
-                ("scale", C.c_float), ("part_o", C.c_void_p), ("part_ml", C.c_void_p)]
+                ("scale", C.c_float), ("part_o", C.c_void_p), ("part_ml", C.c_void_p), ("out_tiled", C.c_int32)]
 
 
 class EmbedArgs(C.Structure):
     _fields_ = [("text_emb", C.c_void_p), ("audio_emb", C.c_void_p), ("pe", C.c_void_p),
                 ("alpha_text", C.c_float), ("alpha_audio", C.c_float),
                 ("tok", C.c_void_p), ("pos", C.c_void_p), ("kind", C.c_void_p),
-                ("R", C.c_int32), ("D", C.c_int32), ("K", C.c_int32), ("card", C.c_int32), ("out", C.c_void_p)]
+                ("R", C.c_int32), ("D", C.c_int32), ("K", C.c_int32), ("card", C.c_int32), ("out", C.c_void_p),
+                ("out_tiled", C.c_int32)]
 
 
 class SamplerCfg(C.Structure):

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const ssrhip_attn_arg
       acc.w = fmaf(w, o.w, acc.w);
     }
     const float inv = 1.0f / den;
-    *reinterpret_cast<float4*>(out + (size_t)r * D + e) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    float* dst = a.out_tiled ? out + SSRHIP_TILED(r, e) : out + (size_t)r * D + e;
+    *reinterpret_cast<float4*>(dst) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
   }
 }
 
@@ -158,6 +159,7 @@ extern "C" int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t str
 extern "C" int ssrhip_attn_combine(const ssrhip_attn_args* a, float* out, ssrhip_stream_t stream) {
   if (int e = check(a, "ssrhip_attn_combine")) return e;
   SSR_REQUIRE(out, "ssrhip_attn_combine: out is null");
+  SSR_REQUIRE(!a->out_tiled || a->R <= 16, "ssrhip_attn_combine: tiled output needs R <= 16");
   if (a->kv.head_dim == 128) hipLaunchKernelGGL(attn_combine_kernel<128>, dim3(a->R), dim3(256), 0, (hipStream_t)stream, *a, out);
   else hipLaunchKernelGGL(attn_combine_kernel<64>, dim3(a->R), dim3(256), 0, (hipStream_t)stream, *a, out);
   SSR_LAUNCH_CHECK();

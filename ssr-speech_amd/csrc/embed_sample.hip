@@ -39,7 +39,8 @@ __device__ __forceinline__ void embed_row(const ssrhip_embed_args& a, int r, int
     e.y = __fadd_rn(e.y, __fmul_rn(alpha, p.y));
     e.z = __fadd_rn(e.z, __fmul_rn(alpha, p.z));
     e.w = __fadd_rn(e.w, __fmul_rn(alpha, p.w));
-    *reinterpret_cast<float4*>(a.out + (size_t)r * D + d) = e;
+    float* dst = a.out_tiled ? a.out + SSRHIP_TILED(r, d) : a.out + (size_t)r * D + d;
+    *reinterpret_cast<float4*>(dst) = e;
   }
 }
 

@@ -91,6 +91,9 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
   const ssrhip_lm_weights& w = lm->w;
   const ssrhip_lm_buffers& b = lm->b;
   const int D = d.d_model, B = b.B, K = d.n_codebooks, Hh = d.head_hidden;
+  // 5..16 rows: the residual stream x, the combined attention output and the hidden h live in the 16-column tiled layout
+  // (include/ssrhip.h SSRHIP_TILED) so that the matrix-core GEMV's operand loads are contiguous KiBs
+  const int tiled = B > 4 ? 1 : 0;
 
   if (tm) tm->slot = 0;
 
@@ -104,6 +107,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     if (!d.ln_folded) { g.ln_w = w.ln1_w[l]; g.ln_b = w.ln1_b[l]; }
     g.ln_eps = 1e-5f;
     g.kv = b.kv; g.layer = l; g.kv_pos = b.kv_pos;
+    g.x_tiled = tiled;                         // q stays row-major for the attention kernel
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
 
     ssrhip_attn_args at;
@@ -120,6 +124,12 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.pro = SSRHIP_PRO_ATTN_COMBINE; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_RESIDUAL;
     g.part_o = b.part_o; g.part_ml = b.part_ml; g.max_splits = b.max_splits; g.row_len = b.row_len;
     g.kv = b.kv;
+    if (B > 4) {
+      // 5..16 rows (matrix-core GEMV): the combine is its own small launch; q is dead after the attention, reuse it
+      at.out_tiled = 1;
+      STEP_CALL(CAT_ATTN, ssrhip_attn_combine(&at, b.q, s));
+      g.pro = SSRHIP_PRO_NONE; g.x = b.q; g.x_tiled = 1; g.y_tiled = 1;
+    }
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
 
     // LN2 + FFN1 + ReLU
@@ -129,6 +139,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.pro = SSRHIP_PRO_LAYERNORM; g.act = SSRHIP_ACT_RELU; g.epi = SSRHIP_EPI_STORE;
     if (!d.ln_folded) { g.ln_w = w.ln2_w[l]; g.ln_b = w.ln2_b[l]; }
     g.ln_eps = 1e-5f;
+    g.x_tiled = tiled; g.y_tiled = tiled;
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
 
     // FFN2 + residual
@@ -136,6 +147,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.W = w.ffn2_w[l]; g.bias = w.ffn2_b[l]; g.x = b.h; g.y = b.x;
     g.B = B; g.N = D; g.K = d.d_ffn; g.groups = 1; g.x_stride = d.d_ffn; g.y_stride = D;
     g.pro = SSRHIP_PRO_NONE; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_RESIDUAL;
+    g.x_tiled = tiled; g.y_tiled = tiled;
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
   }
   {
@@ -147,12 +159,14 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.pro = SSRHIP_PRO_LAYERNORM; g.act = SSRHIP_ACT_GELU_ERF; g.epi = SSRHIP_EPI_STORE;
     if (!d.ln_folded) { g.ln_w = w.lnf_w; g.ln_b = w.lnf_b; }
     g.ln_eps = 1e-5f;
+    g.x_tiled = tiled; g.y_tiled = tiled;
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
     // second Linear of each head: K groups
     memset(&g, 0, sizeof(g));
     g.W = w.head2_w; g.bias = w.head2_b; g.x = b.h; g.y = b.logits;
     g.B = B; g.N = d.card; g.K = Hh; g.groups = K; g.x_stride = K * Hh; g.y_stride = K * d.card;
     g.pro = SSRHIP_PRO_NONE; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_STORE;
+    g.x_tiled = tiled;                         // logits stay row-major for the sampler
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
   }
   ssrhip_sample_args sa;
@@ -164,7 +178,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
   // the sampler also embeds the tokens it chose: x of the next step (no separate embed launch)
   sa.embed.text_emb = w.text_emb; sa.embed.audio_emb = w.audio_emb; sa.embed.pe = w.pe;
   sa.embed.alpha_text = w.alpha_text; sa.embed.alpha_audio = w.alpha_audio;
-  sa.embed.R = B; sa.embed.D = D; sa.embed.K = K; sa.embed.card = d.card; sa.embed.out = b.x;
+  sa.embed.R = B; sa.embed.D = D; sa.embed.K = K; sa.embed.card = d.card; sa.embed.out = b.x; sa.embed.out_tiled = tiled;
   STEP_CALL(CAT_SAMPLE, ssrhip_sample(&sa, s));
   return 0;
 }
@@ -176,7 +190,8 @@ extern "C" int ssrhip_lm_create(const ssrhip_lm_dims* d, const ssrhip_lm_weights
   SSR_REQUIRE(d->d_model % d->n_head == 0, "ssrhip_lm_create: d_model %% n_head != 0");
   const int hd = d->d_model / d->n_head;
   SSR_REQUIRE(hd == 64 || hd == 128, "ssrhip_lm_create: head_dim %d not in {64,128}", hd);
-  SSR_REQUIRE(b->B == 1 || b->B == 2 || b->B == 4, "ssrhip_lm_create: B=%d rows not in {1,2,4}", b->B);
+  SSR_REQUIRE(b->B == 1 || b->B == 2 || b->B == 4 || (b->B >= 5 && b->B <= 16), "ssrhip_lm_create: B=%d rows not in {1,2,4,5..16}", b->B);
+  SSR_REQUIRE(b->B <= 4 || d->ln_folded, "ssrhip_lm_create: B > 4 rows needs LayerNorm gamma/beta folded into the weights (ln_folded)");
   SSR_REQUIRE(d->n_codebooks <= SSRHIP_MAX_CODEBOOKS, "ssrhip_lm_create: too many codebooks");
   ssrhip_lm* lm = new ssrhip_lm();
   lm->d = *d; lm->w = *w; lm->b = *b;
@@ -335,6 +350,6 @@ extern "C" int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ss
   ea.text_emb = w.text_emb; ea.audio_emb = w.audio_emb; ea.pe = w.pe;
   ea.alpha_text = w.alpha_text; ea.alpha_audio = w.alpha_audio;
   ea.tok = b.next_tok; ea.pos = b.next_pos; ea.kind = nullptr;
-  ea.R = b.B; ea.D = D; ea.K = d.n_codebooks; ea.card = d.card; ea.out = b.x;
+  ea.R = b.B; ea.D = D; ea.K = d.n_codebooks; ea.card = d.card; ea.out = b.x; ea.out_tiled = b.B > 4 ? 1 : 0;
   return ssrhip_embed(&ea, s);
 }

@@ -17,6 +17,7 @@
 //     holds 4 consecutive output rows of one batch column => float4 bias / residual / store / KV-append.
 // K > NW*512 (FFN2, K = 8192) loops over chunks. Rows beyond N and columns beyond B are handled by clamping the load
 // addresses (never by predication: see gemv.hip) and masking the stores.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -29,6 +30,7 @@ struct GemvM {
   int steps;    // K / 16 MFMA k-steps in total
   int nchunk;   // ceil(steps / (nw * 32))
   int hd;
+  int rows;     // weight rows per workgroup: 16, or 8 (tile rows 8..15 duplicate 0..7) when N/16 workgroups would leave CUs idle
 };
 
 constexpr int SPW = 32;   // k-steps per wave per chunk (512 floats of K)
@@ -49,13 +51,15 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(const GemvM p) {
   const ssrhip_gemv_args& a = p.a;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, ks = lane >> 4;
-  const int grp = blockIdx.y, row0 = blockIdx.x * 16;
+  const int grp = blockIdx.y, row0 = blockIdx.x * p.rows;
   const int N = a.N, K = a.K, B = a.B;
   const int last = p.steps - 1;
   const float* wbase = a.W + (size_t)grp * N * K;                      // uniform
-  const float* xbase = a.x + (size_t)grp * K;
-  const unsigned wvoff = (unsigned)min(row0 + c, N - 1) * (unsigned)K + ks * 4;
-  const unsigned xvoff = (unsigned)min(c, B - 1) * (unsigned)a.x_stride + ks * 4;
+  const unsigned wvoff = (unsigned)min(row0 + (c & (p.rows - 1)), N - 1) * (unsigned)K + ks * 4;
+  // row-major x: 16 rows x 64 B per wave instruction; tiled x (SSRHIP_TILED): one contiguous KiB per wave instruction
+  const float* xbase = a.x_tiled ? a.x + (size_t)grp * K * 16 : a.x + (size_t)grp * K;
+  const unsigned xvoff = a.x_tiled ? (unsigned)(ks * 16 + c) * 4 : (unsigned)min(c, B - 1) * (unsigned)a.x_stride + ks * 4;
+  const int xstep = a.x_tiled ? 256 : 16;      // floats per k-step
 
   f4v acc = {0.f, 0.f, 0.f, 0.f};
   for (int chunk = 0; chunk < p.nchunk; ++chunk) {
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(const GemvM p) {
     float4 w[DEPTH];
     float4 xr[SPW];
 #pragma unroll
-    for (int t = 0; t < SPW; ++t) xr[t] = ld4(xbase + min(tbase + t, last) * 16 + xvoff);
+    for (int t = 0; t < SPW; ++t) xr[t] = ld4(xbase + min(tbase + t, last) * xstep + xvoff);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) w[i] = ld_nt(wbase + min(tbase + i, last) * 16 + wvoff);
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(const GemvM p) {
 
   // epilogue: this lane holds rows r0..r0+3 of batch column c
   const int r0 = row0 + ks * 4;
-  if (c >= B || r0 >= N) return;
+  if (c >= B || r0 >= N || ks * 4 >= p.rows) return;
   float v[4] = {acc[0], acc[1], acc[2], acc[3]};
   const int nvalid = min(4, N - r0);
 #pragma unroll
@@ -154,6 +158,8 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(const GemvM p) {
     const int D = K, which = r0 / D, cc = r0 % D;
     if (which == 0) dst = a.y + (size_t)c * a.y_stride + cc;
     else dst = kv_addr(a.kv, c, a.layer, which - 1, cc / p.hd, a.kv_pos[c]) + (cc % p.hd);
+  } else if (a.y_tiled) {
+    dst = a.y + (size_t)grp * N * 16 + SSRHIP_TILED(c, r0);
   } else {
     dst = a.y + (size_t)c * a.y_stride + (size_t)grp * N + r0;
   }
@@ -180,6 +186,7 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s) {
   SSR_REQUIRE(a->pro == SSRHIP_PRO_NONE || a->pro == SSRHIP_PRO_LAYERNORM,
               "ssrhip_gemv (B>4): the split-KV combine prologue is not fused; run ssrhip_attn_combine first");
   SSR_REQUIRE(a->x, "ssrhip_gemv: x is null");
+  SSR_REQUIRE(!a->y_tiled || (a->N % 4 == 0 && a->epi != SSRHIP_EPI_QKV_APPEND), "ssrhip_gemv: tiled y needs N %% 4 == 0 and is not available for the q output");
   GemvM p;
   p.a = *a;
   p.steps = a->K / 16;
@@ -195,7 +202,12 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s) {
     SSR_REQUIRE(a->N == 3 * a->K && a->groups == 1 && a->kv.pool && a->kv.table && a->kv_pos && a->kv.head_dim > 0 && a->kv.head_dim % 4 == 0,
                 "ssrhip_gemv: QKV epilogue needs N==3K and a kv cache");
   }
-  dim3 grid((a->N + 15) / 16, a->groups);
+  // 16-row tiles unless that gives fewer workgroups than CUs (out-proj, FFN2: N/16 = 128) — then 8-row tiles: the duplicate
+  // tile rows cost MFMA cycles (not the bound) but no HBM bytes. Measured (tools/gemvm_bench): out-proj 8.7 -> 7.6 us,
+  // FFN2 31 -> 26 us; for N/16 >= 256 the 16-row tile is faster (QKV 17 vs 21 us).
+  p.rows = (a->N / 16) * a->groups >= 256 ? 16 : 8;
+  if (const char* e = getenv("SSRHIP_GEMVM_ROWS")) { const int v = atoi(e); if (v == 8 || v == 16) p.rows = v; }   // tuning knob
+  dim3 grid((a->N + p.rows - 1) / p.rows, a->groups);
   if (a->pro == SSRHIP_PRO_LAYERNORM) hipLaunchKernelGGL((gemv_mfma_kernel<SSRHIP_PRO_LAYERNORM>), grid, dim3(p.nw * 64), 0, s, p);
   else hipLaunchKernelGGL((gemv_mfma_kernel<SSRHIP_PRO_NONE>), grid, dim3(p.nw * 64), 0, s, p);
   SSR_LAUNCH_CHECK();

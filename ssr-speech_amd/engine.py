@@ -126,6 +126,9 @@ class LMWeightsArena:
         return _lib.LMDims(self.D, self.H, self.L, self.F, self.K, self.card, self.Hh, self.n_text, self.max_pos, int(self.ln_folded))
 
 
+MAX_ROWS = 16   # gemv_mfma.hip: one 16-column MFMA tile
+
+
 class DecodeEngine:
     """B rows (= n_utt x (2 if CFG else 1)) decoded in lock-step; one captured hipGraph per engine."""
 
@@ -138,8 +141,8 @@ class DecodeEngine:
         self.use_cfg = use_cfg
         self.rows_per_utt = 2 if use_cfg else 1
         self.B = n_utt * self.rows_per_utt
-        if self.B not in (1, 2, 4):
-            raise ValueError(f"rows B={self.B} not supported by this build (1, 2 or 4)")
+        if self.B not in (1, 2, 4) and not (5 <= self.B <= MAX_ROWS):
+            raise ValueError(f"rows B={self.B} not supported by this build (1, 2, 4 or 5..{MAX_ROWS})")
         self.max_pages = (max_seq + PAGE - 1) // PAGE
         self.max_seq = self.max_pages * PAGE
         self.max_steps = max_steps
@@ -150,9 +153,10 @@ class DecodeEngine:
         n_pages = self.B * self.max_pages
         self.kv_pool = torch.empty(n_pages * L * 2 * H * PAGE * self.hd, **f32)
         self.page_table = torch.arange(n_pages, **i32).view(self.B, self.max_pages).contiguous()
-        self.x = torch.zeros(self.B, D, **f32)
-        self.q = torch.zeros(self.B, D, **f32)
-        self.h = torch.zeros(self.B, max(arena.F, K * arena.Hh), **f32)
+        rows = self.B if self.B <= 4 else MAX_ROWS      # > 4 rows: x / q / h are 16-column tiled buffers (include/ssrhip.h SSRHIP_TILED)
+        self.x = torch.zeros(rows, D, **f32)
+        self.q = torch.zeros(rows, D, **f32)
+        self.h = torch.zeros(rows, max(arena.F, K * arena.Hh), **f32)
         self.logits = torch.zeros(self.B, K, arena.card, **f32)
         self.part_o = torch.zeros(self.B * H * self.max_pages * self.hd, **f32)
         self.part_ml = torch.zeros(self.B * H * self.max_pages * 2, **f32)

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import layout as LY
-from ..engine import DecodeEngine, DecodeKnobs, LMWeightsArena
+from ..engine import MAX_ROWS, DecodeEngine, DecodeKnobs, LMWeightsArena
 from ..weights import lm_param_specs
 
 
@@ -249,15 +249,15 @@ class SSR_Speech(nn.Module):
         assert cfg_coef >= 1.0, cfg_coef
         rows = 2 if aug_text else 1
         if group is None:
-            group = 4 // rows                      # rows per engine are limited to 4 in this build
-        assert group * rows in (1, 2, 4), (group, rows)
+            group = MAX_ROWS // rows               # 16 rows per engine pass: 8 utterances with CFG
+        assert 1 <= group * rows <= MAX_ROWS, (group, rows)
         dev = self.device
         results = [None] * len(utterances)
         greedy = top_k == 1
         for g0 in range(0, len(utterances), group):
             chunk = utterances[g0: g0 + group]
             n_u = len(chunk)
-            while n_u * rows not in (1, 2, 4):     # e.g. 3 utterances x 1 row: pad the group with a copy of the last one
+            while n_u * rows == 3:                 # 3 rows is the one unsupported count: pad the group with a copy of the last one
                 chunk = chunk + [chunk[-1]]
                 n_u += 1
             text_rows, audio_cols, knobs, metas, noises = [], [], [], [], []

@@ -111,6 +111,47 @@ def test_gemv_mfma_rows_matches_torch(L, B, N, K, pro, act, epi):
     torch.testing.assert_close(dy.cpu(), ref, rtol=3e-5, atol=3e-5)
 
 
+def _to_tiled(t):
+    """[B<=16, K] -> the 16-column tiled layout of include/ssrhip.h (SSRHIP_TILED): [K/4][16][4]."""
+    B, K = t.shape
+    out = torch.zeros(K // 4, 16, 4)
+    out[:, :B, :] = t.view(B, K // 4, 4).permute(1, 0, 2)
+    return out.contiguous()
+
+
+def _from_tiled(t, B, K):
+    return t.view(K // 4, 16, 4)[:, :B, :].permute(1, 0, 2).reshape(B, K)
+
+
+@pytest.mark.parametrize("B", [6, 16])
+@pytest.mark.parametrize("G,N,K,pro,act,epi", [(1, 512, 2048, 1, 1, 0), (1, 2048, 8192, 0, 0, 1), (4, 72, 1024, 0, 0, 0), (1, 4096, 2048, 1, 2, 0)])
+def test_gemv_mfma_tiled_activations(L, B, G, N, K, pro, act, epi):
+    """x and/or y in the tiled layout the 5..16-row decode step keeps its activations in."""
+    g = torch.Generator().manual_seed(B + N + K)
+    Wt = torch.randn(G, N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(G, N, generator=g)
+    x = torch.randn(B, G, K, generator=g) * 1.2 + 0.2
+    y0 = torch.randn(B, G, N, generator=g)
+    xin = F.layer_norm(x, (K,), None, None, 1e-5) if pro == 1 else x
+    ref = torch.stack([F.linear(xin[:, k], Wt[k], bias[k]) for k in range(G)], 1)
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    ref = y0 + ref if epi == 1 else ref
+    dW, db = dev(Wt), dev(bias)
+    dx = dev(_to_tiled(x.reshape(B, G * K)))
+    dy = dev(_to_tiled(y0.reshape(B, G * N)))
+    a = _lib.GemvArgs()
+    a.W, a.bias, a.x, a.y = dW.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr()
+    a.B, a.N, a.K, a.groups, a.x_stride, a.y_stride = B, N, K, G, 0, 0
+    a.pro, a.act, a.epi, a.ln_eps = pro, act, epi, 1e-5
+    a.x_tiled, a.y_tiled = 1, 1
+    _lib.check(L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()))
+    sync()
+    got = _from_tiled(dy.cpu(), B, G * N).reshape(B, G, N)
+    torch.testing.assert_close(got, ref, rtol=3e-5, atol=3e-5)
+    a.B = 4
+    assert L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()) != 0       # tiled operands are a 5..16-row feature
+
+
 def test_gemv_mfma_grouped_heads_and_qkv_append(L):
     g = torch.Generator().manual_seed(4)
     G, B, N, K = 4, 11, 72, 1024

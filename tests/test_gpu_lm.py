@@ -164,15 +164,17 @@ def test_full_830m_greedy_steps_match_oracle_on_cpu():
     assert err < 5e-4
 
 
+@pytest.mark.parametrize("n_utt", [3, 8])
 @pytest.mark.parametrize("aug_text,greedy", [(True, True), (False, True), (True, False), (False, False)])
-def test_inference_batch_rows_equal_batch1_runs(aug_text, greedy):
+def test_inference_batch_rows_equal_batch1_runs(aug_text, greedy, n_utt):
     """New capability (the reference is batch-1 only): utterances of DIFFERENT text / prompt lengths decoded in lock-step.
     Row i must equal a batch-1 `inference()` of utterance i seeded with seed+i."""
     args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
     m = _model(args, 21)
     g = torch.Generator().manual_seed(3)
     utts = []
-    for (L, T) in [(9, 14), (13, 22), (6, 10)] if not aug_text else [(9, 14), (13, 22), (6, 10)]:
+    # 3 utterances: 3 rows (padded to 4, VALU GEMV) or 6 rows (matrix-core GEMV); 8 utterances: 8 / 16 rows (SURVEY §8d config 4)
+    for (L, T) in [(9, 14), (13, 22), (6, 10), (11, 17), (7, 12), (10, 20), (12, 9), (8, 15)][:n_utt]:
         utts.append(dict(x=torch.randint(0, 30, (1, L), generator=g), y=torch.randint(0, 64, (1, T, 4), generator=g),
                          mask_interval=torch.LongTensor([[[T, T]]])))
     utts[1]["mask_interval"] = torch.LongTensor([[[5, 9]]])            # one of them is an edit, the others TTS
