@@ -99,25 +99,72 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const ssrhip_lstm_args a
   }
 }
 
-// Gate math for the large-batch path (recurrent part computed by ssrhip_gemm into a.gates [B][4C]).
-__global__ __launch_bounds__(256) void lstm_gates_kernel(const ssrhip_lstm_args a, int t, float* hnext) {
-  const int C = a.C;
-  const long total = (long)a.B * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int b = (int)(i / C), j = (int)(i % C);
-    const float* gr = a.gates + (size_t)b * 4 * C;
-    const float* gin = a.gin + (size_t)b * a.gin_bstride + (size_t)t * 4 * C;
-    const float gi = gr[j] + gin[j], gf = gr[C + j] + gin[C + j], gg = gr[2 * C + j] + gin[2 * C + j], go = gr[3 * C + j] + gin[3 * C + j];
-    float* cc = a.cbuf + (size_t)b * C + j;
-    const float cprev = (t == 0) ? 0.f : *cc;
-    const float cn = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
-    const float hn = sigmoidf_(go) * tanhf(cn);
-    *cc = cn;
-    hnext[(size_t)b * C + j] = hn;
-    float o = hn;
-    if (a.skip) o += a.skip[(size_t)b * a.skip_bstride + (size_t)t * C + j];
-    a.out[(size_t)b * a.out_bstride + (size_t)t * C + j] = o;
+// One LSTM time step for B > 4 items on the matrix core (same tile scheme as gemv_mfma.hip): a workgroup owns 4 hidden units
+// j0..j0+3 = 16 rows of W_hh (row 4u+q of the tile is gate q of unit j0+u, i.e. W_hh row q*C + j0+u — only address math, the
+// weights stay in torch's [4C][C] layout) and one tile of 16 batch columns (blockIdx.y). v_mfma_f32_16x16x4_f32 leaves lane
+// (column n, k-slot u) with rows 4u..4u+3 of column n = the i,f,g,o pre-activations of unit j0+u of item n, so the gate
+// math, the cell update and the h/out stores are lane-local: one launch per step, no [B][4C] round trip.
+// h_{t-1} is kept in the 16-column tiled layout per batch tile (include/ssrhip.h SSRHIP_TILED): contiguous operand loads.
+// W_hh (16.8 MB at C=1024) is re-read every step: workgroup->XCD placement is the same for every launch, so each XCD's
+// L2 keeps its 1/8 of W_hh (plain loads, not nt).
+typedef float f4v_ __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void lstm_step_mfma_kernel(const ssrhip_lstm_args a, int t, const float* hprev, float* hnext, int nw, int steps) {
+  constexpr int SPW = 32, DEPTH = 16;
+  __shared__ f4v_ tile[8][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, ks = lane >> 4;
+  const int C = a.C, j0 = blockIdx.x * 4, bt = blockIdx.y;
+  const int last = steps - 1;
+  const unsigned wvoff = ((unsigned)(c & 3) * C + min(j0 + (c >> 2), C - 1)) * (unsigned)C + ks * 4;
+  const float* xbase = hprev + (size_t)bt * 16 * C;
+  const unsigned xvoff = (unsigned)(ks * 16 + c) * 4;
+  const int tbase = wave * SPW;
+
+  float4 w[DEPTH];
+  float4 xr[SPW];
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) xr[i] = ld4(xbase + min(tbase + i, last) * 256 + xvoff);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i) w[i] = ld4(a.w_hh + min(tbase + i, last) * 16 + wvoff);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) asm volatile("" : "+v"(xr[i].x), "+v"(xr[i].y), "+v"(xr[i].z), "+v"(xr[i].w));
+#pragma unroll
+  for (int i = 0; i < SPW; ++i)
+    if (tbase + i > last) xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  f4v_ acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+    const float4 wv = w[i % DEPTH], xv = xr[i];
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc, 0, 0, 0);
+    if (i + DEPTH < SPW) w[i % DEPTH] = ld4(a.w_hh + min(tbase + i + DEPTH, last) * 16 + wvoff);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (nw > 1) {
+    tile[wave][lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    acc = tile[0][lane];
+    for (int q = 1; q < nw; ++q) acc += tile[q][lane];
+  }
+  const int b = bt * 16 + c, j = j0 + ks;
+  if (b >= a.B || j >= C) return;
+  const float* gin = a.gin + (size_t)b * a.gin_bstride + (size_t)t * 4 * C;
+  const float gi = acc[0] + gin[j], gf = acc[1] + gin[C + j], gg = acc[2] + gin[2 * C + j], go = acc[3] + gin[3 * C + j];
+  float* cc = a.cbuf + (size_t)b * C + j;
+  const float cprev = (t == 0) ? 0.f : *cc;
+  const float cn = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
+  const float hn = sigmoidf_(go) * tanhf(cn);
+  *cc = cn;
+  hnext[(size_t)bt * 16 * C + SSRHIP_TILED(c, j)] = hn;
+  float o = hn;
+  if (a.skip) o += a.skip[(size_t)b * a.skip_bstride + (size_t)t * C + j];
+  a.out[(size_t)b * a.out_bstride + (size_t)t * C + j] = o;
 }
 
 __global__ __launch_bounds__(256) void zero_kernel(float* p, long n) {
@@ -235,7 +282,8 @@ extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stre
   SSR_REQUIRE(a && a->gin && a->w_hh && a->out && a->hbuf && a->cbuf, "ssrhip_lstm_layer: null argument");
   SSR_REQUIRE(a->B > 0 && a->T > 0 && a->C > 0 && a->C % 4 == 0 && a->C <= 2048, "ssrhip_lstm_layer: need C %% 4 == 0, C <= 2048");
   hipStream_t s = (hipStream_t)stream;
-  const size_t hc = (size_t)a->B * a->C;
+  const int nbt = (a->B + 15) / 16;                                          // 16-item batch tiles (B > 4 path)
+  const size_t hc = (a->B <= 4) ? (size_t)a->B * a->C : (size_t)nbt * 16 * a->C;
   hipLaunchKernelGGL(zero_kernel, dim3(nblocks(2 * hc)), dim3(256), 0, s, a->hbuf, (long)(2 * hc));   // h_0 = 0
   {
     if (a->B <= 4) {
@@ -251,15 +299,14 @@ extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stre
         }
       }
     } else {
-      SSR_REQUIRE(a->gates, "ssrhip_lstm_layer: B > 4 needs the gates scratch buffer");
+      // hbuf holds [2][ceil(B/16)][C/4][16][4] (tiled per 16-item batch tile) on this path
+      SSR_REQUIRE(a->C % 16 == 0 && a->C <= 4096, "ssrhip_lstm_layer: B > 4 needs C %% 16 == 0, C <= 4096");
+      const int steps = a->C / 16;
+      int nw = (steps + 31) / 32;
       for (int t = 0; t < a->T; ++t) {
         const float* hp = a->hbuf + (size_t)(t & 1) * hc;
         float* hn = a->hbuf + (size_t)((t + 1) & 1) * hc;
-        ssrhip_gemm_args g;
-        memset(&g, 0, sizeof(g));
-        g.A = hp; g.W = a->w_hh; g.C = a->gates; g.M = a->B; g.N = 4 * a->C; g.K = a->C; g.lda = a->C; g.ldc = 4 * a->C;
-        if (int rc = ssrhip_gemm(&g, stream)) return rc;
-        hipLaunchKernelGGL(lstm_gates_kernel, dim3(nblocks((long)hc)), dim3(256), 0, s, *a, t, hn);
+        hipLaunchKernelGGL(lstm_step_mfma_kernel, dim3((a->C + 3) / 4, nbt), dim3(nw * 64), 0, s, *a, t, hp, hn, nw, steps);
       }
     }
   }

@@ -85,7 +85,8 @@ def test_codec_roundtrip_shapes_and_errors():
 
 
 def test_lstm_large_batch_path_matches_small_batch_path():
-    """B > 4 switches the recurrence to GEMM + gate kernel; same clips must give the same result either way."""
+    """B > 4 switches the recurrence to the fused matrix-core step kernel (16-item batch tiles); same clips must give the
+    same result either way (the B <= 4 path is the one pinned against the reference fixtures)."""
     cfg = W.codec_config_tiny()
     sd = W.codec_state_dict(cfg, seed=4)
     m = WMEncodecModel(cfg, sd, "cuda")
@@ -97,3 +98,19 @@ def test_lstm_large_batch_path_matches_small_batch_path():
     d6 = m.decode(c6)
     d2 = m.decode(c6[:2])
     torch.testing.assert_close(d6[:2], d2, rtol=0, atol=2e-5)
+
+
+def test_lstm_mfma_step_full_width_two_batch_tiles():
+    """Full codec config (LSTM width 1024 -> 2 waves per workgroup), 20 clips = two 16-item batch tiles, the second one ragged."""
+    cfg = W.codec_config_full()
+    sd = W.codec_state_dict(cfg, seed=5)
+    m = WMEncodecModel(cfg, sd, "cuda")
+    g = torch.Generator().manual_seed(1)
+    wav = (torch.randn(20, 1, cfg.hop * 12 + 17, generator=g) * 0.2).cuda()
+    c20, _, e20 = m.encode(wav)
+    for lo in (0, 15, 18):
+        c2, _, e2 = m.encode(wav[lo:lo + 2])
+        torch.testing.assert_close(e20[lo:lo + 2], e2, rtol=0, atol=2e-5)
+    d20 = m.decode(c20)
+    d2 = m.decode(c20[16:19])
+    torch.testing.assert_close(d20[16:19], d2, rtol=0, atol=2e-5)
