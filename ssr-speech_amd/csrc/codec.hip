@@ -226,6 +226,96 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* emb, const
   }
 }
 
+// RVQ encode on the matrix core: a workgroup owns 16 consecutive frames of one item; per stage the score matrix
+// [bins x 16 frames] = -(|x|^2 - (2x).e + |e|^2) is built 16 codes x 16 frames at a time with v_mfma_f32_16x16x4_f32
+// (A = codebook rows straight from L2, B = the doubled residual, register-resident in operand layout); the 4 waves take
+// every 4th code tile, keep a running first-max per (lane = frame, 4 codes) and merge through LDS. The codebook is read
+// once per 16 frames instead of once per frame (the per-frame kernel above is L2-bound: 4 MB of codebook per frame).
+template <int NS>   // D / 16 k-steps
+__global__ __launch_bounds__(256) void rvq_encode_mfma_kernel(const float* emb, const float* cb, const float* e2, int* codes, int T, int n_q,
+                                                              int bins, long emb_bstride) {
+  constexpr int D = NS * 16;
+  __shared__ float redv[4][16];
+  __shared__ int redi[4][16];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, ks = lane >> 4;
+  const int t0 = blockIdx.x * 16, b = blockIdx.y;
+  const float* src = emb + (size_t)b * emb_bstride + (size_t)min(t0 + c, T - 1) * D + ks * 4;
+  float4 xr[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) xr[s] = ld4(src + s * 16);
+  const int ntile = bins / 16;
+  for (int q = 0; q < n_q; ++q) {
+    float p = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) p += (xr[s].x * xr[s].x + xr[s].y * xr[s].y) + (xr[s].z * xr[s].z + xr[s].w * xr[s].w);
+    p += xor16_f(p);
+    p += xor32_f(p);
+    const float x2 = p;                                   // |x|^2 of frame c
+    const float* E = cb + (size_t)q * bins * D;
+    const float* e2q = e2 + (size_t)q * bins;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    float4 ec[NS], en[NS];
+    {
+      const float* er = E + (size_t)(wave * 16 + c) * D + ks * 4;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ec[s] = ld4(er + s * 16);
+    }
+    for (int ct = wave; ct < ntile; ct += 4) {
+      {
+        const float* er = E + (size_t)(min(ct + 4, ntile - 1) * 16 + c) * D + ks * 4;      // clamped, never predicated
+#pragma unroll
+        for (int s = 0; s < NS; ++s) en[s] = ld4(er + s * 16);
+      }
+      const float4 ee = ld4(e2q + ct * 16 + ks * 4);
+      f4v_ acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ec[s].x, 2.0f * xr[s].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ec[s].y, 2.0f * xr[s].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ec[s].z, 2.0f * xr[s].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ec[s].w, 2.0f * xr[s].w, acc, 0, 0, 0);
+      }
+      const int j0 = ct * 16 + ks * 4;                    // this lane: codes j0..j0+3 of frame c, ascending
+      const float s0 = -((x2 - acc[0]) + ee.x), s1 = -((x2 - acc[1]) + ee.y), s2 = -((x2 - acc[2]) + ee.z), s3 = -((x2 - acc[3]) + ee.w);
+      if (s0 > best) { best = s0; bi = j0; }
+      if (s1 > best) { best = s1; bi = j0 + 1; }
+      if (s2 > best) { best = s2; bi = j0 + 2; }
+      if (s3 > best) { best = s3; bi = j0 + 3; }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ec[s] = en[s];
+    }
+    // merge the 4 k-slot lanes of a frame, then the 4 waves: larger score wins, ties -> smaller index (torch.max: first)
+    {
+      float ov = xor16_f(best);
+      int oi = __builtin_bit_cast(int, xor16_f(__builtin_bit_cast(float, bi)));
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      ov = xor32_f(best);
+      oi = __builtin_bit_cast(int, xor32_f(__builtin_bit_cast(float, bi)));
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (ks == 0) { redv[wave][c] = best; redi[wave][c] = bi; }
+    __syncthreads();
+    float bb = redv[0][c];
+    int ii = redi[0][c];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float v = redv[w][c];
+      const int i2 = redi[w][c];
+      if (v > bb || (v == bb && i2 < ii)) { bb = v; ii = i2; }
+    }
+    __syncthreads();
+    if (wave == 0 && ks == 0 && t0 + c < T) codes[((size_t)b * n_q + q) * T + t0 + c] = ii;
+    const float* eb = E + (size_t)ii * D + ks * 4;        // residual = residual - quantized (core_vq.py:389-390)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float4 ev = ld4(eb + s * 16);
+      xr[s].x -= ev.x; xr[s].y -= ev.y; xr[s].z -= ev.z; xr[s].w -= ev.w;
+    }
+  }
+}
+
 __global__ __launch_bounds__(128) void rvq_decode_kernel(const int* codes, const float* cb, float* out, int T, int D, int n_q, int bins,
                                                          long out_bstride) {
   const int t = blockIdx.x, b = blockIdx.y;
@@ -318,6 +408,19 @@ extern "C" int ssrhip_rvq_encode(const float* emb, const float* codebooks, const
                                  int32_t D, int32_t n_q, int32_t bins, int64_t emb_bstride, ssrhip_stream_t stream) {
   SSR_REQUIRE(emb && codebooks && e2 && codes && B > 0 && T > 0 && D > 0 && D % 4 == 0 && n_q > 0 && bins > 0, "ssrhip_rvq_encode: bad argument");
   SSR_REQUIRE(B <= 65535, "ssrhip_rvq_encode: B too large");
+  const bool mfma = bins % 16 == 0 && bins >= 64 && (D == 32 || D == 64 || D == 128 || D == 256) && !getenv("SSRHIP_RVQ_SCALAR");
+  if (mfma) {
+    dim3 grid((T + 15) / 16, B);
+    hipStream_t s = (hipStream_t)stream;
+    switch (D) {
+      case 32: hipLaunchKernelGGL(rvq_encode_mfma_kernel<2>, grid, dim3(256), 0, s, emb, codebooks, e2, codes, T, n_q, bins, (long)emb_bstride); break;
+      case 64: hipLaunchKernelGGL(rvq_encode_mfma_kernel<4>, grid, dim3(256), 0, s, emb, codebooks, e2, codes, T, n_q, bins, (long)emb_bstride); break;
+      case 128: hipLaunchKernelGGL(rvq_encode_mfma_kernel<8>, grid, dim3(256), 0, s, emb, codebooks, e2, codes, T, n_q, bins, (long)emb_bstride); break;
+      default: hipLaunchKernelGGL(rvq_encode_mfma_kernel<16>, grid, dim3(256), 0, s, emb, codebooks, e2, codes, T, n_q, bins, (long)emb_bstride); break;
+    }
+    SSR_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t smem = ((size_t)D + 16) * sizeof(float);
   hipLaunchKernelGGL(rvq_encode_kernel, dim3(T, B), dim3(256), smem, (hipStream_t)stream, emb, codebooks, e2, codes, T, D, n_q, bins, (long)emb_bstride);
   SSR_LAUNCH_CHECK();

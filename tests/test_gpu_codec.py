@@ -114,3 +114,24 @@ def test_lstm_mfma_step_full_width_two_batch_tiles():
     d20 = m.decode(c20)
     d2 = m.decode(c20[16:19])
     torch.testing.assert_close(d20[16:19], d2, rtol=0, atol=2e-5)
+
+
+def test_rvq_encode_mfma_equals_scalar_kernel(monkeypatch):
+    """The matrix-core RVQ search (16 frames per workgroup) against the per-frame scalar kernel: same codes except where
+    the two best scores of a frame are closer than 1e-4 (different fp32 summation order). Full width: 128 dims, 2048 bins."""
+    cfg = W.codec_config_full()
+    sd = W.codec_state_dict(cfg, seed=6)
+    m = WMEncodecModel(cfg, sd, "cuda")
+    g = torch.Generator().manual_seed(2)
+    wav = (torch.randn(3, 1, cfg.hop * 37 + 5, generator=g) * 0.2).cuda()      # 38 frames: a ragged last 16-frame tile
+    c_mfma, _, emb = m.encode(wav)
+    monkeypatch.setenv("SSRHIP_RVQ_SCALAR", "1")
+    c_scalar, _, emb2 = m.encode(wav)
+    monkeypatch.delenv("SSRHIP_RVQ_SCALAR")
+    assert torch.equal(emb, emb2)
+    diff = (c_mfma != c_scalar).cpu()
+    assert diff.float().mean() < 0.02
+    if diff.any():
+        marg = code_margins(sd, cfg, emb.cpu(), c_scalar.cpu())
+        first = diff.float().cumsum(1) == 1
+        assert (marg[diff & first] < 1e-4).all(), (int(diff.sum()), marg[diff & first])
