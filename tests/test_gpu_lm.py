@@ -187,3 +187,26 @@ def test_inference_batch_rows_equal_batch1_runs(aug_text, greedy, n_utt):
         one = m.inference(u["x"].cuda(), torch.LongTensor([L]), u["x"].cuda(), torch.LongTensor([L]), u["y"].cuda(), u["y"].cuda(),
                           u["mask_interval"].cuda(), kvcache=1, **kw)
         assert torch.equal(batch[i][0], one[0]) and torch.equal(batch[i][1], one[1]) and batch[i][2] == one[2] and batch[i][3] == one[3], i
+
+
+@pytest.mark.parametrize("n_utt", [1, 5])
+def test_long_context_many_pages_matches_oracle(n_utt):
+    """Context of ~2,100 positions = 17 KV pages (the bench config uses 8): split-KV partials, their merge in the out-proj
+    prologue (2 rows) / the combine kernel (10 rows, matrix-core path) and the page table beyond 8 pages. Edit of one
+    short span in the middle of a 1,900-frame utterance, greedy with CFG; tokens equal the oracle's on the CPU."""
+    args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
+    m = _model(args, 33)
+    g = torch.Generator().manual_seed(17)
+    L, T = 180, 1900
+    utts = []
+    for i in range(n_utt):
+        x = torch.randint(0, 30, (1, L + i), generator=g)
+        y = torch.randint(0, 64, (1, T + 3 * i, 4), generator=g)
+        utts.append(dict(x=x, y=y, mask_interval=torch.LongTensor([[[900, 905 + i]]])))
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, silence_tokens=[3, 7, 11], cfg_coef=1.5, cfg_stride=1, aug_text=True)
+    got = m.inference_batch(utts, seed=7, **kw)
+    sd = O.reference_params(W.lm_state_dict(args, seed=33))
+    for i in (0, n_utt - 1):
+        torch.manual_seed(7 + i)
+        ref = O.inference(sd, args, utts[i]["x"], utts[i]["y"], utts[i]["mask_interval"], kvcache=1, max_steps=None, **kw)
+        assert torch.equal(got[i][0].cpu(), ref[0]) and torch.equal(got[i][1], ref[1]) and got[i][2] == ref[2], i

@@ -8,7 +8,8 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("gemv_fast_kernel", "gemv_kernel", "attn_decode_kernel", "sample_kernel", "gemm_kernel", "lstm_step_kernel", "rvq_encode_kernel"):
+    for k in ("gemv_fast_kernel", "gemv_mfma_kernel", "gemv_kernel", "attn_decode_kernel", "attn_combine_kernel", "sample_kernel", "gemm_kernel",
+              "lstm_step_mfma_kernel", "lstm_step_kernel", "rvq_encode_mfma_kernel", "rvq_encode_kernel"):
         if k in name:
             tail = name[name.index(k) + len(k):]
             return k + (tail.split("(")[0] if tail.startswith("<") else "")
