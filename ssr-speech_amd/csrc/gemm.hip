@@ -15,7 +15,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 64, BN = 128, BK = 16, LDSW = BK + 4;
+constexpr int BK = 16, LDSW = BK + 4;
 
 __device__ __forceinline__ float act_fn(float v, int act) {
   if (act == SSRHIP_ACT_RELU) return fmaxf(v, 0.f);
@@ -23,9 +23,25 @@ __device__ __forceinline__ float act_fn(float v, int act) {
   return v;
 }
 
-__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }   // nn.ELU(alpha=1)
+// nn.ELU(alpha=1) on operand load. libm's expm1f costs ~40 VALU ops and the convolution views re-load every input element
+// k (taps) x N-tiles times — it made the narrow SEANet layers VALU-bound. exp(v)-1 for v <= 0 as: degree-6 Taylor for
+// v > -0.25 (truncation 1.2e-8), else v_exp_f32 - 1 (abs error <= 1.2e-7 on a result >= 0.22 in magnitude).
+__device__ __forceinline__ float elu1(float v) {
+  const float p = v * (1.0f + v * (0.5f + v * (0.16666667f + v * (0.041666668f + v * (0.0083333338f + v * 0.0013888889f)))));
+  const float e = __expf(v) - 1.0f;
+  const float neg = v > -0.25f ? p : e;
+  return v > 0.f ? v : neg;
+}
 
+// 4 waves arranged MW x NW; each wave owns MT x NT accumulator blocks of 32x32. Block tile = (MW*MT*32) x (NW*NT*32) x 16.
+//   <1,4,2,1>  64 x 128 : the general shape (prefill, wide convolutions, LSTM input GEMM)
+//   <4,1,2,2> 256 x  64 : N <= 64  (SEANet layers with 64 output channels at 16 kHz / 8 kHz: rows are plentiful, columns are not)
+//   <4,1,2,1> 256 x  32 : N <= 32  (ResBlock bottlenecks 64 -> 32, the final 64 -> 1 convolution)
+// With the wide tile a 32-column layer wastes 3 of 4 waves on zero columns (measured 23 TFLOP/s useful on those layers).
+template <int MW, int NW, int MT, int NT>
 __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
+  constexpr int BM = MW * MT * 32, BN = NW * NT * 32;
+  constexpr int LA = BM / 64, LW = (BN + 63) / 64;       // float4 loads per thread per k-tile
   __shared__ __attribute__((aligned(16))) float As[BM * LDSW];
   __shared__ __attribute__((aligned(16))) float Ws[BN * LDSW];
   ssrhip_gemm_args a = a0;
@@ -36,61 +52,87 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
     if (a.R) a.R += z * (size_t)a.strideR;
   }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / NW, wn = wave % NW;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
   const int lr = t >> 2, lc = (t & 3) * 4;            // loader: row, first k column
   const int M = a.M, N = a.N, K = a.K;
 
-  f32x16 acc[2];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto gload = [&](int k0, float4& ra, float4& rw0, float4& rw1) {
+  float4 ra[LA], rw[LW];
+  auto gload = [&](int k0) {
     const bool kin = (k0 + lc) < K;
-    ra = (kin && (m0 + lr) < M) ? ld4(a.A + (size_t)(m0 + lr) * a.lda + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.act_in == SSRHIP_ACT_ELU) { ra.x = elu1(ra.x); ra.y = elu1(ra.y); ra.z = elu1(ra.z); ra.w = elu1(ra.w); }
-    rw0 = (kin && (n0 + lr) < N) ? ld4(a.W + (size_t)(n0 + lr) * K + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
-    rw1 = (kin && (n0 + lr + 64) < N) ? ld4(a.W + (size_t)(n0 + lr + 64) * K + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int m = m0 + lr + 64 * i;
+      ra[i] = (kin && m < M) ? ld4(a.A + (size_t)m * a.lda + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.act_in == SSRHIP_ACT_ELU) { ra[i].x = elu1(ra[i].x); ra[i].y = elu1(ra[i].y); ra[i].z = elu1(ra[i].z); ra[i].w = elu1(ra[i].w); }
+    }
+#pragma unroll
+    for (int i = 0; i < LW; ++i) {
+      const int n = n0 + lr + 64 * i;
+      rw[i] = (kin && n < N && (lr + 64 * i) < BN) ? ld4(a.W + (size_t)n * K + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   };
-  float4 ra, rw0, rw1;
-  gload(0, ra, rw0, rw1);
+  gload(0);
   const int li = lane & 31, lh = lane >> 5;
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();                                   // previous tile fully consumed
-    *reinterpret_cast<float4*>(&As[lr * LDSW + lc]) = ra;
-    *reinterpret_cast<float4*>(&Ws[lr * LDSW + lc]) = rw0;
-    *reinterpret_cast<float4*>(&Ws[(lr + 64) * LDSW + lc]) = rw1;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(&As[(lr + 64 * i) * LDSW + lc]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < LW; ++i)
+      if (lr + 64 * i < BN) *reinterpret_cast<float4*>(&Ws[(lr + 64 * i) * LDSW + lc]) = rw[i];
     __syncthreads();
-    if (k0 + BK < K) gload(k0 + BK, ra, rw0, rw1);     // prefetch next tile under the MFMAs
+    if (k0 + BK < K) gload(k0 + BK);                   // prefetch next tile under the MFMAs
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 8) {
-      const float4 b4 = *reinterpret_cast<const float4*>(&Ws[(wave * 32 + li) * LDSW + kk + lh * 4]);
-      const float4 a0 = *reinterpret_cast<const float4*>(&As[(li)*LDSW + kk + lh * 4]);
-      const float4 a1 = *reinterpret_cast<const float4*>(&As[(32 + li) * LDSW + kk + lh * 4]);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b4.x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b4.x, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b4.y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b4.y, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b4.z, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b4.z, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b4.w, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b4.w, acc[1], 0, 0, 0);
+      float4 b4[NT], a4[MT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b4[j] = *reinterpret_cast<const float4*>(&Ws[((wn * NT + j) * 32 + li) * LDSW + kk + lh * 4]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a4[i] = *reinterpret_cast<const float4*>(&As[((wm * MT + i) * 32 + li) * LDSW + kk + lh * 4]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
     }
   }
   // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const int n = n0 + wave * 32 + li;
-  if (n < N) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + (wn * NT + j) * 32 + li;
+    if (n >= N) continue;
     const float bias = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m < M) {
           if (a.tm_c > 0) {   // transposed-conv trimming: rows of the full output outside [tm_lo, tm_hi) are not stored
             const long u = ((long)m * N + n) / a.tm_c;
             if (u < a.tm_lo || u >= a.tm_hi) continue;
           }
-          float v = act_fn(acc[mt][r] + bias, a.act);
+          float v = act_fn(acc[mt][j][r] + bias, a.act);
           float* c = a.C + (size_t)m * a.ldc + n;
           if (a.residual) v += *c;
           if (a.R) v += a.R[(size_t)m * a.ldr + n];
@@ -152,9 +194,12 @@ __global__ __launch_bounds__(256) void kv_scatter_kernel(const float* qkv, const
 extern "C" int ssrhip_gemm(const ssrhip_gemm_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->A && a->W && a->C, "ssrhip_gemm: null argument");
   SSR_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 4 == 0 && a->lda % 4 == 0, "ssrhip_gemm: K and lda must be multiples of 4");
-  SSR_REQUIRE(a->batch <= 65535 && (a->M + BM - 1) / BM <= 65535, "ssrhip_gemm: grid too large (M=%d batch=%d)", a->M, a->batch);
-  dim3 grid((a->N + BN - 1) / BN, (a->M + BM - 1) / BM, a->batch > 1 ? a->batch : 1);
-  hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  const int bm = a->N <= 64 ? 256 : 64, bn = a->N <= 32 ? 32 : (a->N <= 64 ? 64 : 128);
+  SSR_REQUIRE(a->batch <= 65535 && (a->M + bm - 1) / bm <= 65535, "ssrhip_gemm: grid too large (M=%d batch=%d)", a->M, a->batch);
+  dim3 grid((a->N + bn - 1) / bn, (a->M + bm - 1) / bm, a->batch > 1 ? a->batch : 1);
+  if (bn == 32) hipLaunchKernelGGL((gemm_kernel<4, 1, 2, 1>), grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else if (bn == 64) hipLaunchKernelGGL((gemm_kernel<4, 1, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else hipLaunchKernelGGL((gemm_kernel<1, 4, 2, 1>), grid, dim3(256), 0, (hipStream_t)stream, *a);
   SSR_LAUNCH_CHECK();
   return 0;
 }
