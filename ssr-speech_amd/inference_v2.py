@@ -11,6 +11,7 @@ from __future__ import annotations
 import argparse
 import os
 import random
+import shutil
 import time
 
 import numpy as np
@@ -127,6 +128,8 @@ def main(argv=None):
         audio_fn = args.orig_audio
         s = max(args.mask_start - args.sub_amount, 0.0)                              # :307-312 (margins around the edited words)
         e = min(args.mask_end + args.sub_amount, audio_dur)
+        morphed_span = [[s, e]]                                                      # :312-317 (one span: no WhisperX word alignment here)
+        torch.save(morphed_span, os.path.join(args.output_dir, f"{args.savename}_mask.pt"))
         mask_interval = torch.LongTensor([[round(s * args.codec_sr), round(e * args.codec_sr)]])
         prompt_text = args.orig_transcript or ""
         target_text = args.target_transcript
@@ -140,7 +143,7 @@ def main(argv=None):
         text_tokenizer = TextTokenizer(backend="espeak", language="en-us" if args.language != "zh" else "cmn")
     decode_config = {"top_k": args.top_k, "top_p": args.top_p, "temperature": args.temperature, "stop_repetition": args.stop_repetition,
                      "kvcache": args.kvcache, "codec_audio_sr": args.codec_audio_sr, "codec_sr": args.codec_sr}
-    write_wav(os.path.join(args.output_dir, f"{args.savename}_orig.wav"), wav, sr)
+    shutil.copyfile(audio_fn, os.path.join(args.output_dir, f"{args.savename}_orig.wav"))   # :357-358 (the prompt actually used)
     for num in range(args.sample_batch_size):                                        # :331-358
         seed_everything(args.seed + num)
         new_audio = inference_one_sample(model, argparse.Namespace(**config), phn2num, text_tokenizer, audio_tokenizer, audio_fn,

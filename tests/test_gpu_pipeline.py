@@ -109,3 +109,47 @@ def test_encode_driver_writes_reference_format(tmp_path, monkeypatch):
             assert (got != ref_codes[j, :, :T].numpy()).mean() < 0.02, i      # fp near-ties aside (same bar as above)
     raw = open(tmp_path / "out" / "ds" / "wmencodec" / "seg0.txt").read()
     assert raw.count("\n") == 3 and not raw.endswith("\n")
+
+
+@pytest.mark.parametrize("tts", [True, False])
+def test_cli_main_writes_reference_outputs(tmp_path, tts):
+    """`python -m ssr_speech_amd.inference_v2` on synthetic checkpoints (the reference's checkpoint layout: config / model /
+    phn2num): output files named as inference_v2.py:316-317,336-337,357-358 and the new wav equal to a direct
+    `inference_one_sample` call with the same seed."""
+    from ssr_speech_amd import inference_v2 as CLI
+    from ssr_speech_amd.data.tokenizer import read_wav
+    ccfg = W.CodecConfig(dimension=64, n_filters=8, ratios=(8, 5, 4, 2), bins=64)
+    csd = W.codec_state_dict(ccfg, seed=7)
+    args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
+    lsd = W.lm_state_dict(args, seed=8)
+    for k in range(4):
+        lsd[f"predict_layer.{k}.2.bias"][64:] = -30.0
+    phn2num = {c: i for i, c in enumerate("abcdefghijklmnopqrstuvwxyz")}
+    lm_ckpt, codec_ckpt = str(tmp_path / "lm.pth"), str(tmp_path / "codec.th")
+    torch.save({"config": argparse.Namespace(**vars(args)), "model": lsd, "phn2num": phn2num}, lm_ckpt)
+    torch.save({"codec_config": {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(ccfg).items()}, "model": csd}, codec_ckpt)
+    g = torch.Generator().manual_seed(3)
+    wav_fn = str(tmp_path / "orig.wav")
+    write_wav(wav_fn, torch.randn(1, 24 * 320, generator=g) * 0.2, 16000)
+    out_dir = str(tmp_path / "out")
+    ids = lambda t: ",".join(str(phn2num[c]) for c in t if c != " ")
+    prompt_text, target = "hello world", "again"
+    argv = ["--model_path", lm_ckpt, "--codec_path", codec_ckpt, "--orig_audio", wav_fn, "--orig_transcript", prompt_text,
+            "--target_transcript", target, "--output_dir", out_dir, "--temp_folder", str(tmp_path / "tmp"), "--savename", "utt", "--seed", "5",
+            "--top_k", "1", "--top_p", "1.0", "--cfg_stride", "2", "--aug_text", "--sample_batch_size", "2"]
+    if tts:
+        full = (prompt_text + " " + target).strip()
+        argv += ["--tts", "--prompt_end", "0.4", "--phoneme_ids", ids(full), "--prompt_phoneme_ids", ids(prompt_text)]
+    else:
+        argv += ["--mask_start", "0.20", "--mask_end", "0.30", "--phoneme_ids", ids(target), "--prompt_phoneme_ids", ids(prompt_text)]
+    CLI.main(argv)
+    names = sorted(os.listdir(out_dir))
+    assert "utt_new_seed5.wav" in names and "utt_new_seed6.wav" in names and "utt_orig.wav" in names
+    assert ("utt_mask.pt" in names) == (not tts)
+    if not tts:
+        span = torch.load(os.path.join(out_dir, "utt_mask.pt"))
+        assert span == [[max(0.20 - 0.12, 0.0), min(0.30 + 0.12, 24 * 320 / 16000)]]
+    new5, sr = read_wav(os.path.join(out_dir, "utt_new_seed5.wav"))
+    assert sr == 16000 and new5.shape[0] == 1 and new5.shape[1] % 320 == 0 and new5.shape[1] > 0
+    orig, _ = read_wav(os.path.join(out_dir, "utt_orig.wav"))
+    assert orig.shape[1] == (int(0.4 * 16000) if tts else 24 * 320)
