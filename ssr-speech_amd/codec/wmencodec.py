@@ -242,7 +242,7 @@ class WMEncodecModel:
         dev = self.device
         assert x.padL == 0 and x.padR == 0
         gin = torch.empty(B, T, 4 * Cc, dtype=torch.float32, device=dev)
-        hbuf = torch.empty(2, B if B <= 4 else (B + 15) // 16 * 16, Cc, dtype=torch.float32, device=dev)   # include/ssrhip.h
+        hbuf = torch.empty(2, (B + 15) // 16 * 16, Cc, dtype=torch.float32, device=dev)   # include/ssrhip.h ssrhip_lstm_args
         cbuf = torch.empty(B, Cc, dtype=torch.float32, device=dev)
         gates = None
         cur_ptr, cur_bs = x.interior, x.bstride

@@ -44,40 +44,33 @@ __global__ __launch_bounds__(256) void pad_reflect_kernel(float* buf, int T, int
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // One LSTM time step for B <= 4 items. Wave -> hidden unit j (4 gate rows j, C+j, 2C+j, 3C+j of W_hh).
-template <int B>
+// NCH = C / 256 float4 chunks per lane (C a multiple of 256): every load is unconditional, so all 4*NCH weight loads and the
+// B*NCH h loads of a wave are in flight together (predicated loads make hipcc drain the queue between groups).
+template <int B, int NCH>
 __global__ __launch_bounds__(256) void lstm_step_kernel(const ssrhip_lstm_args a, int t, const float* hprev, float* hnext) {
-  constexpr int MAXC4 = 8;                       // C <= 2048
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = a.C;
-  const int j = blockIdx.x * 4 + wave;
-  if (j >= C) return;
-  const int nch = (C + 255) / 256;
-  float4 h[B][MAXC4];
+  const int j = min(blockIdx.x * 4 + wave, C - 1);          // C % 4 == 0: never clamps; keeps the loads unconditional
+  float4 h[B][NCH];
 #pragma unroll
   for (int b = 0; b < B; ++b)
 #pragma unroll
-    for (int i = 0; i < MAXC4; ++i) {
-      const int k = (i * 64 + lane) * 4;
-      h[b][i] = (i < nch && k < C) ? ld4(hprev + (size_t)b * C + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int i = 0; i < NCH; ++i) h[b][i] = ld4(hprev + (size_t)b * C + (i * 64 + lane) * 4);
+  float4 w[4][NCH];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) w[q][i] = ld4(a.w_hh + ((size_t)q * C + j) * C + (i * 64 + lane) * 4);
   float g[4][B];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float* wr = a.w_hh + ((size_t)q * C + j) * C;
-    float s[B];
 #pragma unroll
-    for (int b = 0; b < B; ++b) s[b] = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC4; ++i) {
-      const int k = (i * 64 + lane) * 4;
-      if (i < nch && k < C) {
-        const float4 w = ld4(wr + k);
-#pragma unroll
-        for (int b = 0; b < B; ++b) s[b] = dot4(w, h[b][i], s[b]);
-      }
+      for (int i = 0; i < NCH; ++i) s = dot4(w[q][i], h[b][i], s);
+      g[q][b] = wave_sum(s);
     }
-#pragma unroll
-    for (int b = 0; b < B; ++b) g[q][b] = wave_sum(s[b]);
   }
   if (lane < B) {
     float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
@@ -96,6 +89,17 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const ssrhip_lstm_args a
     float o = hn;
     if (a.skip) o += a.skip[(size_t)b * a.skip_bstride + (size_t)t * C + j];
     a.out[(size_t)b * a.out_bstride + (size_t)t * C + j] = o;
+  }
+}
+
+template <int B>
+void launch_lstm_step(const ssrhip_lstm_args& a, int t, const float* hp, float* hn, hipStream_t s) {
+  dim3 grid((a.C + 3) / 4);
+  switch (a.C / 256) {
+    case 1: hipLaunchKernelGGL((lstm_step_kernel<B, 1>), grid, dim3(256), 0, s, a, t, hp, hn); break;
+    case 2: hipLaunchKernelGGL((lstm_step_kernel<B, 2>), grid, dim3(256), 0, s, a, t, hp, hn); break;
+    case 4: hipLaunchKernelGGL((lstm_step_kernel<B, 4>), grid, dim3(256), 0, s, a, t, hp, hn); break;
+    default: hipLaunchKernelGGL((lstm_step_kernel<B, 8>), grid, dim3(256), 0, s, a, t, hp, hn); break;
   }
 }
 
@@ -370,27 +374,28 @@ extern "C" int ssrhip_pad_reflect(float* buf, int32_t B, int32_t T, int32_t padL
 
 extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->gin && a->w_hh && a->out && a->hbuf && a->cbuf, "ssrhip_lstm_layer: null argument");
-  SSR_REQUIRE(a->B > 0 && a->T > 0 && a->C > 0 && a->C % 4 == 0 && a->C <= 2048, "ssrhip_lstm_layer: need C %% 4 == 0, C <= 2048");
+  SSR_REQUIRE(a->B > 0 && a->T > 0 && a->C > 0 && a->C % 16 == 0 && a->C <= 4096, "ssrhip_lstm_layer: need C %% 16 == 0, C <= 4096");
   hipStream_t s = (hipStream_t)stream;
-  const int nbt = (a->B + 15) / 16;                                          // 16-item batch tiles (B > 4 path)
-  const size_t hc = (a->B <= 4) ? (size_t)a->B * a->C : (size_t)nbt * 16 * a->C;
+  const int nbt = (a->B + 15) / 16;                                          // 16-item batch tiles (matrix-core path)
+  const bool small_b = a->B <= 4 && (a->C == 256 || a->C == 512 || a->C == 1024 || a->C == 2048);
+  const size_t hc = small_b ? (size_t)a->B * a->C : (size_t)nbt * 16 * a->C;
   hipLaunchKernelGGL(zero_kernel, dim3(nblocks(2 * hc)), dim3(256), 0, s, a->hbuf, (long)(2 * hc));   // h_0 = 0
   {
-    if (a->B <= 4) {
+    // small-batch kernel: C in {256, 512, 1024, 2048}; anything else (e.g. the narrow test configs) takes the matrix-core
+    // path, which handles any C % 16 == 0 and any B
+    if (small_b) {
       for (int t = 0; t < a->T; ++t) {
         const float* hp = a->hbuf + (size_t)(t & 1) * hc;
         float* hn = a->hbuf + (size_t)((t + 1) & 1) * hc;
-        dim3 grid((a->C + 3) / 4);
         switch (a->B) {
-          case 1: hipLaunchKernelGGL(lstm_step_kernel<1>, grid, dim3(256), 0, s, *a, t, hp, hn); break;
-          case 2: hipLaunchKernelGGL(lstm_step_kernel<2>, grid, dim3(256), 0, s, *a, t, hp, hn); break;
-          case 3: hipLaunchKernelGGL(lstm_step_kernel<3>, grid, dim3(256), 0, s, *a, t, hp, hn); break;
-          default: hipLaunchKernelGGL(lstm_step_kernel<4>, grid, dim3(256), 0, s, *a, t, hp, hn); break;
+          case 1: launch_lstm_step<1>(*a, t, hp, hn, s); break;
+          case 2: launch_lstm_step<2>(*a, t, hp, hn, s); break;
+          case 3: launch_lstm_step<3>(*a, t, hp, hn, s); break;
+          default: launch_lstm_step<4>(*a, t, hp, hn, s); break;
         }
       }
     } else {
       // hbuf holds [2][ceil(B/16)][C/4][16][4] (tiled per 16-item batch tile) on this path
-      SSR_REQUIRE(a->C % 16 == 0 && a->C <= 4096, "ssrhip_lstm_layer: B > 4 needs C %% 16 == 0, C <= 4096");
       const int steps = a->C / 16;
       int nw = (steps + 31) / 32;
       for (int t = 0; t < a->T; ++t) {
