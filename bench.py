@@ -80,6 +80,50 @@ def cpu_baseline(args_lm, sd_gpu, x, y, unc, n_steps=25):
                        f"ms/step by threads {{{', '.join(f'{k}: {1000 * v:.1f}' for k, v in per.items())}}} on a {ncpu}-logical-core host; best reported")
 
 
+def codec_leg(dev, with_cpu):
+    """Extra (not `value`): wmencodec encode + decode throughput at the full SEANet config (SURVEY §8 rows B1-B7, config 5
+    shape scaled to 16 clips x 10 s so that the default run stays short), and the oracle's CPU time on one 2 s clip."""
+    from ssr_speech_amd import weights as W
+    from ssr_speech_amd.codec.wmencodec import WMEncodecModel
+    cfg = W.codec_config_full()
+    csd = W.codec_state_dict(cfg, seed=0)
+    m = WMEncodecModel(cfg, csd, dev)
+    g = torch.Generator().manual_seed(0)
+    B, secs = 16, 10.0
+    wav = (torch.randn(B, 1, int(secs * 16000), generator=g) * 0.1).to(dev)
+    codes, _, _ = m.encode(wav)
+    m.decode(codes)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    codes, _, _ = m.encode(wav)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    out_wav = m.decode(codes)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    GF = 6.97e9                                   # FLOP per audio-second, encode and decode each (SURVEY §8d)
+    audio_s = B * secs
+    out = {"workload": f"{B} clips x {secs:.0f} s, 16 kHz, full wmencodec config, synthetic weights",
+           "encode_ms": round(1000 * (t1 - t0), 2), "decode_ms": round(1000 * (t2 - t1), 2),
+           "encode_audio_s_per_s": round(audio_s / (t1 - t0), 1), "decode_audio_s_per_s": round(audio_s / (t2 - t1), 1),
+           "encode_tflops": round(GF * audio_s / (t1 - t0) / 1e12, 1), "decode_tflops": round(GF * audio_s / (t2 - t1) / 1e12, 1),
+           "mfma_fp32_peak_tflops": 157.3, "out_shape": list(out_wav.shape)}
+    if with_cpu:
+        from oracle import codec as OC
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        w1 = wav[:1, :, : 2 * 16000].cpu()
+        c0 = time.perf_counter()
+        ccodes, _, _ = OC.encode(csd, w1, cfg)
+        c1 = time.perf_counter()
+        OC.decode(csd, ccodes, cfg)
+        c2 = time.perf_counter()
+        out["cpu_baseline"] = {"kind": "port", "cores": torch.get_num_threads(), "sample": "oracle/codec.py on 1 clip x 2 s",
+                               "encode_audio_s_per_s": round(2.0 / (c1 - c0), 2), "decode_audio_s_per_s": round(2.0 / (c2 - c1), 2)}
+        same = float((ccodes != codes[:1, :, : ccodes.shape[-1]].cpu()).float().mean())
+        out["cpu_baseline"]["code_mismatch_vs_gpu_first_2s"] = round(same, 4)   # informational: clip context differs beyond the receptive field
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,6 +281,11 @@ def main():
                                   "note": f"prefill of {2 * (L + T0)} rows (host layout + H2D included), 500 frames = 10 s, SEANet+LSTM decode of {tuple(wav.shape)}"}
         except Exception as e:  # the headline metric must not depend on this extra
             out["rtf_10s_tts"] = {"error": repr(e)}
+        if U == 1 and world == 1:
+            try:
+                out["wmencodec"] = codec_leg(dev, with_cpu=not a.no_cpu_baseline)
+            except Exception as e:  # the headline metric must not depend on this extra
+                out["wmencodec"] = {"error": repr(e)}
         if allgather_ms is not None:
             out["allgather_ms"] = round(allgather_ms, 3)
         if world == 1 and not a.no_cpu_baseline and U == 1:
