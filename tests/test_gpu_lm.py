@@ -210,3 +210,22 @@ def test_long_context_many_pages_matches_oracle(n_utt):
         torch.manual_seed(7 + i)
         ref = O.inference(sd, args, utts[i]["x"], utts[i]["y"], utts[i]["mask_interval"], kvcache=1, max_steps=None, **kw)
         assert torch.equal(got[i][0].cpu(), ref[0]) and torch.equal(got[i][1], ref[1]) and got[i][2] == ref[2], i
+
+
+@pytest.mark.parametrize("name", ["tts_sample_topk", "tts_sample_topp_temp", "cfgpre_ctx_sample"])
+def test_sampled_runs_reproduce_reference_from_the_seed_alone(golden_dir, name):
+    """no recorded noise, no recorded uncond_x — only `torch.manual_seed(seed)` as a user of the reference
+    would do. `inference()` consumes the global CPU generator in the reference's order (randint for the CFG text, then one
+    Exp(1) tensor per step, which is what torch.multinomial draws), so the sampled tokens equal the reference's."""
+    g, args, kw = _load(golden_dir, name)
+    m = _model(args, int(g["weight_seed"]))
+    L = g["x"].shape[1]
+    x = torch.from_numpy(g["x"]).cuda()
+    y = torch.from_numpy(g["y"]).cuda()
+    px = torch.from_numpy(g["prompt_x"]).cuda() if "prompt_x" in g.files else x
+    py = torch.from_numpy(g["prompt"]).cuda() if "prompt" in g.files else y
+    torch.manual_seed(int(g["torch_seed"]))
+    res, marks, masks, nmi = m.inference(x, torch.LongTensor([L]), px, torch.LongTensor([px.shape[1]]), y, py,
+                                         torch.from_numpy(g["mask_interval"]).cuda(), **kw)
+    assert np.array_equal(res.cpu().numpy(), g["res"])
+    assert np.array_equal(marks.numpy(), g["marks"])
