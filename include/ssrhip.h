@@ -213,7 +213,7 @@ int ssrhip_pad_reflect(float* buf, int32_t B, int32_t T, int32_t padL, int32_t p
  * gin[b][t][4C] = x_t W_ih^T + b_ih + b_hh (precomputed by ssrhip_gemm); h,c start at 0.
  * out[b][t][C] = h_t (+ skip[b][t][C] when skip != NULL).  cbuf: [B][C]; hbuf: [2][ceil(B/16)*16][C] floats (row-major
  * [B][C] on the small-batch path B <= 4 && C in {256,512,1024,2048}; otherwise kept in the SSRHIP_TILED layout per 16-item
- * tile); gates: unused (may be NULL). C % 16 == 0, C <= 4096. */
+ * tile, which needs C <= 1024); gates: unused (may be NULL). C % 16 == 0. */
 typedef struct ssrhip_lstm_args {
   const float* gin; const float* w_hh; float* out; const float* skip;
   float* hbuf; float* cbuf; float* gates;

@@ -113,62 +113,82 @@ void launch_lstm_step(const ssrhip_lstm_args& a, int t, const float* hp, float* 
 // L2 keeps its 1/8 of W_hh (plain loads, not nt).
 typedef float f4v_ __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(512) void lstm_step_mfma_kernel(const ssrhip_lstm_args a, int t, const float* hprev, float* hnext, int nw, int steps) {
-  constexpr int SPW = 32, DEPTH = 16;
-  __shared__ f4v_ tile[8][64];
+// NT = 16-item batch tiles per workgroup (blockIdx.y covers NT consecutive tiles): the wave's W_hh slice (16 k-steps = 256
+// columns, 16 float4) is loaded ONCE into registers and multiplied with NT h tiles, so W_hh's L2 traffic per step halves for
+// B > 16. Waves: C/256 per workgroup (<= 4: C <= 1024, which leaves 512 VGPRs per wave for the two operand sets).
+template <int NT>
+__global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const ssrhip_lstm_args a, int t, const float* hprev, float* hnext, int nw, int steps,
+                                                              int nbt) {
+  constexpr int SPW = 16;
+  __shared__ f4v_ tile[NT][4][64];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15, ks = lane >> 4;
-  const int C = a.C, j0 = blockIdx.x * 4, bt = blockIdx.y;
+  const int C = a.C, j0 = blockIdx.x * 4, bt0 = blockIdx.y * NT;
   const int last = steps - 1;
   const unsigned wvoff = ((unsigned)(c & 3) * C + min(j0 + (c >> 2), C - 1)) * (unsigned)C + ks * 4;
-  const float* xbase = hprev + (size_t)bt * 16 * C;
   const unsigned xvoff = (unsigned)(ks * 16 + c) * 4;
   const int tbase = wave * SPW;
 
-  float4 w[DEPTH];
-  float4 xr[SPW];
+  float4 xr[NT][SPW];
 #pragma unroll
-  for (int i = 0; i < SPW; ++i) xr[i] = ld4(xbase + min(tbase + i, last) * 256 + xvoff);
-  __builtin_amdgcn_sched_barrier(0);
+  for (int q = 0; q < NT; ++q) {
+    const float* xbase = hprev + (size_t)min(bt0 + q, nbt - 1) * 16 * C;
 #pragma unroll
-  for (int i = 0; i < DEPTH; ++i) w[i] = ld4(a.w_hh + min(tbase + i, last) * 16 + wvoff);
-  __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < SPW; ++i) xr[q][i] = ld4(xbase + min(tbase + i, last) * 256 + xvoff);
+  }
+  float4 w[SPW];
 #pragma unroll
-  for (int i = 0; i < SPW; ++i) asm volatile("" : "+v"(xr[i].x), "+v"(xr[i].y), "+v"(xr[i].z), "+v"(xr[i].w));
+  for (int i = 0; i < SPW; ++i) w[i] = ld4(a.w_hh + min(tbase + i, last) * 16 + wvoff);
 #pragma unroll
-  for (int i = 0; i < SPW; ++i)
-    if (tbase + i > last) xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  f4v_ acc = {0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < NT; ++q)
+#pragma unroll
+    for (int i = 0; i < SPW; ++i)
+      if (tbase + i > last) xr[q][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  f4v_ acc[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) acc[q] = f4v_{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < SPW; ++i) {
-    const float4 wv = w[i % DEPTH], xv = xr[i];
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc, 0, 0, 0);
-    if (i + DEPTH < SPW) w[i % DEPTH] = ld4(a.w_hh + min(tbase + i + DEPTH, last) * 16 + wvoff);
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, xr[q][i].x, acc[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, xr[q][i].y, acc[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, xr[q][i].z, acc[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, xr[q][i].w, acc[q], 0, 0, 0);
   }
   if (nw > 1) {
-    tile[wave][lane] = acc;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) tile[q][wave][lane] = acc[q];
     __syncthreads();
-    if (wave != 0) return;
-    acc = tile[0][lane];
-    for (int q = 1; q < nw; ++q) acc += tile[q][lane];
+    if (wave >= NT) return;                       // wave q finishes batch tile q
   }
-  const int b = bt * 16 + c, j = j0 + ks;
-  if (b >= a.B || j >= C) return;
-  const float* gin = a.gin + (size_t)b * a.gin_bstride + (size_t)t * 4 * C;
-  const float gi = acc[0] + gin[j], gf = acc[1] + gin[C + j], gg = acc[2] + gin[2 * C + j], go = acc[3] + gin[3 * C + j];
-  float* cc = a.cbuf + (size_t)b * C + j;
-  const float cprev = (t == 0) ? 0.f : *cc;
-  const float cn = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
-  const float hn = sigmoidf_(go) * tanhf(cn);
-  *cc = cn;
-  hnext[(size_t)bt * 16 * C + SSRHIP_TILED(c, j)] = hn;
-  float o = hn;
-  if (a.skip) o += a.skip[(size_t)b * a.skip_bstride + (size_t)t * C + j];
-  a.out[(size_t)b * a.out_bstride + (size_t)t * C + j] = o;
+  const int q = (nw > 1) ? wave : 0;
+  f4v_ sum = acc[0];
+  if (nw > 1) {
+    sum = tile[q][0][lane];
+    for (int w2 = 1; w2 < nw; ++w2) sum += tile[q][w2][lane];
+  }
+#pragma unroll
+  for (int qq = 0; qq < NT; ++qq) {               // nw == 1: the single wave walks its NT tiles; nw > 1: only qq == q
+    if (nw > 1 && qq != q) continue;
+    if (nw == 1) sum = acc[qq];
+    const int bt = bt0 + qq;
+    const int b = bt * 16 + c, j = j0 + ks;
+    if (bt >= nbt || b >= a.B || j >= C) continue;
+    const float* gin = a.gin + (size_t)b * a.gin_bstride + (size_t)t * 4 * C;
+    const float gi = sum[0] + gin[j], gf = sum[1] + gin[C + j], gg = sum[2] + gin[2 * C + j], go = sum[3] + gin[3 * C + j];
+    float* cc = a.cbuf + (size_t)b * C + j;
+    const float cprev = (t == 0) ? 0.f : *cc;
+    const float cn = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
+    const float hn = sigmoidf_(go) * tanhf(cn);
+    *cc = cn;
+    hnext[(size_t)bt * 16 * C + SSRHIP_TILED(c, j)] = hn;
+    float o = hn;
+    if (a.skip) o += a.skip[(size_t)b * a.skip_bstride + (size_t)t * C + j];
+    a.out[(size_t)b * a.out_bstride + (size_t)t * C + j] = o;
+  }
 }
 
 __global__ __launch_bounds__(256) void zero_kernel(float* p, long n) {
@@ -397,11 +417,13 @@ extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stre
     } else {
       // hbuf holds [2][ceil(B/16)][C/4][16][4] (tiled per 16-item batch tile) on this path
       const int steps = a->C / 16;
-      int nw = (steps + 31) / 32;
+      SSR_REQUIRE(a->C <= 1024, "ssrhip_lstm_layer: the matrix-core path (B > 4, or C not in {256,512,1024,2048}) needs C <= 1024");
+      const int nw = (steps + 15) / 16;                        // 256 columns of W_hh per wave -> <= 4 waves
       for (int t = 0; t < a->T; ++t) {
         const float* hp = a->hbuf + (size_t)(t & 1) * hc;
         float* hn = a->hbuf + (size_t)((t + 1) & 1) * hc;
-        hipLaunchKernelGGL(lstm_step_mfma_kernel, dim3((a->C + 3) / 4, nbt), dim3(nw * 64), 0, s, *a, t, hp, hn, nw, steps);
+        if (nbt >= 2 && nw >= 2) hipLaunchKernelGGL((lstm_step_mfma_kernel<2>), dim3((a->C + 3) / 4, (nbt + 1) / 2), dim3(nw * 64), 0, s, *a, t, hp, hn, nw, steps, nbt);
+        else hipLaunchKernelGGL((lstm_step_mfma_kernel<1>), dim3((a->C + 3) / 4, nbt), dim3(nw * 64), 0, s, *a, t, hp, hn, nw, steps, nbt);
       }
     }
   }
