@@ -232,6 +232,18 @@ int ssrhip_wm_concat(const float* skip, const int32_t* labels, const float* tabl
                      int32_t C, int32_t E, int32_t rep, int32_t n_labels, int64_t skip_bstride, int64_t cat_bstride,
                      ssrhip_stream_t stream);
 
+/* Fused SEANetResnetBlock (modules/seanet.py:16-60; true_skip, dilation 1, kernel sizes 3 and 1) for C == 64 channels:
+ *   y[b][t][:] = x[b][t][:] + b1 + W1 . ELU(b3 + W3 . ELU(x[b][t-1 : t+2][:]))
+ * x points at the row BEFORE t = 0 of item 0 of a time-major buffer [B][1 + T + 1][C] (halo rows hold the zero / reflect
+ * padding); w3 is [C/2][3][C] (output channel, tap, input channel), w1 is [C][C/2]; y points at row t = 0. */
+typedef struct ssrhip_resblock_args {
+  const float* x; float* y;
+  const float* w3; const float* b3; const float* w1; const float* b1;
+  int32_t B, T, C;
+  int64_t x_bstride, y_bstride;   /* elements between items */
+} ssrhip_resblock_args;
+int ssrhip_resblock(const ssrhip_resblock_args* a, ssrhip_stream_t stream);
+
 /* LayerNorm over rows (transformer.py:58-75) */
 int ssrhip_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int32_t R, int32_t D,
                      ssrhip_stream_t stream);

@@ -103,6 +103,11 @@ class LstmArgs(C.Structure):
 _PP = C.POINTER(C.c_void_p)
 
 
+class ResblockArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
+                ("B", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("x_bstride", C.c_int64), ("y_bstride", C.c_int64)]
+
+
 class LMWeights(C.Structure):
     _fields_ = [("text_emb", C.c_void_p), ("audio_emb", C.c_void_p), ("pe", C.c_void_p),
                 ("alpha_text", C.c_float), ("alpha_audio", C.c_float),
@@ -153,6 +158,7 @@ SYMBOLS = [
     ("ssrhip_rvq_encode", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     ("ssrhip_rvq_decode", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     ("ssrhip_wm_concat", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
+    ("ssrhip_resblock", C.c_int, [C.POINTER(ResblockArgs), C.c_void_p]),
     ("ssrhip_layernorm", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("ssrhip_kv_scatter", C.c_int, [C.c_void_p, C.POINTER(KV), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("ssrhip_lm_create", C.c_int, [C.POINTER(LMDims), C.POINTER(LMWeights), C.POINTER(LMBuffers), C.POINTER(C.c_void_p)]),
@@ -164,7 +170,7 @@ SYMBOLS = [
 ]
 
 ABI_STRUCTS = [KV, GemvArgs, AttnArgs, EmbedArgs, SamplerCfg, SamplerState, SampleArgs, GemmArgs, LMWeights, LMDims,
-               LMBuffers, PrefillArgs, LstmArgs]
+               LMBuffers, PrefillArgs, LstmArgs, ResblockArgs]
 
 _lib = None
 

@@ -149,6 +149,7 @@ class WMEncodecModel:
         if self.device.type != "cuda":
             raise RuntimeError("ssr_speech_amd codec needs a ROCm GPU device; there is no CPU path in this package")
         self.lib = _lib.lib()
+        self.fuse_resblock = True            # tests switch it off to compare with the two-GEMM path
         sd = {k: v.detach().to(torch.float32).cpu() for k, v in state_dict.items()}
         dev = self.device
         self.encoder = _SeaNet(sd, "encoder.", cfg, False, dev)
@@ -234,8 +235,20 @@ class WMEncodecModel:
         return out
 
     def _res(self, cs, x: TM, nxt) -> TM:
-        h = self._conv(cs[0], x, None)
-        return self._conv(cs[1], h, nxt, R=x)
+        c3, c1 = cs
+        if self.fuse_resblock and c3.Cin == 64 and c3.k == 3 and c3.s == 1 and c1.k == 1 and c1.s == 1 and x.padL == 1 and x.padR == 1:
+            # the full-rate 64-channel block as one kernel (csrc/resblock.hip): one read + one write of the activation
+            out = self._alloc_for(x.B, x.T, c1.Cout, nxt)
+            a = _lib.ResblockArgs()
+            a.x, a.y = x.base, out.interior
+            a.w3, a.b3, a.w1, a.b1 = c3.W.data_ptr(), c3.b.data_ptr(), c1.W.data_ptr(), c1.b.data_ptr()
+            a.B, a.T, a.C = x.B, x.T, 64
+            a.x_bstride, a.y_bstride = x.bstride, out.bstride
+            _lib.check(self.lib.ssrhip_resblock(C.byref(a), self._s()), "ssrhip_resblock")
+            self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
+            return out
+        h = self._conv(c3, x, None)
+        return self._conv(c1, h, nxt, R=x)
 
     def _lstm(self, L: _Lstm, x: TM, nxt) -> TM:
         B, T, Cc = x.B, x.T, x.C

@@ -39,6 +39,7 @@ extern "C" int ssrhip_sizeof(int which) {
     case 10: return sizeof(ssrhip_lm_buffers);
     case 11: return sizeof(ssrhip_prefill_args);
     case 12: return sizeof(ssrhip_lstm_args);
+    case 13: return sizeof(ssrhip_resblock_args);
     default: return -1;
   }
 }

@@ -1,0 +1,149 @@
+// resblock.hip — SEANetResnetBlock (audiocraft/modules/seanet.py:16-60, true_skip, dilation 1) as ONE kernel for the
+// 64-channel, full-rate layers (16 kHz: T = 480,000 per 30 s clip), SURVEY §8 row B3 / K10:
+//
+//     y[t] = x[t] + b1 + W1 . ELU( b3 + W3 . ELU( x[t-1 : t+2] ) )          W3: [32][3*64], W1: [64][32]
+//
+// As two GEMM launches the 32-channel intermediate makes a round trip through HBM and the activation is read three times
+// (once per tap) through L2. Here a wave owns 32 consecutive time steps:
+//   * the 34 input rows (halo included) are fetched once, coalesced (one tile ahead), ELU'd once and parked in the wave's
+//     LDS region;
+//   * the weights stay on chip for the whole kernel, which is persistent over time tiles: W3 (24 KB) in LDS shared by the 8
+//     waves of the workgroup, W1 and b3 in registers in the order stage 2 consumes them;
+//   * stage 1  D1[h][t] = sum_k W3[h][k] ELU(x)[t][k]  on v_mfma_f32_32x32x2_f32 with the time steps as the N dimension:
+//     the accumulator layout then leaves lane (t, half) with 16 hidden channels of ITS time step, which is exactly the
+//     B-operand layout stage 2 needs (k = hidden channel, n = time step) — no shuffle, no LDS round trip for the
+//     intermediate (the k order of stage 2 follows the accumulator's row order; W1 is preloaded in that order);
+//   * stage 2  D2[c][t] = sum_h W1[c][h] ELU(D1 + b3)[h][t], then the tile goes back through LDS so that the residual add
+//     and the store to HBM are coalesced 256-byte rows.
+// Waves never synchronise with each other (wave-scope fences only). HBM traffic: one read + one write of the activation.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int C = 64, H = 32, K3 = 3 * C, XS = C + 4;     // XS: padded LDS row stride (floats)
+
+__device__ __forceinline__ float elu_fast(float v) {       // same function as gemm.hip's ELU-on-load
+  const float p = v * (1.0f + v * (0.5f + v * (0.16666667f + v * (0.041666668f + v * (0.0083333338f + v * 0.0013888889f)))));
+  const float e = __expf(v) - 1.0f;
+  const float neg = v > -0.25f ? p : e;
+  return v > 0.f ? v : neg;
+}
+
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+constexpr int NWAVE = 8, W3S = K3 + 4;                    // waves per workgroup; padded LDS row stride of W3
+
+__global__ __launch_bounds__(NWAVE * 64) void resblock64_kernel(const ssrhip_resblock_args a) {
+  __shared__ __attribute__((aligned(16))) float W3s[H * W3S];        // 25 KB, shared by the 8 waves
+  __shared__ __attribute__((aligned(16))) float Xs[NWAVE][34 * XS];  // per wave: ELU(x) rows t0-1 .. t0+32, later the output tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y;
+  const float* xin = a.x + (size_t)b * a.x_bstride;          // row 0 = the halo row in front of t = 0
+  float* yout = a.y + (size_t)b * a.y_bstride;
+  float* xs = Xs[wave];
+
+  // W3 -> LDS once per workgroup (A operand of stage 1, read as float4 per 4 MFMAs); W1 / b3 -> registers
+  for (int i = threadIdx.x; i < H * K3 / 4; i += NWAVE * 64) {
+    const int r = i / (K3 / 4), c4 = i % (K3 / 4);
+    *reinterpret_cast<float4*>(W3s + r * W3S + c4 * 4) = ld4(a.w3 + (size_t)r * K3 + c4 * 4);
+  }
+  float w1r[2][16];                                          // A operand of stage 2: W1[c = 32mb + li][rho(s)], rho = accumulator row order
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w1r[mb][s] = a.w1[(size_t)(mb * 32 + li) * H + (s & 3) + 8 * (s >> 2) + 4 * lh];
+  float b3r[16];                                             // bias of the hidden channel held in accumulator register s
+#pragma unroll
+  for (int s = 0; s < 16; ++s) b3r[s] = a.b3[(s & 3) + 8 * (s >> 2) + 4 * lh];
+  __syncthreads();                                           // the only workgroup barrier: W3s is ready
+
+  const int T = a.T;
+  const int ntile = (T + 31) / 32;
+  const int stride = gridDim.x * NWAVE;
+  // software pipeline: the NEXT tile's 34 input rows are requested (9 float4 per lane) before the current tile is computed
+  float4 xn[9];
+  auto fetch = [&](int tile) {
+    const int t0 = min(tile, ntile - 1) * 32;              // past the end: re-read the last tile (never used)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int idx = min(i * 64 + lane, 34 * 16 - 1);
+      const int row = idx >> 4, c4 = idx & 15;
+      xn[i] = ld4(xin + (size_t)min(t0 + row, T + 1) * C + c4 * 4);   // rows t0-1 .. t0+32 = buffer rows t0 .. t0+33, clamped to the right halo
+    }
+  };
+  fetch(blockIdx.x * NWAVE + wave);
+  for (int tile = blockIdx.x * NWAVE + wave; tile < ntile; tile += stride) {
+    const int t0 = tile * 32;
+    wave_lds_fence();                                        // previous tile's LDS reads are done
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {                            // ELU once per element (it is used by 3 taps)
+      const int idx = min(i * 64 + lane, 34 * 16 - 1);
+      *reinterpret_cast<float4*>(xs + (idx >> 4) * XS + (idx & 15) * 4) =
+          make_float4(elu_fast(xn[i].x), elu_fast(xn[i].y), elu_fast(xn[i].z), elu_fast(xn[i].w));
+    }
+    wave_lds_fence();
+    fetch(tile + stride);
+    // ---- stage 1: 24 x 4 MFMAs, both operands from LDS
+    f32x16 acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < K3 / 8; ++j) {
+      const float4 wv = *reinterpret_cast<const float4*>(W3s + li * W3S + 8 * j + 4 * lh);
+      const float4 xv = *reinterpret_cast<const float4*>(xs + (li + (j >> 3)) * XS + 8 * (j & 7) + 4 * lh);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, xv.x, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, xv.y, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, xv.z, acc1, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, xv.w, acc1, 0, 0, 0);
+    }
+    // ---- stage 2: hidden = ELU(acc1 + b3) straight from the accumulator registers
+    f32x16 acc2[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc2[0][r] = 0.f; acc2[1][r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float hv = elu_fast(acc1[s] + b3r[s]);
+      acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[0][s], hv, acc2[0], 0, 0, 0);
+      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[1][s], hv, acc2[1], 0, 0, 0);
+    }
+    // ---- transpose through LDS (the x tile is dead now): lane (t = li) holds channels 32mb + (r&3) + 8(r>>2) + 4lh
+    wave_lds_fence();
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(xs + li * XS + mb * 32 + 8 * g + 4 * lh) =
+            make_float4(acc2[mb][4 * g], acc2[mb][4 * g + 1], acc2[mb][4 * g + 2], acc2[mb][4 * g + 3]);
+    wave_lds_fence();
+    // ---- residual (raw x re-read: an L2 hit, coalesced) + bias, coalesced 256-byte rows out
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = i * 64 + lane;
+      const int row = idx >> 4, c4 = idx & 15;
+      const int tt = min(t0 + row, T - 1);
+      const float4 xr = ld4(xin + (size_t)(tt + 1) * C + c4 * 4);
+      const float4 v = *reinterpret_cast<const float4*>(xs + row * XS + c4 * 4);
+      const float4 bb = ld4(a.b1 + c4 * 4);
+      if (t0 + row < T)
+        *reinterpret_cast<float4*>(yout + (size_t)tt * C + c4 * 4) =
+            make_float4(xr.x + (v.x + bb.x), xr.y + (v.y + bb.y), xr.z + (v.z + bb.z), xr.w + (v.w + bb.w));
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ssrhip_resblock(const ssrhip_resblock_args* a, ssrhip_stream_t stream) {
+  SSR_REQUIRE(a && a->x && a->y && a->w3 && a->b3 && a->w1 && a->b1, "ssrhip_resblock: null argument");
+  SSR_REQUIRE(a->C == 64 && a->B > 0 && a->B <= 65535 && a->T > 0, "ssrhip_resblock: only the 64-channel block is fused (C=%d)", a->C);
+  int gx = (256 + a->B - 1) / a->B;                       // ~1 eight-wave workgroup per CU in total; every wave then walks many tiles
+  const int need = (a->T + 32 * NWAVE - 1) / (32 * NWAVE);
+  if (gx > need) gx = need;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(resblock64_kernel, dim3(gx, a->B), dim3(NWAVE * 64), 0, (hipStream_t)stream, *a);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}

@@ -135,3 +135,23 @@ def test_rvq_encode_mfma_equals_scalar_kernel(monkeypatch):
         marg = code_margins(sd, cfg, emb.cpu(), c_scalar.cpu())
         first = diff.float().cumsum(1) == 1
         assert (marg[diff & first] < 1e-4).all(), (int(diff.sum()), marg[diff & first])
+
+
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+def test_fused_resblock_equals_two_gemm_path(pad_mode):
+    """csrc/resblock.hip (64-channel SEANetResnetBlock as one kernel) vs the same block as two strided-view GEMMs: encoder
+    (first block) and decoder (last block) at the full config, ragged length (tail tile), 3 clips."""
+    import dataclasses
+    cfg = dataclasses.replace(W.codec_config_full(), pad_mode=pad_mode)
+    sd = W.codec_state_dict(cfg, seed=9)
+    m = WMEncodecModel(cfg, sd, "cuda")
+    g = torch.Generator().manual_seed(3)
+    wav = (torch.randn(3, 1, cfg.hop * 9 + 123, generator=g) * 0.2).cuda()
+    c1, _, e1 = m.encode(wav)
+    d1 = m.decode(c1)
+    m.fuse_resblock = False
+    c0, _, e0 = m.encode(wav)
+    d0 = m.decode(c1)
+    torch.testing.assert_close(e1, e0, rtol=0, atol=2e-5)
+    torch.testing.assert_close(d1, d0, rtol=0, atol=2e-5)
+    assert (c1 != c0).float().mean() < 0.02
