@@ -136,6 +136,16 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const ssrhip_lstm_a
 #pragma unroll
     for (int i = 0; i < SPW; ++i) xr[q][i] = ld4(xbase + min(tbase + i, last) * 256 + xvoff);
   }
+  // the finishing waves (wave q finishes batch tile q) request their gate inputs and cell state NOW: they do not depend on
+  // the recurrent product, so their L2/HBM latency hides under the MFMA chain instead of following it
+  float pg[4] = {0.f, 0.f, 0.f, 0.f}, pc = 0.f;
+  const bool fin = (nw > 1) && (wave < NT);
+  if (fin) {
+    const int bt = bt0 + wave, bb = min(bt * 16 + c, a.B - 1), jj = min(j0 + ks, C - 1);
+    const float* gin = a.gin + (size_t)bb * a.gin_bstride + (size_t)t * 4 * C;
+    pg[0] = gin[jj]; pg[1] = gin[C + jj]; pg[2] = gin[2 * C + jj]; pg[3] = gin[3 * C + jj];
+    pc = (t == 0) ? 0.f : a.cbuf[(size_t)bb * C + jj];
+  }
   float4 w[SPW];
 #pragma unroll
   for (int i = 0; i < SPW; ++i) w[i] = ld4(a.w_hh + min(tbase + i, last) * 16 + wvoff);
@@ -177,11 +187,14 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const ssrhip_lstm_a
     const int bt = bt0 + qq;
     const int b = bt * 16 + c, j = j0 + ks;
     if (bt >= nbt || b >= a.B || j >= C) continue;
-    const float* gin = a.gin + (size_t)b * a.gin_bstride + (size_t)t * 4 * C;
-    const float gi = sum[0] + gin[j], gf = sum[1] + gin[C + j], gg = sum[2] + gin[2 * C + j], go = sum[3] + gin[3 * C + j];
     float* cc = a.cbuf + (size_t)b * C + j;
-    const float cprev = (t == 0) ? 0.f : *cc;
-    const float cn = sigmoidf_(gf) * cprev + sigmoidf_(gi) * tanhf(gg);
+    if (!fin) {                                   // single-wave workgroups (narrow C): no early request was made
+      const float* gin = a.gin + (size_t)b * a.gin_bstride + (size_t)t * 4 * C;
+      pg[0] = gin[j]; pg[1] = gin[C + j]; pg[2] = gin[2 * C + j]; pg[3] = gin[3 * C + j];
+      pc = (t == 0) ? 0.f : *cc;
+    }
+    const float gi = sum[0] + pg[0], gf = sum[1] + pg[1], gg = sum[2] + pg[2], go = sum[3] + pg[3];
+    const float cn = sigmoidf_(gf) * pc + sigmoidf_(gi) * tanhf(gg);
     const float hn = sigmoidf_(go) * tanhf(cn);
     *cc = cn;
     hnext[(size_t)bt * 16 * C + SSRHIP_TILED(c, j)] = hn;
