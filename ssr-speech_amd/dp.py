@@ -53,3 +53,23 @@ def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token
             res.append(out[r, i, :, : int(all_lens[r, i])].to(torch.int64).clone())
     assert len(res) == n_total
     return res
+
+
+def generate(model, utterances: Sequence[dict], seed: int = 0, pad_token: int = None, device=None, **decode_kw):
+    """BASELINE config 4 in one call: shard `utterances` (dicts {x, y, mask_interval}, see `SSR_Speech.inference_batch`)
+    over the ranks of the default process group, decode this rank's shard in lock-step (up to 8 utterances x CFG rows per
+    engine pass), and all-gather the generated codec tokens so that every rank holds all of them before codec decode.
+    Utterance i uses the RNG stream `seed + i` whatever the world size. Returns (tokens, local) where tokens[i] is the int64
+    [K, T_i'] result of utterance i (all utterances, every rank) and local = (lo, hi, the 4-tuples of this rank's shard)."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    lo, hi = shard_range(len(utterances), world, rank)
+    outs = model.inference_batch(list(utterances[lo:hi]), seed=seed, first_index=lo, **decode_kw) if hi > lo else []
+    K = int(model.args.n_codebooks)
+    if pad_token is None:
+        pad_token = int(model.args.empty_token)
+    toks = [o[0][0] for o in outs]                                   # res [1, K, T'] -> [K, T']
+    if device is None:
+        device = toks[0].device if toks else torch.device("cpu")
+    return gather_tokens(toks, len(utterances), K, pad_token, device=device), (lo, hi, outs)

@@ -57,3 +57,52 @@ def test_gather_tokens_world2(n_total):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+class _StubModel:
+    """Stands in for SSR_Speech on the CPU: `inference_batch` returns tokens that depend only on (utterance, seed + global
+    index), which is the contract `dp.generate` relies on."""
+
+    class args:
+        n_codebooks = 4
+        empty_token = 2048
+
+    def inference_batch(self, utterances, seed=0, first_index=0, **kw):
+        out = []
+        for j, u in enumerate(utterances):
+            g = torch.Generator().manual_seed(seed + first_index + j)
+            T = int(u["x"].shape[1]) + 3
+            out.append((torch.randint(0, 2048, (1, 4, T), generator=g), None, None, None))
+        return out
+
+
+def _gen_worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    utts = [dict(x=torch.zeros(1, 4 + i, dtype=torch.long)) for i in range(n_total)]
+    toks, (lo, hi, outs) = dp.generate(_StubModel(), utts, seed=40)
+    ref = _StubModel().inference_batch(utts, seed=40, first_index=0)          # what ONE process would produce
+    ok = len(toks) == n_total and all(torch.equal(toks[i], ref[i][0][0]) for i in range(n_total)) and (lo, hi) == dp.shard_range(n_total, world, rank) \
+        and len(outs) == hi - lo
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [7, 1])
+def test_generate_world2_equals_single_process(n_total):
+    """`dp.generate` on 2 ranks == the same utterances decoded by one process (per-utterance seeds), incl. an empty shard."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gen_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
