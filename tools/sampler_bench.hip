@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int reps = 200;
   ssrhip_sampler_state s0; memset(&s0, 0, sizeof(s0)); s0.num_cfg_tag = 1; s0.prev_token = -1; s0.num_gen = 5;
-  float tot = 0; unsigned long long acc[16] = {0};
+  float tot = 0; unsigned long long acc[16] = {0}, fine[6] = {0};
   for (int r = 0; r < reps; ++r) {
     s0.n_steps = r; CK(hipMemcpy(st, &s0, sizeof(s0), hipMemcpyHostToDevice));
     CK(hipEventRecord(e0, 0));
@@ -44,10 +44,13 @@ int main(int argc, char** argv) {
 #ifdef SSR_SAMPLE_PROFILE
     unsigned long long p[16]; CK(hipMemcpyFromSymbol(p, HIP_SYMBOL(g_sample_prof), sizeof(p)));
     if (r >= 10) for (int i = 1; i < 9; ++i) acc[i] += p[i] - p[i - 1];
+    if (r >= 10) { fine[0] += p[10] - p[9]; fine[1] += p[11] - p[10]; fine[2] += p[12] - p[11]; fine[3] += p[13] - p[12]; fine[4] += p[14] - p[13]; fine[5] += p[15] - p[14]; }
 #endif
   }
   printf("top_k=%d top_p=%.2f: %.2f us per launch (event)\n", top_k, top_p, 1000 * tot / (reps - 10));
   const char* nm[9] = {"", "load+edit", "argmax/temp/keys", "(kmin..)", "top-k", "softmax+top-p", "sample", "barrier", "state"};
   for (int i = 1; i < 9; ++i) printf("  phase %d %-18s %8.0f clk\n", i, i < 8 ? nm[i] : "embed", (double)acc[i] / (reps - 10));
+  const char* fn[6] = {"bin_select<0>: zero+bins+barrier", "atomics+barrier", "scan+barrier", "collect+barrier", "overflow flag+barrier", "rank+barrier"};
+  for (int i = 0; i < 6; ++i) printf("    %-30s %8.0f clk\n", fn[i], (double)fine[i] / (reps - 10));
   return 0;
 }
