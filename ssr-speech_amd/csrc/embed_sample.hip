@@ -9,6 +9,7 @@
 //   (<= 34 per lane), top-k / top-p thresholds are found by bisection on the order-preserving integer
 //   image of the logits (ballot+popcount for counts, fixed-order DPP wave sums for mass) — no sort, no
 //   atomics, bit-reproducible.  No host round trip per step.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -182,14 +183,14 @@ __device__ __forceinline__ uint32_t radix_select(const uint32_t (&key)[MAXE], co
 // caller runs radix_select.
 template <int MODE>
 __device__ __forceinline__ uint32_t bin_select(const uint32_t (&key)[MAXE], const float (&p)[MAXE], const float (&l)[MAXE], float lo, float scale,
-                                               unsigned kk, float lim, bool active, SelShared& sh, int k, int sub, int lane, bool& fallback) {
+                                               unsigned kk, float lim, bool active, SelShared& sh, int k, int sub, int lane, int force_radix, bool& fallback) {
   const float SC = 1099511627776.0f;   // 2^40
   const unsigned long long limfx = (unsigned long long)((double)lim * (double)SC);
   unsigned long long* mine64 = sh.hist[k][sub];
   unsigned* mine32 = reinterpret_cast<unsigned*>(mine64);
   if (MODE == 0) { for (int j = lane; j < 256; j += 64) mine32[j] = 0u; }
   else { for (int j = lane; j < 256; j += 64) mine64[j] = 0ull; }
-  if (threadIdx.x == 0) sh.overflow = 0;
+  if (threadIdx.x == 0) sh.overflow = force_radix;
   if (sub == 0 && lane == 0) { sh.ncand[k] = 0; sh.result[k] = 0u; }
   if (MODE == 0) STAMP(9);
   int vb[MAXE];
@@ -299,7 +300,7 @@ __device__ __forceinline__ uint32_t bin_select(const uint32_t (&key)[MAXE], cons
   return (found && !fallback) ? sh.result[k] : 0u;
 }
 
-__global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(const ssrhip_sample_args a) {
+__global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(const ssrhip_sample_args a, const int force_radix) {
   __shared__ SelShared sel;
   __shared__ float sh_f[SSRHIP_MAX_CODEBOOKS][WPC];
   __shared__ float sh_g[SSRHIP_MAX_CODEBOOKS][WPC];
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(const ssrhip_sam
     if (kk == 1) thr = kmax;
     else if (kk < card) {
       bool fb;
-      thr = bin_select<0>(key, p, l, vlo, vscale, (unsigned)kk, 0.f, active, sel, kc, sub, lane, fb);
+      thr = bin_select<0>(key, p, l, vlo, vscale, (unsigned)kk, 0.f, active, sel, kc, sub, lane, force_radix, fb);
       if (fb) thr = radix_select<0>(key, p, (unsigned)kk, 0.f, active, sel, kc, sub, lane);          // workgroup-uniform
     }
   }
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(const ssrhip_sam
   __syncthreads();
   if (c_topp < 1.0f) {   // uniform
     bool fb;
-    uint32_t tp = bin_select<1>(key, p, l, vlo, vscale, 0u, c_topp * Z, active, sel, kc, sub, lane, fb);
+    uint32_t tp = bin_select<1>(key, p, l, vlo, vscale, 0u, c_topp * Z, active, sel, kc, sub, lane, force_radix, fb);
     if (fb) tp = radix_select<1>(key, p, 0u, c_topp * Z, active, sel, kc, sub, lane);                // workgroup-uniform
     if (tp > thr) {
       thr = tp;
@@ -585,7 +586,8 @@ extern "C" int ssrhip_sample(const ssrhip_sample_args* a, ssrhip_stream_t stream
   SSR_REQUIRE(a->card > 0 && a->card <= 64 * WPC * MAXE, "ssrhip_sample: card=%d exceeds %d", a->card, 64 * WPC * MAXE);
   if (a->embed.out) SSR_REQUIRE(a->embed.audio_emb && a->embed.pe && a->embed.D % 4 == 0 && a->embed.K == a->K && a->embed.card == a->card,
                                 "ssrhip_sample: fused embed needs audio_emb, pe, matching K/card");
-  hipLaunchKernelGGL(sample_kernel, dim3(a->n_utt), dim3(SAMPLE_THREADS), 0, (hipStream_t)stream, *a);
+  const char* e = getenv("SSRHIP_SAMPLE_RADIX");          // test knob: always take the radix-select path (value baked in at graph capture)
+  hipLaunchKernelGGL(sample_kernel, dim3(a->n_utt), dim3(SAMPLE_THREADS), 0, (hipStream_t)stream, *a, (e && atoi(e)) ? 1 : 0);
   SSR_LAUNCH_CHECK();
   return 0;
 }

@@ -483,6 +483,60 @@ def test_sampler_state_machine_matches_oracle(L, case):
         torch.testing.assert_close(dbgs[s], rec["edited_logits"][s], rtol=0, atol=0)   # edits + CFG combine are exact
 
 
+def _full_card_script(case, top_k, S=8):
+    args = W.lm_args_830m()
+    K = args.n_codebooks
+    card = args.audio_vocab_size + args.n_special + args.max_n_spans
+    g = torch.Generator().manual_seed(hash((case, top_k)) % 1000)
+    logits_seq, noise_seq = [], []
+    for s in range(S):
+        lg = torch.randn(2, K, 1, card, generator=g) * (0.05 if case == "narrow" else 2.0)
+        if case == "ties":
+            lg = torch.round(lg * 2) / 2
+        if case == "flat":
+            lg = torch.zeros_like(lg)
+        lg[..., args.eog] -= 30.0                          # keep the scripted run going
+        logits_seq.append(lg)
+        noise_seq.append(torch.empty(K, card).exponential_(1, generator=g))
+    return args, logits_seq, noise_seq
+
+
+# top-p on tied logits is not compared with the reference: its sorted-prefix cut falls INSIDE a group of equal logits at a
+# position decided by torch.sort's tie order, which no order-free selection can (or should) reproduce. top-k keeps ties whole.
+@pytest.mark.parametrize("case,top_k,top_p", [("normal", 40, 0.8), ("normal", 0, 0.8), ("normal", 300, 1.0), ("normal", 40, 0.999),
+                                              ("narrow", 40, 0.8), ("narrow", 0, 0.5), ("ties", 40, 1.0), ("ties", 300, 1.0), ("flat", 40, 1.0)])
+def test_sampler_full_card_selection_paths(L, case, top_k, top_p):
+    """card = 2056 (the 830M shape: 9 logits per lane): the value-bin selection on ordinary logits ("normal", "narrow"), and the
+    radix fallback when one bin holds more than 64 elements ("ties": logits rounded to halves, "flat": all equal). Tokens
+    must equal the oracle's for the same Exp(1) noise."""
+    args, logits_seq, noise_seq = _full_card_script(case, top_k)
+    K = args.n_codebooks
+    sil = [1388, 1898, 131]
+    knobs = dict(top_k=top_k, top_p=top_p, temperature=1.0, stop_repetition=2, silence_tokens=sil, cfg_coef=1.5, cfg_stride=2, aug_text=True)
+    text_len, audio_pos0 = 100, 8
+    st = O.SpanState()
+    ref = []
+    for s in range(len(logits_seq)):
+        smp = O.step_logits_to_samples(logits_seq[s].clone(), st, args, audio_pos0 + s + 1, text_len, top_k=top_k, top_p=top_p, temperature=1.0,
+                                       stop_repetition=2, silence_tokens=sil, cfg_coef=1.5, cfg_stride=2, aug_text=True, noise=noise_seq[s])
+        ref.append(smp.squeeze(-1).clone())
+    got, _, state = _run_sampler_script(L, args, [l.squeeze(2) for l in logits_seq], knobs, noise_seq, text_len, audio_pos0)
+    assert torch.equal(got, torch.stack(ref)), (case, got, torch.stack(ref))
+
+
+@pytest.mark.parametrize("case,top_k,top_p", [("normal", 40, 0.8), ("narrow", 0, 0.6), ("ties", 40, 0.8), ("flat", 7, 0.3)])
+def test_sampler_bin_path_equals_radix_path(L, monkeypatch, case, top_k, top_p):
+    """The value-bin selection and the radix selection define the same thresholds with the same integer arithmetic: the
+    sampled tokens are identical, ties or not (SSRHIP_SAMPLE_RADIX=1 forces the radix path)."""
+    args, logits_seq, noise_seq = _full_card_script(case, top_k)
+    knobs = dict(top_k=top_k, top_p=top_p, temperature=1.0, stop_repetition=2, silence_tokens=[1388, 1898, 131], cfg_coef=1.5, cfg_stride=2, aug_text=True)
+    seq = [l.squeeze(2) for l in logits_seq]
+    got, _, _ = _run_sampler_script(L, args, seq, knobs, noise_seq, 100, 8)
+    monkeypatch.setenv("SSRHIP_SAMPLE_RADIX", "1")
+    ref, _, _ = _run_sampler_script(L, args, seq, knobs, noise_seq, 100, 8)
+    assert torch.equal(got, ref)
+
+
 def test_sampler_filter_golden(L, golden_dir):
     """top-k / top-p keep-sets against the reference's top_k_top_p_filtering (golden), via the sampled
     token: with noise == 1 the draw is the argmax of the filtered distribution; with huge noise on the
