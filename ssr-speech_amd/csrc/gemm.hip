@@ -35,6 +35,8 @@ __device__ __forceinline__ float elu1(float v) {
 
 // 4 waves arranged MW x NW; each wave owns MT x NT accumulator blocks of 32x32. Block tile = (MW*MT*32) x (NW*NT*32) x 16.
 //   <1,4,2,1>  64 x 128 : the general shape (prefill, wide convolutions, LSTM input GEMM)
+//   <2,2,1,1>  64 x  64 : when 64 x 128 tiles would not even give one workgroup per CU (prefill of a single prompt: M ~ 600,
+//                         N = 2048 -> 160 workgroups; with 64 x 64 tiles 320)
 //   <4,1,2,2> 256 x  64 : N <= 64  (SEANet layers with 64 output channels at 16 kHz / 8 kHz: rows are plentiful, columns are not)
 //   <4,1,2,1> 256 x  32 : N <= 32  (ResBlock bottlenecks 64 -> 32, the final 64 -> 1 convolution)
 // With the wide tile a 32-column layer wastes 3 of 4 waves on zero columns (measured 23 TFLOP/s useful on those layers).
@@ -194,10 +196,14 @@ __global__ __launch_bounds__(256) void kv_scatter_kernel(const float* qkv, const
 extern "C" int ssrhip_gemm(const ssrhip_gemm_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->A && a->W && a->C, "ssrhip_gemm: null argument");
   SSR_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 4 == 0 && a->lda % 4 == 0, "ssrhip_gemm: K and lda must be multiples of 4");
-  const int bm = a->N <= 64 ? 256 : 64, bn = a->N <= 32 ? 32 : (a->N <= 64 ? 64 : 128);
+  int bm = a->N <= 64 ? 256 : 64, bn = a->N <= 32 ? 32 : (a->N <= 64 ? 64 : 128);
+  const long wide_wgs = (long)((a->N + 127) / 128) * ((a->M + 63) / 64) * (a->batch > 1 ? a->batch : 1);
+  const bool small_grid = a->N > 64 && wide_wgs < 256;
+  if (small_grid) bn = 64;
   SSR_REQUIRE(a->batch <= 65535 && (a->M + bm - 1) / bm <= 65535, "ssrhip_gemm: grid too large (M=%d batch=%d)", a->M, a->batch);
   dim3 grid((a->N + bn - 1) / bn, (a->M + bm - 1) / bm, a->batch > 1 ? a->batch : 1);
-  if (bn == 32) hipLaunchKernelGGL((gemm_kernel<4, 1, 2, 1>), grid, dim3(256), 0, (hipStream_t)stream, *a);
+  if (small_grid) hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1>), grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else if (bn == 32) hipLaunchKernelGGL((gemm_kernel<4, 1, 2, 1>), grid, dim3(256), 0, (hipStream_t)stream, *a);
   else if (bn == 64) hipLaunchKernelGGL((gemm_kernel<4, 1, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, *a);
   else hipLaunchKernelGGL((gemm_kernel<1, 4, 2, 1>), grid, dim3(256), 0, (hipStream_t)stream, *a);
   SSR_LAUNCH_CHECK();

@@ -333,7 +333,8 @@ def test_embed_matches_oracle(L):
 
 # ------------------------------------------------------------------------------------------ GEMM / LN / scatter
 @pytest.mark.parametrize("M,N,K,act,res", [(600, 384, 2048, 0, 0), (70, 130, 64, 1, 0), (64, 128, 512, 0, 1), (333, 72, 128, 2, 1), (5, 2056, 1024, 0, 0),
-                                           (5000, 32, 192, 0, 1), (1000, 64, 448, 2, 0), (777, 1, 448, 0, 0), (300, 33, 64, 1, 1)])   # N <= 64: the tall 256-row tiles
+                                           (5000, 32, 192, 0, 1), (1000, 64, 448, 2, 0), (777, 1, 448, 0, 0), (300, 33, 64, 1, 1),   # N <= 64: the tall 256-row tiles
+                                           (2100, 2048, 256, 1, 1)])   # >= 256 wide tiles: 64x128 (the smaller shapes above use 64x64)
 def test_gemm_matches_torch(L, M, N, K, act, res):
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g)
