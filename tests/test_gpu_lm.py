@@ -126,9 +126,12 @@ def test_state_dict_keys_are_the_references():
     assert vars(m.args)["n_codebooks"] == 4
 
 
-def test_full_830m_greedy_steps_match_oracle_on_cpu():
-    """Full 'English 830M' shape (SURVEY §8 constants), synthetic weights: 24 greedy CFG steps on the GPU vs
-    the oracle on this box's CPU cores: same token ids, logits within LOGIT_ATOL·(scale)."""
+@pytest.mark.parametrize("mode", ["tts", "edit"])
+def test_full_830m_greedy_steps_match_oracle_on_cpu(mode):
+    """Full 'English 830M' shape (SURVEY §8 constants), synthetic weights: greedy CFG steps on the GPU vs the oracle on this
+    box's CPU cores: same token ids, logits within 5e-4. "tts" = BASELINE config 1/2 shape (short prompt, empty span at the
+    end); "edit" = config 3 shape (L=120 phonemes, 397-frame utterance, single span [150, 250) => 3-segment layout,
+    context > 3 KV pages at the first step)."""
     args = W.lm_args_830m()
     torch.manual_seed(0)
     sd_gpu = W.lm_state_dict(args, seed=0, device="cuda")
@@ -136,11 +139,15 @@ def test_full_830m_greedy_steps_match_oracle_on_cpu():
     m.load_state_dict({k: v.cpu() for k, v in sd_gpu.items()})
     m = m.to("cuda").eval()
     gen = torch.Generator().manual_seed(2024)
-    L, N, steps = 40, 60, 24
+    if mode == "tts":
+        L, N, steps = 40, 60, 24
+        mi = torch.LongTensor([[[N, N]]])
+    else:
+        L, N, steps = 120, 397, 10
+        mi = torch.LongTensor([[[150, 250]]])
     x = torch.randint(0, 100, (1, L), generator=gen)
     y = torch.randint(0, 2048, (1, N, 4), generator=gen)
     unc = torch.randint(0, 101, (1, L), generator=gen)
-    mi = torch.LongTensor([[[N, N]]])
     kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=5, aug_text=True)
     # oracle on the CPU (weights are bit-identical: same generator, checked below)
     sd_cpu = O.reference_params({k: v.cpu() for k, v in sd_gpu.items()})
@@ -160,7 +167,7 @@ def test_full_830m_greedy_steps_match_oracle_on_cpu():
     assert np.array_equal(got_tok, ref_tok), (got_tok, ref_tok)
     last = eng.dbg_logits[0].cpu().numpy()
     err = np.abs(last - ref_log[steps - 1]).max()
-    print(f"830M: max |logit diff| at step {steps}: {err:.2e} (logit std {ref_log[steps-1][np.abs(ref_log[steps-1])<1e3].std():.2f})")
+    print(f"830M {mode}: max |logit diff| at step {steps}: {err:.2e} (logit std {ref_log[steps-1][np.abs(ref_log[steps-1])<1e3].std():.2f})")
     assert err < 5e-4
 
 
