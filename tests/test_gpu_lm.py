@@ -252,3 +252,44 @@ def test_dp_generate_single_rank_equals_inference_batch():
     assert (lo, hi) == (0, 5) and len(toks) == 5
     for i in range(5):
         assert torch.equal(toks[i], ref[i][0][0])
+
+
+def test_full_830m_ten_rows_match_oracle_on_cpu():
+    """The 5..16-row (matrix-core) decode step at the full 830M shape: 5 utterances x CFG = 10 rows of different lengths in
+    one engine, 6 greedy steps; every utterance's tokens equal the oracle's (run one by one on the CPU) and its post-edit
+    logits agree within 5e-4."""
+    from ssr_speech_amd import layout as LY
+    from ssr_speech_amd.engine import DecodeEngine, DecodeKnobs, LMWeightsArena
+    args = W.lm_args_830m()
+    sd_gpu = W.lm_state_dict(args, seed=0, device="cuda")
+    arena = LMWeightsArena(args, sd_gpu, torch.device("cuda"))
+    sd_cpu = O.reference_params({k: v.cpu() for k, v in sd_gpu.items()})
+    gen = torch.Generator().manual_seed(77)
+    n_utt, steps = 5, 6
+    eng = DecodeEngine(arena, n_utt, True, 256, 64, debug_logits=True)
+    rows, cols, knobs, utts = [], [], [], []
+    for u in range(n_utt):
+        L, N = 20 + 3 * u, 30 + 5 * u
+        x = torch.randint(0, 100, (1, L), generator=gen)
+        y = torch.randint(0, 2048, (1, N, 4), generator=gen)
+        unc = torch.randint(0, 101, (1, L), generator=gen)
+        mi = torch.LongTensor([[[N, N]]])
+        cated, _, num_task, _ = LY.build_layout(y[0].T.numpy(), mi[0].numpy(), args)
+        rows += [x[0].numpy(), unc[0].numpy()]
+        cols.append(cated)
+        knobs.append(DecodeKnobs(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, cfg_coef=1.5, cfg_stride=2, use_cfg=True,
+                                 text_len=L, n_spans=num_task, seed=u))
+        utts.append((x, y, unc, mi))
+    eng.start(rows, cols, knobs, noise=None)
+    eng.decode(steps, use_graph=True)
+    torch.cuda.synchronize()
+    got = eng.generated[:, :steps].cpu().numpy()
+    last = eng.dbg_logits.cpu().numpy()
+    for u, (x, y, unc, mi) in enumerate(utts):
+        trace = {}
+        O.inference(sd_cpu, args, x, y, mi, uncond_x=unc, max_steps=steps, trace=trace, top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2,
+                    kvcache=1, cfg_coef=1.5, cfg_stride=2, aug_text=True)
+        ref_tok = torch.stack(trace["samples"]).numpy()
+        assert np.array_equal(got[u], ref_tok), (u, got[u], ref_tok)
+        err = np.abs(last[u] - torch.stack(trace["edited_logits"]).numpy()[steps - 1]).max()
+        assert err < 5e-4, (u, err)
