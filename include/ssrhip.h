@@ -219,6 +219,10 @@ typedef struct ssrhip_lstm_args {
   float* hbuf; float* cbuf; float* gates;
   int32_t B, T, C;
   int64_t gin_bstride, out_bstride, skip_bstride;   /* element strides between items */
+  /* time window of this call: steps [t_begin, t_end) of the T-step sequence (t_end == 0 means T). t_begin == 0 starts from
+   * h = c = 0; a later window continues from the state the previous call left in hbuf / cbuf. Lets a caller run two stacked
+   * layers as a software pipeline over chunks of steps on two streams (layer 2 chunk i beside layer 1 chunk i+1). */
+  int32_t t_begin, t_end;
 } ssrhip_lstm_args;
 int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stream);
 /* residual vector quantisation (quantization/core_vq.py:164-179, 382-400): emb [B][T][D] time-major;

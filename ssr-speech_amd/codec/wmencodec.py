@@ -250,31 +250,70 @@ class WMEncodecModel:
         h = self._conv(c3, x, None)
         return self._conv(c1, h, nxt, R=x)
 
+    LSTM_CHUNK = 64          # time steps per pipeline stage of the two stacked LSTM layers
+
     def _lstm(self, L: _Lstm, x: TM, nxt) -> TM:
+        """2-layer LSTM + skip (lstm.py:10-25). Each layer: input GEMM over time (MFMA) + one launch per time step. With two
+        layers the recurrences are software-pipelined over chunks of LSTM_CHUNK steps on two streams: layer 2 works on chunk
+        i (its input GEMM for that chunk, then its steps) while layer 1 already runs chunk i+1 — the step kernels are
+        latency-bound and leave most of the GPU idle, so the two chains overlap almost completely."""
         B, T, Cc = x.B, x.T, x.C
         dev = self.device
         assert x.padL == 0 and x.padR == 0
-        gin = torch.empty(B, T, 4 * Cc, dtype=torch.float32, device=dev)
-        hbuf = torch.empty(2, (B + 15) // 16 * 16, Cc, dtype=torch.float32, device=dev)   # include/ssrhip.h ssrhip_lstm_args
-        cbuf = torch.empty(B, Cc, dtype=torch.float32, device=dev)
-        gates = None
-        cur_ptr, cur_bs = x.interior, x.bstride
-        out = None
-        for l, (wih, whh, bias) in enumerate(L.layers):
-            last = l == len(L.layers) - 1
-            self._gemm(cur_ptr, wih, bias, gin.data_ptr(), T, 4 * Cc, Cc, Cc, 4 * Cc, batch=B, sA=cur_bs, sC=T * 4 * Cc)
-            out = self._alloc_for(B, T, Cc, nxt) if last else TM(B, T, Cc, 0, 0, dev)
+        nl = len(L.layers)
+        rows = (B + 15) // 16 * 16                                     # include/ssrhip.h ssrhip_lstm_args
+        gins = [torch.empty(B, T, 4 * Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
+        hbufs = [torch.empty(2, rows, Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
+        cbufs = [torch.empty(B, Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
+        outs = [self._alloc_for(B, T, Cc, nxt) if l == nl - 1 else TM(B, T, Cc, 0, 0, dev) for l in range(nl)]
+
+        def in_gemm(l, t0, t1):                                        # gin_l[:, t0:t1] = in_l[:, t0:t1] W_ih^T + b
+            src_ptr, src_bs = (x.interior, x.bstride) if l == 0 else (outs[l - 1].interior, outs[l - 1].bstride)
+            wih, _, bias = L.layers[l]
+            self._gemm(src_ptr + 4 * t0 * Cc, wih, bias, gins[l].data_ptr() + 4 * t0 * 4 * Cc, t1 - t0, 4 * Cc, Cc, Cc, 4 * Cc,
+                       batch=B, sA=src_bs, sC=T * 4 * Cc)
+
+        def steps(l, t0, t1):
             a = _lib.LstmArgs()
-            a.gin, a.w_hh, a.out = gin.data_ptr(), whh.data_ptr(), out.interior
-            a.skip = x.interior if last else 0                         # y = lstm(x) + x (lstm.py:21-23)
-            a.hbuf, a.cbuf, a.gates = hbuf.data_ptr(), cbuf.data_ptr(), (gates.data_ptr() if gates is not None else 0)
+            a.gin, a.w_hh, a.out = gins[l].data_ptr(), L.layers[l][1].data_ptr(), outs[l].interior
+            a.skip = x.interior if l == nl - 1 else 0                   # y = lstm(x) + x (lstm.py:21-23)
+            a.hbuf, a.cbuf, a.gates = hbufs[l].data_ptr(), cbufs[l].data_ptr(), 0
             a.B, a.T, a.C = B, T, Cc
-            a.gin_bstride, a.out_bstride, a.skip_bstride = T * 4 * Cc, out.bstride, x.bstride
+            a.gin_bstride, a.out_bstride, a.skip_bstride = T * 4 * Cc, outs[l].bstride, x.bstride
+            a.t_begin, a.t_end = t0, t1
             _lib.check(self.lib.ssrhip_lstm_layer(C.byref(a), self._s()), "ssrhip_lstm_layer")
-            cur_ptr, cur_bs = out.interior, out.bstride
+
+        if nl == 2 and T > self.LSTM_CHUNK:
+            main = torch.cuda.current_stream(dev)
+            side = self._side_stream()
+            in_gemm(0, 0, T)
+            ev_done = []
+            for t0 in range(0, T, self.LSTM_CHUNK):
+                t1 = min(t0 + self.LSTM_CHUNK, T)
+                steps(0, t0, t1)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    in_gemm(1, t0, t1)
+                    steps(1, t0, t1)
+                ev_done.append(ev)
+            fin = torch.cuda.Event()
+            fin.record(side)
+            main.wait_event(fin)
+        else:
+            for l in range(nl):
+                in_gemm(l, 0, T)
+                steps(l, 0, T)
+        out = outs[-1]
         self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
-        self._keep = (gin, hbuf, cbuf, gates)
+        self._keep = (gins, hbufs, cbufs, outs)
         return out
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
 
     def _run(self, nodes, x: TM, after=None) -> TM:
         """Run consecutive nodes; `after` = the node that will consume the result (decides its halo)."""

@@ -412,12 +412,14 @@ extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stre
   const int nbt = (a->B + 15) / 16;                                          // 16-item batch tiles (matrix-core path)
   const bool small_b = a->B <= 4 && (a->C == 256 || a->C == 512 || a->C == 1024 || a->C == 2048);
   const size_t hc = small_b ? (size_t)a->B * a->C : (size_t)nbt * 16 * a->C;
-  hipLaunchKernelGGL(zero_kernel, dim3(nblocks(2 * hc)), dim3(256), 0, s, a->hbuf, (long)(2 * hc));   // h_0 = 0
+  const int t_lo = a->t_begin, t_hi = a->t_end > 0 ? a->t_end : a->T;
+  SSR_REQUIRE(t_lo >= 0 && t_lo < t_hi && t_hi <= a->T, "ssrhip_lstm_layer: bad time window [%d, %d) of %d", t_lo, t_hi, a->T);
+  if (t_lo == 0) hipLaunchKernelGGL(zero_kernel, dim3(nblocks(2 * hc)), dim3(256), 0, s, a->hbuf, (long)(2 * hc));   // h_0 = 0
   {
     // small-batch kernel: C in {256, 512, 1024, 2048}; anything else (e.g. the narrow test configs) takes the matrix-core
     // path, which handles any C % 16 == 0 and any B
     if (small_b) {
-      for (int t = 0; t < a->T; ++t) {
+      for (int t = t_lo; t < t_hi; ++t) {
         const float* hp = a->hbuf + (size_t)(t & 1) * hc;
         float* hn = a->hbuf + (size_t)((t + 1) & 1) * hc;
         switch (a->B) {
@@ -432,7 +434,7 @@ extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stre
       const int steps = a->C / 16;
       SSR_REQUIRE(a->C <= 1024, "ssrhip_lstm_layer: the matrix-core path (B > 4, or C not in {256,512,1024,2048}) needs C <= 1024");
       const int nw = (steps + 15) / 16;                        // 256 columns of W_hh per wave -> <= 4 waves
-      for (int t = 0; t < a->T; ++t) {
+      for (int t = t_lo; t < t_hi; ++t) {
         const float* hp = a->hbuf + (size_t)(t & 1) * hc;
         float* hn = a->hbuf + (size_t)((t + 1) & 1) * hc;
         if (nbt >= 2 && nw >= 2) hipLaunchKernelGGL((lstm_step_mfma_kernel<2>), dim3((a->C + 3) / 4, (nbt + 1) / 2), dim3(nw * 64), 0, s, *a, t, hp, hn, nw, steps, nbt);
