@@ -155,3 +155,20 @@ def test_fused_resblock_equals_two_gemm_path(pad_mode):
     torch.testing.assert_close(e1, e0, rtol=0, atol=2e-5)
     torch.testing.assert_close(d1, d0, rtol=0, atol=2e-5)
     assert (c1 != c0).float().mean() < 0.02
+
+
+@pytest.mark.parametrize("B", [2, 6])
+def test_lstm_two_stream_pipeline_equals_sequential_layers(B):
+    """T' = 150 frames > LSTM_CHUNK: the two LSTM layers run chunk-pipelined on two streams (windows of the time axis through
+    ssrhip_lstm_args.t_begin/t_end, ragged last chunk); bit-identical to running layer 1 over all steps, then layer 2."""
+    cfg = W.codec_config_full()
+    sd = W.codec_state_dict(cfg, seed=12)
+    m = WMEncodecModel(cfg, sd, "cuda")
+    g = torch.Generator().manual_seed(4)
+    wav = (torch.randn(B, 1, cfg.hop * 150, generator=g) * 0.2).cuda()
+    c1, _, e1 = m.encode(wav)
+    d1 = m.decode(c1)
+    m.LSTM_CHUNK = 10 ** 9                       # never pipelined
+    c0, _, e0 = m.encode(wav)
+    d0 = m.decode(c1)
+    assert torch.equal(e1, e0) and torch.equal(c1, c0) and torch.equal(d1, d0)
