@@ -1,67 +1,105 @@
-"""`inference_one_sample` — the reference's per-utterance glue (`inference_scale.py:17-88`) with the same positional
-signature: phonemes -> ids, wav -> codes (HIP codec), `model.inference` (HIP decode engine), watermark wav assembly,
-codes -> wav (HIP codec)."""
+"""`inference_one_sample` — one utterance through the whole HIP path: phonemes -> ids, prompt wav -> codec codes,
+AR decode (`SSR_Speech.inference`), codes -> wav (plain or watermarked decode).
+
+Only the positional signature and the returned tensor are the reference's (`inference_scale.py:18`, `:88`; SURVEY §8
+row C1) so that `inference_v2.py`-style drivers can call it unchanged; the body is organised around three stages:
+
+  1. `_phoneme_ids`           text -> LongTensor [1, L]                (ids missing from `phn2num` are dropped, :20-34)
+  2. `_prompt_codes`          wav file -> codes [1, T, K], scale       (:36-38)
+  3. `_render`                generated codes -> waveform [1, 1, n]    (:63-86), using `kept_audio_track` for the
+                              watermark decoder's skip input (:67-78, pinned by tests/golden/glue_watermark.npz)
+"""
 from __future__ import annotations
 
 import logging
 import time
+from typing import Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
 
 from .data.tokenizer import read_wav, tokenize_audio, tokenize_text
 
+HOP = 320          # samples per codec frame at 16 kHz / 50 Hz; the reference hard-codes it (:66, :69, :76, :86)
+log = logging.getLogger(__name__)
 
-def assemble_watermark_wav(wav: torch.Tensor, n_frames: int, masks, ori_masks, hop: int = 320) -> torch.Tensor:
-    """inference_scale.py:67-78: the original audio in the kept regions (moved to their new positions), zeros where
-    audio was generated; `masks` are kept intervals in NEW frame coordinates, `ori_masks` in ORIGINAL coordinates."""
-    new_wav = torch.zeros(1, n_frames * hop)
-    ori = [(max(a, 0), b) for a, b in ori_masks]
-    new = [(max(a, 0), b) for a, b in masks]
-    for i in range(len(ori)):
-        new_wav[:, new[i][0] * hop: new[i][1] * hop] = wav[:, ori[i][0] * hop: ori[i][1] * hop]
-    return new_wav
+
+def _phoneme_ids(text_tokenizer, phn2num: dict, text: str) -> torch.Tensor:
+    ids = [phn2num[p] for p in tokenize_text(text_tokenizer, text=text.strip()) if p in phn2num]
+    return torch.tensor(ids, dtype=torch.long).view(1, -1)
+
+
+def _prompt_codes(audio_tokenizer, audio_fn: str, n_codebooks: int) -> Tuple[torch.Tensor, object]:
+    codes, scale, _emb = tokenize_audio(audio_tokenizer, audio_fn)           # [1, K, T]
+    frames_first = codes.transpose(2, 1)                                     # [1, T, K] as `inference` wants it
+    if frames_first.ndim != 3 or frames_first.shape[0] != 1 or frames_first.shape[2] != n_codebooks:
+        raise AssertionError(tuple(frames_first.shape))
+    return frames_first[..., :n_codebooks], scale
+
+
+def kept_audio_track(wav: torch.Tensor, n_frames: int, kept_new: Sequence, kept_old: Sequence, hop: int = HOP) -> torch.Tensor:
+    """Waveform the watermark decoder's skip-encoder sees: silence where frames were generated, the ORIGINAL audio where
+    frames were kept, moved to where those frames sit in the new utterance (reference `inference_scale.py:67-78`).
+
+    wav       [1, n] original audio, n a multiple of `hop`
+    kept_new  intervals (frame units) of kept audio in the NEW frame axis   (`masks` of `SSR_Speech.inference`)
+    kept_old  the same intervals in the ORIGINAL frame axis                 (`non_mask_intervals`)
+    -> [1, n_frames * hop]
+
+    Done per frame: a gather of whole hop-sized rows, so a kept interval must have the same length on both axes."""
+    if wav.ndim != 2 or wav.shape[0] != 1 or wav.shape[1] % hop:
+        raise ValueError(f"expected mono audio [1, k*{hop}], got {tuple(wav.shape)}")
+    src = wav.reshape(-1, hop)
+    track = torch.zeros(n_frames, hop, dtype=wav.dtype)
+    for (new_a, new_b), (old_a, old_b) in zip(kept_new, kept_old):
+        new_a, old_a = max(int(new_a), 0), max(int(old_a), 0)
+        new_b, old_b = int(new_b), int(old_b)
+        if new_b - new_a != old_b - old_a:
+            raise ValueError(f"kept interval changed length: new [{new_a},{new_b}) vs original [{old_a},{old_b})")
+        if new_b > new_a:
+            track[new_a:new_b] = src[old_a:old_b]
+    return track.reshape(1, n_frames * hop)
+
+
+def _render(audio_tokenizer, codes, marks, kept_new, kept_old, scale, audio_fn, use_watermark: bool) -> torch.Tensor:
+    if not use_watermark:
+        return audio_tokenizer.decode(codes, scale)
+    wav, _sr = read_wav(audio_fn)
+    short = -wav.shape[-1] % HOP                                             # zero-extend to whole frames, like the encode side
+    if short:
+        wav = F.pad(wav, (0, short))
+    track = kept_audio_track(wav, codes.shape[-1], kept_new, kept_old)
+    dev = codes.device
+    return audio_tokenizer.wmdecode(codes, marks.to(dev), track.unsqueeze(0).to(dev), scale)
 
 
 @torch.no_grad()
 def inference_one_sample(model, model_args, phn2num, text_tokenizer, audio_tokenizer, audio_fn, prompt_text, target_text, mask_interval,
                          cfg_coef, cfg_stride, aug_text, aug_context, use_watermark, tts, device, decode_config):
-    # phonemize (inference_scale.py:20-34): phonemes missing from phn2num are silently dropped
-    text_tokens = [phn2num[phn] for phn in tokenize_text(text_tokenizer, text=target_text.strip()) if phn in phn2num]
-    text_tokens = torch.LongTensor(text_tokens).unsqueeze(0)
-    text_tokens_lens = torch.LongTensor([text_tokens.shape[-1]])
-    prompt_text_tokens = [phn2num[phn] for phn in tokenize_text(text_tokenizer, text=prompt_text.strip()) if phn in phn2num]
-    prompt_text_tokens = torch.LongTensor(prompt_text_tokens).unsqueeze(0)
-    prompt_text_tokens_lens = torch.LongTensor([prompt_text_tokens.shape[-1]])
+    """Positional signature of the reference (`inference_scale.py:18`). `aug_context` is accepted and — exactly as in the
+    reference, which never forwards it (:42-58) — not handed to `model.inference`. Returns the waveform [1, 1, n]; for
+    `tts` the prompt part (the first kept interval) is cut off (:85-86)."""
+    K = int(model_args.n_codebooks)
+    target_ids = _phoneme_ids(text_tokenizer, phn2num, target_text)
+    prompt_ids = _phoneme_ids(text_tokenizer, phn2num, prompt_text)
+    prompt_frames, scale = _prompt_codes(audio_tokenizer, audio_fn, K)
+    rate = decode_config["codec_sr"]
+    log.info("prompt: %d codec frames (%.2f s), %d target phonemes", prompt_frames.shape[1], prompt_frames.shape[1] / rate, target_ids.shape[1])
 
-    encoded_frames, scale, emb = tokenize_audio(audio_tokenizer, audio_fn)
-    original_audio = encoded_frames.transpose(2, 1)  # [1,T,K]
-    assert original_audio.ndim == 3 and original_audio.shape[0] == 1 and original_audio.shape[2] == model_args.n_codebooks, original_audio.shape
-    logging.info(f"with direct encodec encoding before input, original audio length: {original_audio.shape[1]} codec frames, "
-                 f"which is {original_audio.shape[1] / decode_config['codec_sr']:.2f} sec.")
-
-    stime = time.time()
-    encoded_frames, marks, masks, ori_masks = model.inference(
-        text_tokens.to(device), text_tokens_lens.to(device), prompt_text_tokens.to(device), prompt_text_tokens_lens.to(device),
-        original_audio[..., :model_args.n_codebooks].to(device), original_audio[..., :model_args.n_codebooks].to(device),
-        mask_interval=mask_interval.unsqueeze(0).to(device), top_k=decode_config['top_k'], top_p=decode_config['top_p'],
-        temperature=decode_config['temperature'], stop_repetition=decode_config['stop_repetition'], kvcache=decode_config['kvcache'],
+    t0 = time.perf_counter()
+    on_dev = lambda t: t.to(device)
+    result = model.inference(
+        on_dev(target_ids), on_dev(torch.tensor([target_ids.shape[1]])), on_dev(prompt_ids), on_dev(torch.tensor([prompt_ids.shape[1]])),
+        on_dev(prompt_frames), on_dev(prompt_frames), mask_interval=on_dev(mask_interval.unsqueeze(0)),
+        top_k=decode_config["top_k"], top_p=decode_config["top_p"], temperature=decode_config["temperature"],
+        stop_repetition=decode_config["stop_repetition"], kvcache=decode_config["kvcache"],
         cfg_coef=cfg_coef, cfg_stride=cfg_stride, aug_text=aug_text)
-    logging.info(f"inference on one sample take: {time.time() - stime:.4f} sec.")
-    if type(encoded_frames) == tuple:
-        encoded_frames = encoded_frames[0]
-    logging.info(f"generated encoded_frames.shape: {encoded_frames.shape}, which is {encoded_frames.shape[-1] / decode_config['codec_sr']} sec.")
+    codes, marks, kept_new, kept_old = result
+    if isinstance(codes, tuple):                                             # tolerated by the reference too (:60-61)
+        codes = codes[0]
+    log.info("AR decode: %.3f s for %d frames (%.2f s of audio)", time.perf_counter() - t0, codes.shape[-1], codes.shape[-1] / rate)
 
-    if use_watermark:
-        multiple = 320
-        wav, sr = read_wav(audio_fn)
-        padding_length = (multiple - (wav.shape[-1] % multiple)) % multiple
-        if padding_length > 0:
-            wav = F.pad(wav, (0, padding_length), "constant", 0)
-        new_wav = assemble_watermark_wav(wav, encoded_frames.shape[-1], masks, ori_masks, 320)
-        generated_sample = audio_tokenizer.wmdecode(encoded_frames, marks.to(encoded_frames.device), new_wav.unsqueeze(0).to(encoded_frames.device), scale)
-    else:
-        generated_sample = audio_tokenizer.decode(encoded_frames, scale)
+    wave = _render(audio_tokenizer, codes, marks, kept_new, kept_old, scale, audio_fn, bool(use_watermark))
     if tts:
-        generated_sample = generated_sample[:, :, masks[0][1] * 320:]
-    return generated_sample
+        wave = wave[..., int(kept_new[0][1]) * HOP:]
+    return wave

@@ -51,7 +51,6 @@ def test_inference_one_sample_matches_oracle(tmp_path, tts, use_watermark):
     # oracle: same steps on the CPU
     import torch.nn.functional as F
     from ssr_speech_amd.data.tokenizer import read_wav
-    from ssr_speech_amd.inference_scale import assemble_watermark_wav
     w16, _ = read_wav(fn)
     w16 = F.pad(w16, (0, (320 - w16.shape[-1] % 320) % 320))
     codes, _, _ = OC.encode(csd, w16.unsqueeze(0), ccfg)
@@ -62,7 +61,9 @@ def test_inference_one_sample_matches_oracle(tmp_path, tts, use_watermark):
     res, marks, masks, ori = O.inference(O.reference_params(lsd), args, x, got_codes.cpu().transpose(2, 1), mi.unsqueeze(0), top_k=1, top_p=1.0,
                                          temperature=1, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=2, aug_text=True)
     if use_watermark:
-        new_wav = assemble_watermark_wav(w16, res.shape[-1], masks, ori, 320)
+        new_wav = torch.zeros(1, res.shape[-1] * 320)         # the test's own statement of inference_scale.py:67-78 (pinned by test_glue.py)
+        for (na, nb), (oa, ob) in zip(masks, ori):
+            new_wav[:, max(na, 0) * 320: nb * 320] = w16[:, max(oa, 0) * 320: ob * 320]
         ref_wav, _ = OC.wmdecode(csd, res, marks, new_wav.unsqueeze(0), ccfg)
     else:
         ref_wav = OC.decode(csd, res, ccfg)
@@ -70,6 +71,46 @@ def test_inference_one_sample_matches_oracle(tmp_path, tts, use_watermark):
         ref_wav = ref_wav[:, :, masks[0][1] * 320:]
     assert out.shape == ref_wav.shape
     np.testing.assert_allclose(out.cpu().numpy(), ref_wav.numpy(), rtol=0, atol=5e-4)
+
+
+class RecordingTokenizer:
+    """Same double as oracle/make_golden_glue.py: fixed codes in, remembers what the glue hands to the codec."""
+    sample_rate, channels = 16000, 1
+
+    def __init__(self, codes):
+        self.codes, self.calls = codes, []
+
+    def encode(self, wav):
+        return self.codes, None, None
+
+    def wmdecode(self, frames, marks, wav, scale):
+        self.calls.append((frames.cpu(), marks.cpu(), wav.cpu()))
+        return torch.arange(frames.shape[-1] * 320, dtype=torch.float32).view(1, 1, -1)
+
+
+@pytest.mark.parametrize("name", ["tts", "edit_mid", "edit_start", "edit_two"])
+def test_glue_hands_the_codec_what_the_reference_glue_does(tmp_path, name):
+    """the REAL reference `inference_one_sample` (around the real tiny reference LM) recorded the frames, marks
+    and re-assembled waveform it passed to `wmdecode` and the --tts cut; the HIP LM + this package's glue must hand over the
+    identical tensors (greedy decode: bit-exact) — tests/golden/glue_watermark.npz."""
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "glue_watermark.npz"))
+    args = W.lm_args_tiny()
+    m = SSR_Speech(args)
+    m.load_state_dict(W.lm_state_dict(args, seed=int(G[f"{name}_torch_seed"])))
+    m = m.to("cuda").eval()
+    fn = str(tmp_path / "p.wav")
+    write_wav(fn, torch.from_numpy(G[f"{name}_wav"]), 16000)
+    tok = RecordingTokenizer(torch.from_numpy(G[f"{name}_codes"]))
+    phn2num = {c: i for i, c in enumerate("abcdefghijklmnopqrstuvwxyz")}
+    decode_config = {"top_k": 1, "top_p": 1.0, "temperature": 1, "stop_repetition": 2, "kvcache": 1, "codec_audio_sr": 16000, "codec_sr": 50}
+    torch.manual_seed(int(G[f"{name}_torch_seed"]))
+    out = inference_one_sample(m, argparse.Namespace(**vars(args)), phn2num, FakePhonemizer(), tok, fn, "hello world", "hello world again and again",
+                               torch.from_numpy(G[f"{name}_mask_interval"]), 1.5, 2, True, False, True, bool(G[f"{name}_tts"]), "cuda", decode_config)
+    frames, marks, new_wav = tok.calls[-1]
+    np.testing.assert_array_equal(frames.numpy(), G[f"{name}_frames"])
+    np.testing.assert_array_equal(marks.numpy(), G[f"{name}_marks"])
+    np.testing.assert_array_equal(new_wav.numpy(), G[f"{name}_new_wav"])
+    assert int(out[0, 0, 0]) == int(G[f"{name}_sample_first"]) and out.shape[-1] == int(G[f"{name}_sample_len"])
 
 
 def test_encode_driver_writes_reference_format(tmp_path, monkeypatch):

@@ -10,7 +10,7 @@ import torch
 import ssr_speech_amd  # noqa: F401
 from ssr_speech_amd import inference_v2 as CLI
 from ssr_speech_amd.data import tokenizer as TK
-from ssr_speech_amd.inference_scale import assemble_watermark_wav
+from ssr_speech_amd.inference_scale import kept_audio_track
 
 
 def test_cli_flag_surface_matches_reference(golden_dir):
@@ -57,7 +57,7 @@ def test_watermark_wav_assembly():
     wav = torch.arange(8 * hop, dtype=torch.float32).unsqueeze(0)
     masks = [(0, 3), (7, 10)]          # kept intervals, new coordinates
     ori = [(0, 3), (5, 8)]             # kept intervals, original coordinates
-    out = assemble_watermark_wav(wav, 10, masks, ori, hop)
+    out = kept_audio_track(wav, 10, masks, ori, hop)
     assert out.shape == (1, 40)
     assert torch.equal(out[0, :12], wav[0, :12]) and torch.equal(out[0, 28:40], wav[0, 20:32]) and out[0, 12:28].abs().sum() == 0
 
