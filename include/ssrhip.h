@@ -145,7 +145,10 @@ typedef struct ssrhip_sampler_cfg {     /* per utterance, device memory, read-on
   int32_t n_spans;         /* num_task */
   int32_t empty_token, eog, eos, sos, mts, max_n_spans;
   int32_t max_steps;       /* capacity of `generated` per utterance */
-  uint32_t seed_lo, seed_hi; /* on-device RNG stream when noise==NULL */
+  uint32_t seed_lo, seed_hi; /* on-device RNG stream when noise==NULL or use_noise==0 */
+  int32_t use_noise;       /* 1: take the multinomial's Exp(1) draws from `noise` (host-drawn, reproduces torch's CPU stream);
+                              0: on-device hash RNG. Lets one engine keep ONE persistent noise buffer (stable pointer, no graph
+                              re-capture) whether or not a given generation uses it. */
 } ssrhip_sampler_cfg;
 
 typedef struct ssrhip_sampler_state {   /* per utterance, device memory, mutated every step */

@@ -40,11 +40,16 @@ CASES = [
     ("tiny_odd", W.codec_config_tiny, "constant", 1, 48 * 5 + 7, 33),        # not a hop multiple: extra-padding rule
     ("full_const_1s", W.codec_config_full, "constant", 1, 16000, 34),
     ("full_reflect_short", W.codec_config_full, "reflect", 1, 320 * 12, 35),
+    # inputs shorter than the reflect pad at several layers (conv.py:79-83: zero-extend, reflect, cut) — 2 samples, and a
+    # single-frame decode whose k=7 convolutions see T=1
+    ("tiny_reflect_veryshort", W.codec_config_tiny, "reflect", 2, 2, 36),
 ]
 
 
-def main(gold):
+def main(gold, only=None):
     for name, mk, pad_mode, B, n, seed in CASES:
+        if only and name not in only:
+            continue
         cfg = mk()
         cfg.pad_mode = pad_mode
         m, sd = ref_model(cfg, seed)
@@ -82,4 +87,4 @@ def main(gold):
 
 
 if __name__ == "__main__":
-    main(os.path.join(ROOT, "tests", "golden"))
+    main(os.path.join(ROOT, "tests", "golden"), only=sys.argv[1:] or None)

@@ -68,7 +68,7 @@ class SamplerCfg(C.Structure):
                 ("text_len", C.c_int32), ("n_spans", C.c_int32),
                 ("empty_token", C.c_int32), ("eog", C.c_int32), ("eos", C.c_int32), ("sos", C.c_int32),
                 ("mts", C.c_int32), ("max_n_spans", C.c_int32), ("max_steps", C.c_int32),
-                ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32)]
+                ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32), ("use_noise", C.c_int32)]
 
 
 class SamplerState(C.Structure):

@@ -183,8 +183,6 @@ class WMEncodecModel:
 
     def _fill_pads(self, buf: TM, structural_zero: bool = False):
         if self.cfg.pad_mode == "reflect" and not structural_zero and (buf.padL + buf.padR) > 0:
-            if buf.T <= max(buf.padL, buf.padR):
-                raise NotImplementedError("reflect padding of an input shorter than the pad (conv.py:79-83 zero-extension) is not implemented")
             _lib.check(self.lib.ssrhip_pad_reflect(buf.base, buf.B, buf.T, buf.padL, buf.padR, buf.C, buf.bstride, self._s()), "ssrhip_pad_reflect")
         elif self.cfg.pad_mode not in ("constant", "reflect"):
             raise ValueError(self.cfg.pad_mode)

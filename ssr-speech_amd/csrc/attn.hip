@@ -12,6 +12,8 @@
 // Replaces F.scaled_dot_product_attention (models/modules/activation.py:634); the additive mask the
 // reference builds (models/ssr.py:227-255) is exactly "row r sees positions < row_len[r]".
 #include <stdlib.h>
+#include <algorithm>
+using std::min;
 #include "common.h"
 
 namespace {
@@ -175,12 +177,32 @@ int check(const ssrhip_attn_args* a, const char* who) {
 
 }  // namespace
 
+// gridDim.z / gridDim.y carry the row index and are limited to 65535: longer row lists (a 16-row prefill has ~4k rows per
+// sequence) are issued in slices of at most 65535 rows, each slice seeing its own sub-arrays.
+static ssrhip_attn_args row_slice(const ssrhip_attn_args& a, int r0, int n) {
+  ssrhip_attn_args s = a;
+  const size_t H = a.kv.n_head, HD = a.kv.head_dim;
+  s.q = a.q + (size_t)r0 * (a.q_stride ? a.q_stride : H * HD);
+  s.row_seq = a.row_seq + r0;
+  s.row_len = a.row_len + r0;
+  s.part_o = a.part_o + (size_t)r0 * H * a.max_splits * HD;
+  s.part_ml = a.part_ml + (size_t)r0 * H * a.max_splits * 2;
+  s.R = n;
+  return s;
+}
+enum { MAX_GRID_ROWS = 65535 };
+
 extern "C" int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t stream) {
   if (int e = check(a, "ssrhip_attn_decode")) return e;
-  dim3 grid(a->max_splits, a->kv.n_head, a->R);
-  if (a->kv.head_dim == 128) hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-  else hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-  SSR_LAUNCH_CHECK();
+  SSR_REQUIRE(a->R <= MAX_GRID_ROWS || a->row_seq, "ssrhip_attn_decode: more than %d rows need an explicit row_seq", MAX_GRID_ROWS);
+  for (int r0 = 0; r0 < a->R; r0 += MAX_GRID_ROWS) {
+    const int n = min(a->R - r0, (int)MAX_GRID_ROWS);
+    const ssrhip_attn_args s = a->R <= MAX_GRID_ROWS ? *a : row_slice(*a, r0, n);
+    dim3 grid(s.max_splits, s.kv.n_head, n);
+    if (s.kv.head_dim == 128) hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, s);
+    else hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, s);
+    SSR_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -188,9 +210,21 @@ extern "C" int ssrhip_attn_combine(const ssrhip_attn_args* a, float* out, ssrhip
   if (int e = check(a, "ssrhip_attn_combine")) return e;
   SSR_REQUIRE(out, "ssrhip_attn_combine: out is null");
   SSR_REQUIRE(!a->out_tiled || a->R <= 16, "ssrhip_attn_combine: tiled output needs R <= 16");
-  SSR_REQUIRE(a->R <= 65535, "ssrhip_attn_combine: R too large");
-  if (a->kv.head_dim == 128) hipLaunchKernelGGL(attn_combine_kernel<128>, dim3((a->kv.n_head + 1) / 2, a->R), dim3(64), 0, (hipStream_t)stream, *a, out);
-  else hipLaunchKernelGGL(attn_combine_kernel<64>, dim3((a->kv.n_head + 3) / 4, a->R), dim3(64), 0, (hipStream_t)stream, *a, out);
-  SSR_LAUNCH_CHECK();
+  const size_t D = (size_t)a->kv.n_head * a->kv.head_dim;
+  for (int r0 = 0; r0 < a->R; r0 += MAX_GRID_ROWS) {
+    const int n = min(a->R - r0, (int)MAX_GRID_ROWS);
+    ssrhip_attn_args s = *a;
+    float* o = out;
+    if (a->R > MAX_GRID_ROWS) {            // the combine never reads q / row_seq: only the per-row arrays move
+      s.row_len = a->row_len + r0;
+      s.part_o = a->part_o + (size_t)r0 * a->kv.n_head * a->max_splits * a->kv.head_dim;
+      s.part_ml = a->part_ml + (size_t)r0 * a->kv.n_head * a->max_splits * 2;
+      s.R = n;
+      o = out + (size_t)r0 * D;
+    }
+    if (s.kv.head_dim == 128) hipLaunchKernelGGL(attn_combine_kernel<128>, dim3((s.kv.n_head + 1) / 2, n), dim3(64), 0, (hipStream_t)stream, s, o);
+    else hipLaunchKernelGGL(attn_combine_kernel<64>, dim3((s.kv.n_head + 3) / 4, n), dim3(64), 0, (hipStream_t)stream, s, o);
+    SSR_LAUNCH_CHECK();
+  }
   return 0;
 }

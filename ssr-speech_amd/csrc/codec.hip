@@ -29,15 +29,23 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* x, const fl
   }
 }
 
-__global__ __launch_bounds__(256) void pad_reflect_kernel(float* buf, int T, int padL, int padR, int C, long bstride) {
+// Reflect padding with the reference's small-input rule (audiocraft/modules/conv.py:71-88): an input no longer than the larger
+// pad is first zero-extended on the right by `extra = max_pad - T + 1` samples, reflected, and the last `extra` samples of
+// the result are dropped again. x' = [x, 0 * extra], T' = T + extra; a halo row takes x'[i] (zero when i >= T).
+__global__ __launch_bounds__(256) void pad_reflect_kernel(float* buf, int T, int padL, int padR, int C, long bstride, int extra) {
   float* b = buf + (size_t)blockIdx.y * bstride;
   const long total = (long)(padL + padR) * C;
+  const int Tx = T + extra;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int p = (int)(i / C), c = (int)(i % C);
-    int dst, src;
-    if (p < padL) { dst = p; src = padL + (padL - p); }                       // interior index (padL - p), edge excluded
-    else { const int r = p - padL; dst = padL + T + r; src = padL + (T - 2 - r); }
-    b[(size_t)dst * C + c] = b[(size_t)src * C + c];
+    int dst, src;                                                             // src: index into x'
+    if (p < padL) { dst = p; src = padL - p; }                                // edge excluded
+    else {
+      const int r = p - padL;
+      dst = padL + T + r;
+      src = (T + r < Tx) ? T + r : Tx - 2 - (T + r - Tx);                     // still inside the zero extension, else mirrored
+    }
+    b[(size_t)dst * C + c] = (src < T) ? b[(size_t)(padL + src) * C + c] : 0.f;
   }
 }
 
@@ -397,10 +405,11 @@ extern "C" int ssrhip_conv_cin1(const float* x, const float* w, const float* bia
 
 extern "C" int ssrhip_pad_reflect(float* buf, int32_t B, int32_t T, int32_t padL, int32_t padR, int32_t C, int64_t bstride, ssrhip_stream_t stream) {
   SSR_REQUIRE(buf && B > 0 && T > 0 && C > 0 && padL >= 0 && padR >= 0, "ssrhip_pad_reflect: bad argument");
-  SSR_REQUIRE(T > padL && T > padR, "ssrhip_pad_reflect: reflect padding needs T (%d) > pads (%d,%d)", T, padL, padR);
   if (padL + padR == 0) return 0;
+  const int max_pad = padL > padR ? padL : padR;
+  const int extra = T <= max_pad ? max_pad - T + 1 : 0;                       // conv.py:79-83
   dim3 grid(nblocks((long)(padL + padR) * C), B);
-  hipLaunchKernelGGL(pad_reflect_kernel, grid, dim3(256), 0, (hipStream_t)stream, buf, T, padL, padR, C, (long)bstride);
+  hipLaunchKernelGGL(pad_reflect_kernel, grid, dim3(256), 0, (hipStream_t)stream, buf, T, padL, padR, C, (long)bstride, extra);
   SSR_LAUNCH_CHECK();
   return 0;
 }

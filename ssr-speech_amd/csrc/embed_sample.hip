@@ -469,7 +469,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(const ssrhip_sam
   // ---- multinomial(softmax, 1) == argmax(prob / q), q ~ Exp(1)   (torch CPU fast path; :85).
   // The positive normaliser does not change the argmax, so it is dropped.
   {
-    const float* nz = a.noise ? a.noise + (((size_t)u * c_maxsteps + step) * K + kc) * card : nullptr;
+    const float* nz = (a.noise && c.use_noise) ? a.noise + (((size_t)u * c_maxsteps + step) * K + kc) * card : nullptr;
     const uint32_t sd = hash32(c_seedlo + (uint32_t)step * 0x9E3779B1u) ^ hash32(c_seedhi + (uint32_t)kc * 0x85EBCA6Bu + 0x632BE5ABu);
     float best = -1.f;
     int bi = 0x7fffffff;

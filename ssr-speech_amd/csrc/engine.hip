@@ -194,6 +194,9 @@ extern "C" int ssrhip_lm_create(const ssrhip_lm_dims* d, const ssrhip_lm_weights
   SSR_REQUIRE(b->B == 1 || b->B == 2 || b->B == 4 || (b->B >= 5 && b->B <= 16), "ssrhip_lm_create: B=%d rows not in {1,2,4,5..16}", b->B);
   SSR_REQUIRE(b->B <= 4 || d->ln_folded, "ssrhip_lm_create: B > 4 rows needs LayerNorm gamma/beta folded into the weights (ln_folded)");
   SSR_REQUIRE(d->n_codebooks <= SSRHIP_MAX_CODEBOOKS, "ssrhip_lm_create: too many codebooks");
+  // a row's text and audio positions are both below its sequence capacity: the sinusoidal table must cover it (embed reads pe[pos])
+  SSR_REQUIRE((int64_t)b->kv.max_pages * SSRHIP_PAGE <= d->max_pos, "ssrhip_lm_create: sequence capacity %lld exceeds the position table (%d rows)",
+              (long long)b->kv.max_pages * SSRHIP_PAGE, d->max_pos);
   ssrhip_lm* lm = new ssrhip_lm();
   lm->d = *d; lm->w = *w; lm->b = *b;
   // deep-copy the per-layer pointer arrays (the caller's ctypes arrays may be temporaries)

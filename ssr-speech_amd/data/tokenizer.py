@@ -42,6 +42,15 @@ def codec_config_from_xp_cfg(cfg) -> CodecConfig:
     cm = _cfg_get(cfg, "compression_model", "wmencodec")
     if cm != "wmencodec":
         raise KeyError(f"Unexpected compression model {cm}")          # builders.py:114
+    # Architecture switches this implementation does not have: refuse them instead of silently producing wrong audio / codes
+    # (the reference ships e.g. config/model/encodec/encodec_base_causal.yaml). Absent keys mean the reference's defaults.
+    fixed = [("encodec.causal", False), ("seanet.causal", False), ("encodec.renormalize", False), ("seanet.true_skip", True),
+             ("seanet.norm", "weight_norm"), ("seanet.activation", "ELU"), ("seanet.dilation_base", 2), ("seanet.final_activation", None),
+             ("seanet.n_residual_layers", 1), ("seanet.disable_norm_outer_blocks", 0)]
+    for key, want in fixed:
+        got = _cfg_get(cfg, key, want)
+        if got != want and not (want is None and got in ("", "null", "None")):
+            raise NotImplementedError(f"codec checkpoint has {key}={got!r}; ssr_speech_amd implements {key}={want!r} only")
     ratios = _cfg_get(cfg, "seanet.ratios", [8, 5, 4, 2])
     return CodecConfig(
         channels=int(_cfg_get(cfg, "channels", 1)), dimension=int(_cfg_get(cfg, "seanet.dimension", 128)),

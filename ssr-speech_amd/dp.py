@@ -23,6 +23,17 @@ def utterance_seed(seed: int, global_index: int) -> int:
     return int(seed) + int(global_index)
 
 
+def _collective_device(hint=None) -> torch.device:
+    """Device the collective's buffers must live on. It is a property of the BACKEND, not of this rank's data: under nccl
+    (RCCL) every rank must pass GPU tensors even when its own shard is empty (fewer utterances than ranks)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    if hint is not None and torch.device(hint).type == "cuda" and dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        return torch.device("cpu")        # gloo collectives run on host buffers
+    return torch.device(hint) if hint is not None else torch.device("cpu")
+
+
 def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token: int, device=None) -> List[torch.Tensor]:
     """local[i]: int tensor [K, T_i] of this rank's utterances (rank-contiguous shard of `n_total`).
     Returns the list of all `n_total` token tensors on every rank. One all_gather of lengths (n ints per
@@ -32,7 +43,7 @@ def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token
         return [t.clone() for t in local]
     world, rank = dist.get_world_size(), dist.get_rank()
     if device is None:
-        device = local[0].device if len(local) else torch.device("cpu")
+        device = _collective_device(local[0].device if len(local) else None)
     n_max = (n_total + world - 1) // world
     lens = torch.zeros(n_max, dtype=torch.int32, device=device)
     for i, t in enumerate(local):
@@ -71,5 +82,5 @@ def generate(model, utterances: Sequence[dict], seed: int = 0, pad_token: int = 
         pad_token = int(model.args.empty_token)
     toks = [o[0][0] for o in outs]                                   # res [1, K, T'] -> [K, T']
     if device is None:
-        device = toks[0].device if toks else torch.device("cpu")
+        device = _collective_device(getattr(model, "device", None))
     return gather_tokens(toks, len(utterances), K, pad_token, device=device), (lo, hi, outs)

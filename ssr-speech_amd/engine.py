@@ -68,6 +68,7 @@ class LMWeightsArena:
         self.alpha_text = float(sd["text_positional_embedding.alpha"].reshape(-1)[0])
         self.alpha_audio = float(sd["audio_positional_embedding.alpha"].reshape(-1)[0])
         self.pe = sine_pe_table(max_pos, self.D).to(**f32).contiguous()
+        self.generation = 0     # bumped whenever a device pointer handed to an engine changes (engines re-create their ctx)
         # LayerNorm's affine part is folded into the Linear that follows it (one-time repack at load):
         #   Linear(LN(x)) = W (gamma * xhat + beta) + b = (W diag(gamma)) xhat + (b + W beta),  xhat = (x - mean) * rstd
         # so the decode GEMV only standardises x (in registers, no gamma/beta traffic); ln*_w / ln*_b become ones / zeros.
@@ -96,6 +97,17 @@ class LMWeightsArena:
         self.head1_b = (h1b.double() + h1w.double() @ bet.double()).to(torch.float32).contiguous()
         self.head2_w = torch.stack([g(f"predict_layer.{k}.2.weight") for k in range(self.K)]).contiguous()
         self.head2_b = torch.stack([g(f"predict_layer.{k}.2.bias") for k in range(self.K)]).contiguous()
+
+    def ensure_positions(self, n: int) -> bool:
+        """Grow the sinusoidal table so that positions [0, n) exist, like `SinePositionalEmbedding.extend_pe` does on demand
+        (models/modules/embedding.py:66-92: no length limit in the reference). Returns True when the table was rebuilt
+        (its device pointer changed: engines built on the old one must be discarded)."""
+        if n <= self.max_pos:
+            return False
+        self.max_pos = ((int(n) + 4095) // 4096) * 4096
+        self.pe = sine_pe_table(self.max_pos, self.D).to(dtype=torch.float32, device=self.device).contiguous()
+        self.generation += 1
+        return True
 
     def nbytes_per_step(self) -> int:
         """Algorithmic weight bytes one decode step must stream."""
@@ -129,6 +141,49 @@ class LMWeightsArena:
 MAX_ROWS = 16   # gemv_mfma.hip: one 16-column MFMA tile
 
 
+class TorchCpuNoiseFeed:
+    """The Exp(1) tensors `torch.multinomial(probs[K, card], 1)` draws on the CPU — one `exponential_` of the logits' shape per
+    decode step (reference models/ssr.py:85 via :713/:732; checked in oracle/make_golden.py::make_sampler) — produced a chunk of
+    steps at a time so that the host draws for steps [s, s+n) while the GPU decodes the previous chunk. One contiguous
+    `[n, K, card].exponential_()` consumes the generator exactly like n successive per-step draws (tests/test_noise_feed.py).
+
+    generators[u] is utterance u's `torch.Generator`, or None for the global CPU generator (what the reference uses).
+    `finish(u, n_taken)` puts that generator in the state it has after exactly `n_taken` per-step draws, i.e. where the
+    reference leaves it — chunks drawn ahead of the stop are un-drawn."""
+
+    def __init__(self, generators, K: int, card: int):
+        self.gens = list(generators)
+        self.K, self.card = K, card
+        self.marks = [[] for _ in self.gens]      # per utterance: (first step of the chunk, generator state before drawing it)
+        self.drawn = [0] * len(self.gens)
+
+    def _get(self, u):
+        g = self.gens[u]
+        return torch.get_rng_state() if g is None else g.get_state()
+
+    def _set(self, u, st):
+        g = self.gens[u]
+        if g is None:
+            torch.set_rng_state(st)
+        else:
+            g.set_state(st)
+
+    def draw(self, u: int, out: torch.Tensor):
+        """Fill `out` [n, K, card] (CPU, may be pinned) with the draws of the next n steps of utterance u."""
+        self.marks[u].append((self.drawn[u], self._get(u)))
+        out.exponential_(1, generator=self.gens[u])
+        self.drawn[u] += out.shape[0]
+
+    def finish(self, u: int, n_taken: int):
+        if n_taken >= self.drawn[u]:
+            return
+        s0, st = [m for m in self.marks[u] if m[0] <= n_taken][-1]
+        self._set(u, st)
+        if n_taken > s0:
+            torch.empty(n_taken - s0, self.K, self.card).exponential_(1, generator=self.gens[u])
+        self.drawn[u] = n_taken
+
+
 class DecodeEngine:
     """B rows (= n_utt x (2 if CFG else 1)) decoded in lock-step; one captured hipGraph per engine."""
 
@@ -145,6 +200,7 @@ class DecodeEngine:
             raise ValueError(f"rows B={self.B} not supported by this build (1, 2, 4 or 5..{MAX_ROWS})")
         self.max_pages = (max_seq + PAGE - 1) // PAGE
         self.max_seq = self.max_pages * PAGE
+        arena.ensure_positions(self.max_seq)      # every text / audio position of a row is < its sequence capacity
         self.max_steps = max_steps
         D, H, L, K = arena.D, arena.H, arena.L, arena.K
         self.hd = D // H
@@ -167,11 +223,15 @@ class DecodeEngine:
         self.cfg_dev = torch.zeros(n_utt * C.sizeof(_lib.SamplerCfg), dtype=torch.uint8, device=dev)
         self.state_dev = torch.zeros(n_utt * C.sizeof(_lib.SamplerState), dtype=torch.uint8, device=dev)
         self.generated = torch.zeros(n_utt, max_steps, K, **i32)
-        self.noise = None
+        # ONE persistent buffer for host-drawn sampling noise: its pointer is baked into the captured graph, so generations
+        # with / without host noise reuse the same context (ssrhip_sampler_cfg.use_noise selects per utterance)
+        self.noise = torch.empty(n_utt, max_steps, K, arena.card, **f32)
+        self._pinned = None
+        self._copy_stream = None
+        self._arena_gen = arena.generation
         self.dbg_logits = torch.zeros(n_utt, K, arena.card, **f32) if debug_logits else None
         self._w = arena.c_struct()
         self._ctx = None
-        self._noise_ptr = 0
 
     # ------------------------------------------------------------------ C structs
     def kv_struct(self):
@@ -189,14 +249,13 @@ class DecodeEngine:
         b.kv_pos, b.row_len = self.kv_pos.data_ptr(), self.row_len.data_ptr()
         b.kv = self.kv_struct()
         b.cfg, b.state = self.cfg_dev.data_ptr(), self.state_dev.data_ptr()
-        b.noise = self.noise.data_ptr() if self.noise is not None else 0
+        b.noise = self.noise.data_ptr()
         b.generated = self.generated.data_ptr()
         b.dbg_logits = self.dbg_logits.data_ptr() if self.dbg_logits is not None else 0
         d = self.a.dims()
         ctx = C.c_void_p()
         _lib.check(self.lib.ssrhip_lm_create(C.byref(d), C.byref(self._w), C.byref(b), C.byref(ctx)), "ssrhip_lm_create")
         self._ctx = ctx
-        self._noise_ptr = b.noise
 
     def close(self):
         if self._ctx is not None:
@@ -211,10 +270,13 @@ class DecodeEngine:
 
     # ------------------------------------------------------------------ set-up of one generation
     def start(self, text_rows: List[np.ndarray], audio_cols: List[np.ndarray], knobs: List[DecodeKnobs],
-              noise: Optional[torch.Tensor] = None):
+              noise: Optional[torch.Tensor] = None, host_noise: bool = False):
         """text_rows[b]: int array [L_b] (row b's text ids); audio_cols[u]: int array [K, T0_u]
         (layout-built prompt columns, WITHOUT the mask token that starts generation);
-        knobs[u]. Runs the prefill and arms the decode state."""
+        knobs[u]. Runs the prefill and arms the decode state.
+
+        Sampling noise: `noise` [n_utt, steps, K, card] (any device) is copied into the engine's buffer now; `host_noise=True`
+        promises that `run_to_completion(feed=...)` will stream it in chunk by chunk; neither = on-device RNG (knobs.seed)."""
         a, dev = self.a, self.device
         K = a.K
         assert len(text_rows) == self.B and len(audio_cols) == self.n_utt and len(knobs) == self.n_utt
@@ -261,15 +323,24 @@ class DecodeEngine:
             c.empty_token, c.eog, c.eos, c.sos = int(args.empty_token), int(args.eog), int(args.eos), int(args.sos)
             c.mts, c.max_n_spans, c.max_steps = int(args.mts), int(args.max_n_spans), int(self.max_steps)
             c.seed_lo, c.seed_hi = int(kn.seed) & 0xFFFFFFFF, (int(kn.seed) >> 32) & 0xFFFFFFFF
+            c.use_noise = int(noise is not None or host_noise)
             s = sts[u]
             s.span, s.num_gen, s.num_eog, s.num_cfg_tag, s.prev_token, s.consec_silence = 0, 0, 0, 1, -1, 0
             s.audio_pos = int(np.asarray(audio_cols[u]).shape[1])
             s.n_steps, s.done = 0, 0
         self.cfg_dev.copy_(torch.frombuffer(bytearray(bytes(cfgs)), dtype=torch.uint8))
         self.state_dev.copy_(torch.frombuffer(bytearray(bytes(sts)), dtype=torch.uint8))
-        self.noise = noise
-        want_noise = noise.data_ptr() if noise is not None else 0
-        if self._ctx is None or want_noise != self._noise_ptr:
+        if noise is not None:
+            assert noise.dim() == 4 and noise.shape[0] == self.n_utt and tuple(noise.shape[2:]) == (K, a.card), noise.shape
+            n = min(noise.shape[1], self.max_steps)
+            self.noise[:, :n].copy_(noise[:, :n].to(torch.float32), non_blocking=True)
+            if n < self.max_steps:
+                self.noise[:, n:].fill_(1.0)          # steps past the supplied draws: a defined value, never uninitialised memory
+        if self._arena_gen != a.generation:          # the arena re-allocated a table (position table grown): refresh the pointers
+            self._w = a.c_struct()
+            self._arena_gen = a.generation
+            self.close()
+        if self._ctx is None:
             self._create_ctx()
 
         # first decode input of every row: the span-0 mask token at audio position T0 (ssr.py:655-662)
@@ -307,16 +378,61 @@ class DecodeEngine:
         arr = (_lib.SamplerState * self.n_utt).from_buffer_copy(raw)
         return list(arr)
 
-    def run_to_completion(self, chunk: int = 16, use_graph: bool = True, max_total: Optional[int] = None):
+    def run_to_completion(self, chunk: int = 16, use_graph: bool = True, max_total: Optional[int] = None,
+                          feed: Optional[TorchCpuNoiseFeed] = None):
+        """Decode in chunks of `chunk` steps until every utterance reports done (the flags are polled once per chunk).
+        With `feed`, the host draws the NEXT chunk's sampling noise into pinned memory and uploads it on a copy stream while
+        the GPU runs the current chunk (a 16-step chunk is ~14 ms of GPU time at 830M; its draws ~3 ms of host time)."""
         total = 0
         limit = self.max_steps if max_total is None else min(max_total, self.max_steps)
+        dev = self.device
+        main = torch.cuda.current_stream(dev) if feed is not None else None
+        live = [True] * self.n_utt
+        ready = None
+        if feed is not None:
+            K, card = self.a.K, self.a.card
+            if self._pinned is None or self._pinned[0].shape[1] != chunk:
+                self._pinned = [torch.empty(self.n_utt, chunk, K, card, dtype=torch.float32).pin_memory() for _ in range(2)]
+                self._copy_stream = torch.cuda.Stream(dev)
+            slot_free = [None, None]
+
+            def stage(ci: int, s0: int, s1: int):
+                """draw + upload the noise of steps [s0, s1) (chunk index ci); returns the event the decode must wait for"""
+                buf = self._pinned[ci & 1]
+                if slot_free[ci & 1] is not None:
+                    slot_free[ci & 1].synchronize()            # the upload that last used this staging slot has finished
+                for u in range(self.n_utt):
+                    if live[u]:
+                        feed.draw(u, buf[u, : s1 - s0])
+                with torch.cuda.stream(self._copy_stream):
+                    self.noise[:, s0:s1].copy_(buf[:, : s1 - s0], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy_stream)
+                slot_free[ci & 1] = ev
+                return ev
+
+            ready = stage(0, 0, min(chunk, limit))             # overlaps with the prefill `start()` enqueued
+        ci = 0
+        states = None
         while total < limit:
             n = min(chunk, limit - total)
+            if ready is not None:
+                main.wait_event(ready)
             self.decode(n, use_graph)
             total += n
-            if all(s.done for s in self.states()):
+            if feed is not None and total < limit:
+                ready = stage(ci + 1, total, min(total + chunk, limit))      # host works while the GPU decodes chunk ci
+            ci += 1
+            states = self.states()                              # blocks until chunk ci-1 has finished
+            live = [not s_.done for s_ in states]
+            if not any(live):
                 break
-        return self.states()
+        if states is None:
+            states = self.states()
+        if feed is not None:
+            for u, s_ in enumerate(states):
+                feed.finish(u, int(s_.n_steps))
+        return states
 
     def time_kernels(self, n_steps: int):
         """Event-timed eager steps: list of (kind, avg_us) per launch slot of one decode step

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import layout as LY
-from ..engine import MAX_ROWS, DecodeEngine, DecodeKnobs, LMWeightsArena
+from ..engine import MAX_ROWS, DecodeEngine, DecodeKnobs, LMWeightsArena, TorchCpuNoiseFeed
 from ..weights import lm_param_specs
 
 
@@ -102,6 +102,10 @@ class SSR_Speech(nn.Module):
             self._arena = LMWeightsArena(self.args, self.state_dict(), dev)
         cap_seq = ((need_seq + 1023) // 1024) * 1024
         cap_steps = ((need_steps + 255) // 256) * 256
+        if self._arena.ensure_positions(cap_seq):      # long text / long utterances: grow the position table (reference: extend_pe)
+            for e in self._engines.values():
+                e.close()
+            self._engines = {}
         key = (n_utt, use_cfg, cap_seq, cap_steps, bool(self.debug_logits))
         eng = self._engines.get(key)
         if eng is None:
@@ -197,22 +201,18 @@ class SSR_Speech(nn.Module):
         knobs = DecodeKnobs(top_k=top_k, top_p=top_p, temperature=temperature, stop_repetition=stop_repetition,
                             silence_tokens=tuple(int(s) for s in silence_tokens), cfg_coef=cfg_coef, cfg_stride=cfg_stride,
                             use_cfg=bool(aug_text), text_len=L, n_spans=num_task, seed=int(torch.initial_seed()))
-        noise_dev = None
         greedy = top_k == 1
+        feed = None
         if noise is not None:
-            nz = torch.ones(1, eng.max_steps, K, eng.a.card, dtype=torch.float32)
-            n = min(noise.shape[0], eng.max_steps)
-            nz[0, :n] = noise[:n].to(torch.float32).cpu()
-            noise_dev = nz.to(dev)
+            eng.start(text_rows, [cated], [knobs], noise=noise.to(torch.float32).unsqueeze(0))
         elif not greedy:
-            # reproduce the reference's CPU sampling stream: torch.multinomial(probs[K,card], 1) draws
-            # one Exp(1) tensor of that shape per step from the global generator
-            nz = torch.empty(1, eng.max_steps, K, eng.a.card, dtype=torch.float32)
-            for s in range(min(cap, eng.max_steps)):
-                nz[0, s].exponential_(1)
-            noise_dev = nz.to(dev)
-        eng.start(text_rows, [cated], [knobs], noise=noise_dev)
-        states = eng.run_to_completion(chunk=16, use_graph=use_graph, max_total=cap)
+            # reproduce the reference's CPU sampling stream: torch.multinomial(probs[K,card], 1) draws one Exp(1) tensor of that
+            # shape per step from the global generator (after the uncond_x draw above) — streamed in 16 steps at a time beside the decode
+            feed = TorchCpuNoiseFeed([None], K, eng.a.card)
+            eng.start(text_rows, [cated], [knobs], host_noise=True)
+        else:
+            eng.start(text_rows, [cated], [knobs])
+        states = eng.run_to_completion(chunk=16, use_graph=use_graph, max_total=cap, feed=feed)
         st = states[0]
         gen = eng.generated[0, : st.n_steps].cpu().numpy().astype(np.int64)
         self.last_run = dict(steps=st.n_steps, done=st.done, span_end=list(st.span_end), prefill_rows=(L + T0) * (2 if aug_text else 1))
@@ -260,16 +260,17 @@ class SSR_Speech(nn.Module):
             while n_u * rows == 3:                 # 3 rows is the one unsupported count: pad the group with a copy of the last one
                 chunk = chunk + [chunk[-1]]
                 n_u += 1
-            text_rows, audio_cols, knobs, metas, noises = [], [], [], [], []
+            text_rows, audio_cols, knobs, metas, gens = [], [], [], [], []
             cap_max, seq_max = 1, 1
             for j, u in enumerate(chunk):
                 gi = first_index + g0 + min(j, len(utterances) - g0 - 1)
-                torch.manual_seed(seed + gi)       # same stream as a batch-1 run of this utterance
+                rng = torch.Generator().manual_seed(seed + gi)      # same stream as `torch.manual_seed(seed + gi)` + a batch-1 run
+                gens.append(rng)
                 x_np = u["x"].detach().cpu().numpy().astype(np.int64)
                 L = x_np.shape[1]
                 text_rows.append(x_np[0])
                 if aug_text:
-                    text_rows.append(torch.randint(0, self.n_text_tokens, (1, L)).numpy().astype(np.int64)[0])     # ssr.py:574
+                    text_rows.append(torch.randint(0, self.n_text_tokens, (1, L), generator=rng).numpy().astype(np.int64)[0])     # ssr.py:574
                 y_np = u["y"][0].transpose(1, 0).detach().cpu().numpy().astype(np.int64)
                 mi = u["mask_interval"][0].detach().cpu().numpy().astype(np.int64)
                 cated, mask_position, num_task, nmi = LY.build_layout(y_np, mi, self.args)
@@ -281,20 +282,11 @@ class SSR_Speech(nn.Module):
                                          silence_tokens=tuple(int(s) for s in silence_tokens), cfg_coef=cfg_coef, cfg_stride=cfg_stride,
                                          use_cfg=bool(aug_text), text_len=L, n_spans=num_task, seed=seed + gi))
                 metas.append((y_np, nmi, num_task, cap))
-                if not greedy:
-                    nz = torch.empty(cap, K, self.n_audio_tokens[0], dtype=torch.float32)
-                    for s_ in range(cap):
-                        nz[s_].exponential_(1)     # the Exp(1) tensors torch.multinomial would draw, in order
-                    noises.append(nz)
             eng = self._get_engine(n_u, bool(aug_text), seq_max, cap_max)
-            noise_dev = None
-            if not greedy:
-                nzall = torch.ones(n_u, eng.max_steps, K, eng.a.card, dtype=torch.float32)
-                for j, nz in enumerate(noises):
-                    nzall[j, : nz.shape[0]] = nz
-                noise_dev = nzall.to(dev)
-            eng.start(text_rows, audio_cols, knobs, noise=noise_dev)
-            states = eng.run_to_completion(chunk=16, use_graph=use_graph, max_total=cap_max)
+            # sampling: every utterance's own generator feeds its Exp(1) draws (what torch.multinomial would consume), chunk by chunk
+            feed = None if greedy else TorchCpuNoiseFeed(gens, K, eng.a.card)
+            eng.start(text_rows, audio_cols, knobs, host_noise=not greedy)
+            states = eng.run_to_completion(chunk=16, use_graph=use_graph, max_total=cap_max, feed=feed)
             for j in range(min(n_u, len(utterances) - g0)):
                 st = states[j]
                 if st.done != 1:
