@@ -141,6 +141,43 @@ class LMWeightsArena:
 MAX_ROWS = 16   # gemv_mfma.hip: one 16-column MFMA tile
 
 
+class PagePool:
+    """Host-side allocator of the paged KV cache's physical pages (replaces the dense `past` tensor the reference re-concatenates
+    every step, models/ssr.py:685-686 / modules/activation.py:626-631). A free list; pages are handed to a row when its
+    sequence is about to cross into a new 128-position page and go back when its utterance is done. `order` fixes the order
+    in which an untouched pool hands pages out (tests pass a shuffled one; the kernels only ever see the table)."""
+
+    def __init__(self, n_pages: int, order: Optional[Sequence[int]] = None):
+        self.n_pages = int(n_pages)
+        order = list(range(self.n_pages)) if order is None else [int(p) for p in order]
+        if sorted(order) != list(range(self.n_pages)):
+            raise ValueError("page order must be a permutation of range(n_pages)")
+        self._order = order
+        self.reset()
+
+    def reset(self):
+        self._free = self._order[::-1]          # pop() hands out order[0] first
+        self._owner = {}
+
+    @property
+    def n_free(self) -> int:
+        return len(self._free)
+
+    def take(self, owner) -> int:
+        if not self._free:
+            raise RuntimeError(f"KV page pool exhausted ({self.n_pages} pages of {PAGE} positions): raise pool_pages")
+        p = self._free.pop()
+        self._owner[p] = owner
+        return p
+
+    def give_back(self, pages: Sequence[int]):
+        for p in pages:
+            if p not in self._owner:
+                raise RuntimeError(f"page {p} returned twice (or never taken)")
+            del self._owner[p]
+            self._free.append(p)
+
+
 class TorchCpuNoiseFeed:
     """The Exp(1) tensors `torch.multinomial(probs[K, card], 1)` draws on the CPU — one `exponential_` of the logits' shape per
     decode step (reference models/ssr.py:85 via :713/:732; checked in oracle/make_golden.py::make_sampler) — produced a chunk of
@@ -187,7 +224,11 @@ class TorchCpuNoiseFeed:
 class DecodeEngine:
     """B rows (= n_utt x (2 if CFG else 1)) decoded in lock-step; one captured hipGraph per engine."""
 
-    def __init__(self, arena: LMWeightsArena, n_utt: int, use_cfg: bool, max_seq: int, max_steps: int, debug_logits: bool = False):
+    def __init__(self, arena: LMWeightsArena, n_utt: int, use_cfg: bool, max_seq: int, max_steps: int, debug_logits: bool = False,
+                 pool_pages: Optional[int] = None, page_order: Optional[Sequence[int]] = None):
+        """max_seq: longest sequence (text + audio positions) any ONE row may reach; pool_pages: physical KV pages shared by all
+        rows (default rows x pages-per-row, the no-sharing worst case; a batch of short and long utterances needs only the sum
+        of their own page counts)."""
         self.lib = _lib.lib()
         self.a = arena
         dev = arena.device
@@ -206,9 +247,16 @@ class DecodeEngine:
         self.hd = D // H
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
-        n_pages = self.B * self.max_pages
-        self.kv_pool = torch.empty(n_pages * L * 2 * H * PAGE * self.hd, **f32)
-        self.page_table = torch.arange(n_pages, **i32).view(self.B, self.max_pages).contiguous()
+        n_pages = self.B * self.max_pages if pool_pages is None else int(pool_pages)
+        self.pages = PagePool(n_pages, page_order)
+        self.scratch_page = n_pages              # one extra page: where the rows of a FINISHED utterance keep (harmlessly) writing
+        self.kv_pool = torch.empty((n_pages + 1) * L * 2 * H * PAGE * self.hd, **f32)
+        self.page_table = torch.full((self.B, self.max_pages), self.scratch_page, **i32)
+        self._table_host = np.full((self.B, self.max_pages), self.scratch_page, dtype=np.int32)
+        self._row_pages: List[List[int]] = [[] for _ in range(self.B)]
+        self._kv0 = [0] * self.B                 # sequence length of each row after the prefill
+        self._steps_enqueued = 0
+        self._utt_live = [False] * n_utt
         rows = self.B if self.B <= 4 else MAX_ROWS      # > 4 rows: x / q / h are 16-column tiled buffers (include/ssrhip.h SSRHIP_TILED)
         self.x = torch.zeros(rows, D, **f32)
         self.q = torch.zeros(rows, D, **f32)
@@ -298,6 +346,14 @@ class DecodeEngine:
             seqs.append(np.full(Lb + T0, b, dtype=np.int32))
             rposs.append(np.arange(Lb + T0, dtype=np.int32))
             kv0.append(Lb + T0)
+        # KV pages: everything back to the pool, then each row gets the pages its prompt (+ the first decoded position) needs
+        self.pages.reset()
+        self._table_host[:] = self.scratch_page
+        self._row_pages = [[] for _ in range(self.B)]
+        self._kv0 = list(kv0)
+        self._steps_enqueued = 0
+        self._utt_live = [True] * self.n_utt
+        self._grow_pages(0)
         tok = torch.from_numpy(np.concatenate(toks)).to(dev)
         pos = torch.from_numpy(np.concatenate(poss)).to(dev)
         kind = torch.from_numpy(np.concatenate(kinds)).to(dev)
@@ -369,8 +425,45 @@ class DecodeEngine:
         self._keep = (tok, pos, kind, seq, rpos, rlen, ws)   # alive until the stream has consumed them
         return R
 
+    # ------------------------------------------------------------------ KV page bookkeeping
+    def _grow_pages(self, steps_ahead: int):
+        """Make sure every row of a live utterance owns the pages for positions [0, kv0 + steps_ahead] (the decode step at
+        sequence length S appends position S), round-robin over rows so that concurrent rows interleave in the pool, then
+        push the table if it changed. Ordered on the caller's stream before the launches that need it."""
+        want = [0] * self.B
+        for b in range(self.B):
+            if self._utt_live[b // self.rows_per_utt]:
+                want[b] = min((self._kv0[b] + steps_ahead) // PAGE + 1, self.max_pages)
+        changed = False
+        more = True
+        while more:
+            more = False
+            for b in range(self.B):
+                have = len(self._row_pages[b])
+                if have < want[b]:
+                    p = self.pages.take(b)
+                    self._row_pages[b].append(p)
+                    self._table_host[b, have] = p
+                    changed = more = True
+        if changed:
+            self.page_table.copy_(torch.from_numpy(self._table_host))       # pageable source: staged before this call returns
+
+    def release_utterance(self, u: int):
+        """Utterance u is done: its rows' pages go back to the pool and the rows are pointed at the scratch page (they stay in
+        the lock-step batch and keep appending at a frozen position; nothing reads what they produce)."""
+        if not self._utt_live[u]:
+            return
+        self._utt_live[u] = False
+        for b in range(u * self.rows_per_utt, (u + 1) * self.rows_per_utt):
+            self.pages.give_back(self._row_pages[b])
+            self._row_pages[b] = []
+            self._table_host[b, :] = self.scratch_page
+        self.page_table.copy_(torch.from_numpy(self._table_host))
+
     # ------------------------------------------------------------------ decode
     def decode(self, n_steps: int, use_graph: bool = True):
+        self._steps_enqueued += int(n_steps)
+        self._grow_pages(self._steps_enqueued)
         _lib.check(self.lib.ssrhip_lm_decode(self._ctx, int(n_steps), int(use_graph), _lib.stream_ptr()), "ssrhip_lm_decode")
 
     def states(self) -> List[_lib.SamplerState]:
@@ -425,6 +518,9 @@ class DecodeEngine:
             ci += 1
             states = self.states()                              # blocks until chunk ci-1 has finished
             live = [not s_.done for s_ in states]
+            for u in range(self.n_utt):
+                if not live[u]:
+                    self.release_utterance(u)
             if not any(live):
                 break
         if states is None:
@@ -437,6 +533,8 @@ class DecodeEngine:
     def time_kernels(self, n_steps: int):
         """Event-timed eager steps: list of (kind, avg_us) per launch slot of one decode step
         (kind: 'gemv' | 'attn' | 'sample')."""
+        self._steps_enqueued += int(n_steps)
+        self._grow_pages(self._steps_enqueued)
         n_out = 8 * self.a.L + 16
         us = (C.c_float * n_out)()
         kind = (C.c_int32 * n_out)()
@@ -451,6 +549,9 @@ class DecodeEngine:
         Leaves the hidden-state buffers dirty: `start()` again before decoding."""
         us = C.c_float()
         n = C.c_int32()
+        if kind == "sample":                     # the sampler advances the positions on every replay (3 warm-up replays inside)
+            self._steps_enqueued += int(n_replays) + 3
+            self._grow_pages(self._steps_enqueued)
         _lib.check(self.lib.ssrhip_lm_time_category(self._ctx, ("gemv", "attn", "sample").index(kind), int(n_replays),
                                                     _lib.stream_ptr(), C.byref(us), C.byref(n)), "ssrhip_lm_time_category")
         return float(us.value), int(n.value)

@@ -74,6 +74,32 @@ def _render(audio_tokenizer, codes, marks, kept_new, kept_old, scale, audio_fn, 
 
 
 @torch.no_grad()
+def inference_samples(model, model_args, phn2num, text_tokenizer, audio_tokenizer, audio_fn, prompt_text, target_text, mask_interval,
+                      cfg_coef, cfg_stride, aug_text, aug_context, use_watermark, tts, device, decode_config, seeds):
+    """`--sample_batch_size N` in one pass: the N samples of ONE utterance (seeds `seeds[i]`) decoded in lock-step through
+    `SSR_Speech.inference_batch`, so the weights stream once per step for all of them (the reference loops them one after the
+    other, `inference_v2.py:331-358`). Sample i is bit-identical to `inference_one_sample` called after
+    `torch.manual_seed(seeds[i])`: the prompt is encoded once (it is the same for every sample) and every sample keeps its
+    own RNG stream. `seeds` must be consecutive integers. Returns the list of waveforms [1, 1, n_i]."""
+    seeds = [int(s) for s in seeds]
+    assert seeds == list(range(seeds[0], seeds[0] + len(seeds))), "seeds must be consecutive (seed + sample index)"
+    K = int(model_args.n_codebooks)
+    target_ids = _phoneme_ids(text_tokenizer, phn2num, target_text)
+    prompt_frames, scale = _prompt_codes(audio_tokenizer, audio_fn, K)
+    one = {"x": target_ids, "y": prompt_frames, "mask_interval": mask_interval.unsqueeze(0)}
+    t0 = time.perf_counter()
+    results = model.inference_batch([one] * len(seeds), top_k=decode_config["top_k"], top_p=decode_config["top_p"],
+                                    temperature=decode_config["temperature"], stop_repetition=decode_config["stop_repetition"],
+                                    cfg_coef=cfg_coef, cfg_stride=cfg_stride, aug_text=aug_text, seed=seeds[0])
+    log.info("AR decode of %d samples in lock-step: %.3f s", len(seeds), time.perf_counter() - t0)
+    waves = []
+    for codes, marks, kept_new, kept_old in results:
+        wave = _render(audio_tokenizer, codes, marks, kept_new, kept_old, scale, audio_fn, bool(use_watermark))
+        waves.append(wave[..., int(kept_new[0][1]) * HOP:] if tts else wave)
+    return waves
+
+
+@torch.no_grad()
 def inference_one_sample(model, model_args, phn2num, text_tokenizer, audio_tokenizer, audio_fn, prompt_text, target_text, mask_interval,
                          cfg_coef, cfg_stride, aug_text, aug_context, use_watermark, tts, device, decode_config):
     """Positional signature of the reference (`inference_scale.py:18`). `aug_context` is accepted and — exactly as in the

@@ -92,7 +92,7 @@ def main(argv=None):
     args = parse_args(argv)
     seed_everything(args.seed)
     from .data.tokenizer import AudioTokenizer, TextTokenizer, read_wav, write_wav
-    from .inference_scale import inference_one_sample
+    from .inference_scale import inference_one_sample, inference_samples
     from .models.ssr import SSR_Speech
 
     device = "cuda" if torch.cuda.is_available() else "cpu"
@@ -144,13 +144,18 @@ def main(argv=None):
     decode_config = {"top_k": args.top_k, "top_p": args.top_p, "temperature": args.temperature, "stop_repetition": args.stop_repetition,
                      "kvcache": args.kvcache, "codec_audio_sr": args.codec_audio_sr, "codec_sr": args.codec_sr}
     shutil.copyfile(audio_fn, os.path.join(args.output_dir, f"{args.savename}_orig.wav"))   # :357-358 (the prompt actually used)
-    for num in range(args.sample_batch_size):                                        # :331-358
-        seed_everything(args.seed + num)
-        new_audio = inference_one_sample(model, argparse.Namespace(**config), phn2num, text_tokenizer, audio_tokenizer, audio_fn,
-                                         prompt_text, target_text, mask_interval, args.cfg_coef, args.cfg_stride, args.aug_text,
-                                         args.aug_context, args.use_watermark, args.tts, device, decode_config)
-        out = os.path.join(args.output_dir, f"{args.savename}_new_seed{args.seed + num}.wav")
-        write_wav(out, new_audio[0].cpu(), args.codec_audio_sr)
+    common = (model, argparse.Namespace(**config), phn2num, text_tokenizer, audio_tokenizer, audio_fn, prompt_text, target_text, mask_interval,
+              args.cfg_coef, args.cfg_stride, args.aug_text, args.aug_context, args.use_watermark, args.tts, device, decode_config)
+    seeds = [args.seed + num for num in range(args.sample_batch_size)]               # :331-332: sample `num` runs under seed + num
+    if len(seeds) > 1:
+        # all samples of the utterance in ONE lock-step decode (same outputs as the reference's sequential loop :331-358)
+        seed_everything(seeds[-1])
+        waves = inference_samples(*common, seeds=seeds)
+    else:
+        seed_everything(seeds[0])
+        waves = [inference_one_sample(*common)]
+    for s_, new_audio in zip(seeds, waves):
+        write_wav(os.path.join(args.output_dir, f"{args.savename}_new_seed{s_}.wav"), new_audio[0].cpu(), args.codec_audio_sr)
     print(f"Running time: {time.time() - start_time:.4f} s")                         # :360-363
 
 

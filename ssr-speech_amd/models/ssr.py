@@ -63,6 +63,7 @@ class SSR_Speech(nn.Module):
         self._arena: Optional[LMWeightsArena] = None
         self._engines: Dict[tuple, DecodeEngine] = {}
         self.debug_logits = False          # tests: keep the per-step post-edit logits
+        self.page_order = None             # tests: permutation deciding which physical KV pages the allocator hands out first
         self.last_run: dict = {}
 
     # ------------------------------------------------------------------ nn.Module plumbing
@@ -93,7 +94,7 @@ class SSR_Speech(nn.Module):
                                   "scope of ssr_speech_amd: only the inference hot path is implemented.")
 
     # ------------------------------------------------------------------ engine management
-    def _get_engine(self, n_utt: int, use_cfg: bool, need_seq: int, need_steps: int) -> DecodeEngine:
+    def _get_engine(self, n_utt: int, use_cfg: bool, need_seq: int, need_steps: int, need_pages: Optional[int] = None) -> DecodeEngine:
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("ssr_speech_amd.SSR_Speech.inference needs the model on a ROCm GPU (model.to('cuda')); "
@@ -106,13 +107,22 @@ class SSR_Speech(nn.Module):
             for e in self._engines.values():
                 e.close()
             self._engines = {}
-        key = (n_utt, use_cfg, cap_seq, cap_steps, bool(self.debug_logits))
+        rows = n_utt * (2 if use_cfg else 1)
+        # KV pool: `need_pages` = sum over rows of the pages each row can reach (short and long utterances share one pool);
+        # rounded up so that similar batches reuse the engine; never more than rows x pages-per-row
+        pool = rows * (cap_seq // 128)
+        if need_pages is not None:
+            pool = min(pool, ((int(need_pages) + 7) // 8) * 8)
+        key = (n_utt, use_cfg, cap_seq, cap_steps, bool(self.debug_logits), pool, tuple(self.page_order) if self.page_order is not None else None)
         eng = self._engines.get(key)
         if eng is None:
             for e in self._engines.values():     # one engine (KV pool) resident at a time
                 e.close()
             self._engines = {}
-            eng = DecodeEngine(self._arena, n_utt, use_cfg, cap_seq, cap_steps, debug_logits=self.debug_logits)
+            order = None
+            if self.page_order is not None:      # tests: a caller-chosen hand-out order of the physical pages
+                order = [p for p in self.page_order if p < pool] if len(self.page_order) >= pool else None
+            eng = DecodeEngine(self._arena, n_utt, use_cfg, cap_seq, cap_steps, debug_logits=self.debug_logits, pool_pages=pool, page_order=order)
             self._engines[key] = eng
         return eng
 
@@ -261,7 +271,7 @@ class SSR_Speech(nn.Module):
                 chunk = chunk + [chunk[-1]]
                 n_u += 1
             text_rows, audio_cols, knobs, metas, gens = [], [], [], [], []
-            cap_max, seq_max = 1, 1
+            cap_max, seq_max, pages_sum = 1, 1, 0
             for j, u in enumerate(chunk):
                 gi = first_index + g0 + min(j, len(utterances) - g0 - 1)
                 rng = torch.Generator().manual_seed(seed + gi)      # same stream as `torch.manual_seed(seed + gi)` + a batch-1 run
@@ -277,12 +287,13 @@ class SSR_Speech(nn.Module):
                 T0 = cated.shape[1]
                 cap = max(10 * L + 2 - T0, 1) + num_task * (K + 1)
                 cap_max, seq_max = max(cap_max, cap), max(seq_max, L + T0 + cap + 8)
+                pages_sum += rows * ((L + T0 + cap + 16) // 128 + 1)      # + the 16-step chunk the allocator provisions ahead
                 audio_cols.append(cated)
                 knobs.append(DecodeKnobs(top_k=top_k, top_p=top_p, temperature=temperature, stop_repetition=stop_repetition,
                                          silence_tokens=tuple(int(s) for s in silence_tokens), cfg_coef=cfg_coef, cfg_stride=cfg_stride,
                                          use_cfg=bool(aug_text), text_len=L, n_spans=num_task, seed=seed + gi))
                 metas.append((y_np, nmi, num_task, cap))
-            eng = self._get_engine(n_u, bool(aug_text), seq_max, cap_max)
+            eng = self._get_engine(n_u, bool(aug_text), seq_max, cap_max, need_pages=pages_sum)
             # sampling: every utterance's own generator feeds its Exp(1) draws (what torch.multinomial would consume), chunk by chunk
             feed = None if greedy else TorchCpuNoiseFeed(gens, K, eng.a.card)
             eng.start(text_rows, audio_cols, knobs, host_noise=not greedy)

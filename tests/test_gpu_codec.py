@@ -13,6 +13,7 @@ import ssr_speech_amd  # noqa: F401
 from ssr_speech_amd import weights as W
 from ssr_speech_amd.codec.wmencodec import WMEncodecModel
 from oracle import codec as OC
+from helpers_codec import code_margins
 
 pytestmark = pytest.mark.gpu
 ATOL = 2e-4
@@ -25,21 +26,6 @@ def load_case(golden_dir, name):
     cfg = W.CodecConfig(dimension=c[0], n_filters=c[1], bins=c[2], n_q=c[3], ratios=tuple(c[4:]), pad_mode=str(g["pad_mode"]))
     sd = W.codec_state_dict(cfg, seed=int(g["weight_seed"]))
     return g, cfg, sd
-
-
-def code_margins(sd, cfg, emb, codes):
-    """top-1 minus top-2 score of every RVQ decision along the reference's own residual path."""
-    B, D, T = emb.shape
-    res = emb.clone()
-    out = torch.zeros(B, cfg.n_q, T)
-    for q in range(cfg.n_q):
-        E = sd[f"quantizer.vq.layers.{q}._codebook.embed"]
-        x = res.permute(0, 2, 1).reshape(-1, D)
-        dist = -(x.pow(2).sum(1, keepdim=True) - 2 * x @ E.t() + E.t().pow(2).sum(0, keepdim=True))
-        top2 = dist.topk(2, dim=-1).values
-        out[:, q] = (top2[:, 0] - top2[:, 1]).view(B, T)
-        res = res - torch.nn.functional.embedding(codes[:, q], E).permute(0, 2, 1)
-    return out
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -65,8 +51,16 @@ def test_codec_matches_reference(golden_dir, name):
     np.testing.assert_allclose(mark.cpu().numpy(), g["mark"], rtol=0, atol=ATOL)
     out2, none = m.wmdecode(ref_codes.cuda(), torch.from_numpy(g["labels"]).cuda(), torch.from_numpy(g["wav_pad"]).cuda(), with_mark=False)
     assert none is None and torch.equal(out2, out)
+    # detect_watermark (wmencodec.py:377-382) argmaxes the detector output [B,2,T'] over TIME (its squeeze(-1) is a no-op): values
+    # must equal the reference's, except where the reference's own two largest entries along time are an fp32 near-tie
     det = m.detect_watermark(torch.from_numpy(g["wmdecoded"]).cuda())
-    assert tuple(det.shape) == g["detect"].shape
+    assert tuple(det.shape) == g["detect"].shape and det.dtype == torch.int64
+    ref_det = g["detect"]
+    bad = det.cpu().numpy() != ref_det
+    if bad.any():
+        per_class = np.moveaxis(g["mark"], 1, 2)                     # [B, 2, T']
+        top2 = np.sort(per_class, axis=-1)[..., -2:]
+        assert ((top2[..., 1] - top2[..., 0])[bad] < 2 * ATOL).all(), (det.cpu().numpy(), ref_det)
 
 
 def test_codec_roundtrip_shapes_and_errors():
@@ -155,6 +149,37 @@ def test_fused_resblock_equals_two_gemm_path(pad_mode):
     torch.testing.assert_close(e1, e0, rtol=0, atol=2e-5)
     torch.testing.assert_close(d1, d0, rtol=0, atol=2e-5)
     assert (c1 != c0).float().mean() < 0.02
+
+
+@pytest.mark.parametrize("B", [6, 20])
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+def test_large_batch_kernels_match_the_oracle_directly(B, pad_mode):
+    """The kernels only batches > 4 reach — `lstm_step_mfma` (16-item batch tiles; B=20: two tiles, the second ragged), the
+    fused residual blocks and the batched strided-view GEMMs — against oracle/codec.py itself (not against this package's
+    small-batch path): full config, both pad modes, ragged length. Every item of the batch is checked."""
+    import dataclasses
+    cfg = dataclasses.replace(W.codec_config_full(), pad_mode=pad_mode)
+    sd = W.codec_state_dict(cfg, seed=13)
+    m = WMEncodecModel(cfg, sd, "cuda")
+    g = torch.Generator().manual_seed(5)
+    wav = torch.randn(B, 1, cfg.hop * 11 + 129, generator=g) * 0.2
+    codes, _, emb = m.encode(wav.cuda())
+    o_codes, _, o_emb = OC.encode(sd, wav, cfg)
+    np.testing.assert_allclose(emb.cpu().numpy(), o_emb.numpy(), rtol=0, atol=ATOL)
+    diff = codes.cpu() != o_codes
+    if diff.any():
+        marg = code_margins(sd, cfg, o_emb, o_codes)
+        first = diff.float().cumsum(1) == 1
+        assert (marg[diff & first] < 1e-4).all(), (int(diff.sum()), marg[diff & first])
+    dec = m.decode(o_codes.cuda())
+    np.testing.assert_allclose(dec.cpu().numpy(), OC.decode(sd, o_codes, cfg).numpy(), rtol=0, atol=ATOL)
+    T = o_codes.shape[-1]
+    labels = (torch.arange(T).unsqueeze(0).repeat(B, 1) % 3 == 0).long()
+    wav_pad = torch.nn.functional.pad(wav, (0, T * cfg.hop - wav.shape[-1]))
+    out, mark = m.wmdecode(o_codes.cuda(), labels.cuda(), wav_pad.cuda())
+    o_out, o_mark = OC.wmdecode(sd, o_codes, labels, wav_pad, cfg)
+    np.testing.assert_allclose(out.cpu().numpy(), o_out.numpy(), rtol=0, atol=ATOL)
+    np.testing.assert_allclose(mark.cpu().numpy(), o_mark.numpy(), rtol=0, atol=ATOL)
 
 
 @pytest.mark.parametrize("B", [2, 6])

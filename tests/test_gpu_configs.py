@@ -1,0 +1,153 @@
+"""GPU: BASELINE.json's configurations at their STATED shapes, each against the oracle on this box's CPU
+plus size-independent properties:
+
+  config 2   830M, L=130 phonemes, 160-frame prompt, cfg_stride=5, top_k=40 / top_p=0.8 sampling — tokens identical to the
+             oracle's under the same seed (the sampler consumes torch's CPU stream), 20 steps.
+  config 4   830M, 8 utterances x CFG = 16 rows of different lengths in one engine (the per-GPU shard of the 64-utterance batch).
+  config 5   wmencodec encode + decode of randn(256, 1, 480000) * 0.1 on ONE GPU: shapes, finiteness, code range, the
+             decode_latent round trip, and three clips cut from the batch compared with the oracle.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import ssr_speech_amd  # noqa: F401
+from ssr_speech_amd import weights as W
+from ssr_speech_amd.models.ssr import SSR_Speech
+from oracle import codec as OC, lm as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _model_830m():
+    args = W.lm_args_830m()
+    sd_gpu = W.lm_state_dict(args, seed=0, device="cuda")
+    m = SSR_Speech(args)
+    m.load_state_dict({k: v.cpu() for k, v in sd_gpu.items()})
+    sd_cpu = O.reference_params({k: v.cpu() for k, v in sd_gpu.items()})
+    return args, m.to("cuda").eval(), sd_gpu, sd_cpu
+
+
+def test_config2_830m_sampled_top_k40_top_p08_matches_oracle():
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    args, m, _, sd_cpu = _model_830m()
+    gen = torch.Generator().manual_seed(2024)
+    L, N, steps = 130, 160, 20
+    x = torch.randint(0, 100, (1, L), generator=gen)
+    y = torch.randint(0, 2048, (1, N, 4), generator=gen)
+    unc = torch.randint(0, 101, (1, L), generator=gen)
+    mi = torch.LongTensor([[[N, N]]])
+    kw = dict(top_k=40, top_p=0.8, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=5, aug_text=True)
+    torch.manual_seed(4242)
+    trace = {}
+    O.inference(sd_cpu, args, x, y, mi, uncond_x=unc, max_steps=steps, trace=trace, **kw)
+    rng_after_ref = torch.get_rng_state()
+    ref_tok = torch.stack(trace["samples"]).numpy()
+    torch.manual_seed(4242)
+    out = m.inference(x.cuda(), torch.LongTensor([L]), x.cuda(), torch.LongTensor([L]), y.cuda(), y.cuda(), mi.cuda(),
+                      uncond_x=unc, max_new_steps=steps, **kw)
+    assert out is None and m.last_run["steps"] == steps
+    eng = next(iter(m._engines.values()))
+    got_tok = eng.generated[0, :steps].cpu().numpy()
+    assert np.array_equal(got_tok, ref_tok), (got_tok, ref_tok)
+    assert len({tuple(t) for t in ref_tok.tolist()}) > 5            # it really sampled (not one token repeated)
+    # the global generator is left where the reference's loop leaves it: exactly `steps` multinomial draws consumed
+    assert torch.equal(torch.get_rng_state(), rng_after_ref)
+
+
+def test_config4_830m_sixteen_rows_match_oracle():
+    """8 utterances x CFG = 16 rows (the matrix-core GEMV's full tile, two attention row groups) at the 830M shape, greedy,
+    every utterance with its own text / prompt length; tokens equal the oracle's run one by one on the CPU."""
+    from ssr_speech_amd import layout as LY
+    from ssr_speech_amd.engine import DecodeEngine, DecodeKnobs, LMWeightsArena
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    args = W.lm_args_830m()
+    sd_gpu = W.lm_state_dict(args, seed=0, device="cuda")
+    arena = LMWeightsArena(args, sd_gpu, torch.device("cuda"))
+    sd_cpu = O.reference_params({k: v.cpu() for k, v in sd_gpu.items()})
+    gen = torch.Generator().manual_seed(78)
+    n_utt, steps = 8, 5
+    eng = DecodeEngine(arena, n_utt, True, 512, 64, debug_logits=True)
+    rows, cols, knobs, utts = [], [], [], []
+    for u in range(n_utt):
+        L, N = 18 + 4 * u, 150 + 7 * u                       # prompts of ~3 s as in config 4: context crosses a page boundary
+        x = torch.randint(0, 100, (1, L), generator=gen)
+        y = torch.randint(0, 2048, (1, N, 4), generator=gen)
+        unc = torch.randint(0, 101, (1, L), generator=gen)
+        mi = torch.LongTensor([[[N, N]]])
+        cated, _, num_task, _ = LY.build_layout(y[0].T.numpy(), mi[0].numpy(), args)
+        rows += [x[0].numpy(), unc[0].numpy()]
+        cols.append(cated)
+        knobs.append(DecodeKnobs(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, cfg_coef=1.5, cfg_stride=2, use_cfg=True,
+                                 text_len=L, n_spans=num_task, seed=u))
+        utts.append((x, y, unc, mi))
+    eng.start(rows, cols, knobs)
+    eng.decode(steps, use_graph=True)
+    torch.cuda.synchronize()
+    got = eng.generated[:, :steps].cpu().numpy()
+    last = eng.dbg_logits.cpu().numpy()
+    worst = 0.0
+    for u, (x, y, unc, mi) in enumerate(utts):
+        trace = {}
+        O.inference(sd_cpu, args, x, y, mi, uncond_x=unc, max_steps=steps, trace=trace, top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2,
+                    kvcache=1, cfg_coef=1.5, cfg_stride=2, aug_text=True)
+        ref_tok = torch.stack(trace["samples"]).numpy()
+        assert np.array_equal(got[u], ref_tok), (u, got[u], ref_tok)
+        err = float(np.abs(last[u] - torch.stack(trace["edited_logits"]).numpy()[steps - 1]).max())
+        worst = max(worst, err)
+        assert err < 5e-4, (u, err)
+    print(f"830M x 16 rows: max |logit diff| at step {steps}: {worst:.2e}")
+
+
+def test_config5_codec_256_clips_of_30s_on_one_gpu():
+    from ssr_speech_amd.codec.wmencodec import WMEncodecModel
+    from helpers_codec import code_margins
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    cfg = W.codec_config_full()
+    sd = W.codec_state_dict(cfg, seed=0)
+    m = WMEncodecModel(cfg, sd, "cuda")
+    B, n = 256, 480000
+    g = torch.Generator().manual_seed(0)
+    wav = torch.randn(B, 1, n, generator=g) * 0.1
+    wav[-1, :, n - 12345:] = 0.0                                   # a ragged clip inside the batch (zero-padded tail, data/encode.py)
+    wav_gpu = wav.cuda()
+    torch.cuda.reset_peak_memory_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    codes, scale, emb = m.encode(wav_gpu)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    dec = m.decode(codes)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
+    T = n // cfg.hop
+    print(f"config 5: encode {1000 * (t1 - t0):.0f} ms, decode {1000 * (t2 - t1):.0f} ms, peak {peak_gb:.1f} GiB "
+          f"({B * 30 / (t1 - t0):.0f} / {B * 30 / (t2 - t1):.0f} audio-s per s)")
+    # ---- properties at the full size
+    assert scale is None and tuple(codes.shape) == (B, cfg.n_q, T) and codes.dtype == torch.int64
+    assert tuple(emb.shape) == (B, cfg.dimension, T) and tuple(dec.shape) == (B, 1, n)
+    assert int(codes.min()) >= 0 and int(codes.max()) < cfg.bins
+    assert bool(torch.isfinite(emb).all()) and bool(torch.isfinite(dec).all())
+    lat = m.decode_latent(codes[:4])                                # round trip of the quantiser: latent = sum of the chosen code vectors
+    want = sum(torch.nn.functional.embedding(codes[:4, q].cpu(), sd[f"quantizer.vq.layers.{q}._codebook.embed"]) for q in range(cfg.n_q)).permute(0, 2, 1)
+    torch.testing.assert_close(lat.cpu(), want, rtol=0, atol=1e-6)
+    # items are independent: the first clip alone gives the same result as inside the batch of 256
+    c1, _, e1 = m.encode(wav_gpu[:1])
+    torch.testing.assert_close(e1, emb[:1], rtol=0, atol=2e-5)
+    del lat, c1, e1
+    # ---- three clips against the oracle (first / middle / the ragged last one)
+    for b in (0, 131, B - 1):
+        o_codes, _, o_emb = OC.encode(sd, wav[b:b + 1], cfg)
+        np.testing.assert_allclose(emb[b:b + 1].cpu().numpy(), o_emb.numpy(), rtol=0, atol=2e-4)
+        diff = codes[b:b + 1].cpu() != o_codes
+        if diff.any():                                              # fp32 near-ties of the RVQ argmax: judged by the oracle's own margin
+            marg = code_margins(sd, cfg, o_emb, o_codes)
+            first = diff.float().cumsum(1) == 1
+            assert (marg[diff & first] < 1e-4).all(), (b, int(diff.sum()))
+        assert diff.float().mean() < 0.01, b
+        o_dec = OC.decode(sd, codes[b:b + 1].cpu(), cfg)            # decode of the GPU's own codes: isolates the decoder
+        np.testing.assert_allclose(dec[b:b + 1].cpu().numpy(), o_dec.numpy(), rtol=0, atol=2e-4)

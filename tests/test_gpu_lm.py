@@ -293,3 +293,66 @@ def test_full_830m_ten_rows_match_oracle_on_cpu():
         assert np.array_equal(got[u], ref_tok), (u, got[u], ref_tok)
         err = np.abs(last[u] - torch.stack(trace["edited_logits"]).numpy()[steps - 1]).max()
         assert err < 5e-4, (u, err)
+
+
+@pytest.mark.parametrize("name", ["tts_greedy_cfg5", "edit_3span_greedy", "tts_sample_topk"])
+def test_shuffled_page_table_end_to_end(golden_dir, name):
+    """The KV pages are handed out by a host-side allocator (engine.PagePool); here in a SHUFFLED order, so the page table
+    the kernels walk is an arbitrary permutation (by default it is already interleaved across rows, never the identity of
+    the dense layout). Tokens must still equal the reference's."""
+    g, args, kw = _load(golden_dir, name)
+    m = _model(args, int(g["weight_seed"]))
+    rng = np.random.default_rng(5)
+    m.page_order = [int(p) for p in rng.permutation(64)]
+    L = g["x"].shape[1]
+    x, y = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["y"]).cuda()
+    extra = {"uncond_x": torch.from_numpy(g["uncond_x"])} if kw.get("aug_text") else {}
+    if "sample" in name:
+        extra["noise"] = torch.from_numpy(g["step_noise"])
+    res, marks, masks, nmi = m.inference(x, torch.LongTensor([L]), x, torch.LongTensor([L]), y, y, torch.from_numpy(g["mask_interval"]).cuda(), **kw, **extra)
+    eng = next(iter(m._engines.values()))
+    tab = eng._table_host
+    assert eng.pages.n_pages <= 64 and not np.array_equal(tab[tab != eng.scratch_page], np.arange((tab != eng.scratch_page).sum()))
+    assert np.array_equal(res.cpu().numpy(), g["res"]) and np.array_equal(marks.numpy(), g["marks"])
+
+
+def test_page_pool_is_shared_and_pages_return_when_an_utterance_finishes():
+    """One long and several short utterances in one lock-step batch: the pool holds the SUM of what each row can reach, not
+    rows x the longest; pages grow on demand while decoding and come back when an utterance is done; results equal batch-1 runs."""
+    args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
+    m = _model(args, 44)
+    g = torch.Generator().manual_seed(9)
+    shapes = [(60, 500), (6, 20), (7, 30), (5, 25)]              # the first one reaches ~1,100 positions, the others < 128
+    utts = [dict(x=torch.randint(0, 30, (1, L), generator=g), y=torch.randint(0, 64, (1, T, 4), generator=g),
+                 mask_interval=torch.LongTensor([[[T, T]]])) for L, T in shapes]
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, silence_tokens=[3, 7, 11], cfg_coef=1.5, cfg_stride=1, aug_text=True)
+    got = m.inference_batch(utts, seed=3, **kw)
+    eng = next(iter(m._engines.values()))
+    assert eng.pages.n_pages < eng.B * eng.max_pages, (eng.pages.n_pages, eng.B, eng.max_pages)      # smaller than the dense reservation
+    assert eng.pages.n_free == eng.pages.n_pages                                                      # everything was returned
+    assert (eng._table_host == eng.scratch_page).all()
+    for i, u in enumerate(utts):
+        torch.manual_seed(3 + i)
+        L = u["x"].shape[1]
+        one = m.inference(u["x"].cuda(), torch.LongTensor([L]), u["x"].cuda(), torch.LongTensor([L]), u["y"].cuda(), u["y"].cuda(),
+                          u["mask_interval"].cuda(), kvcache=1, **kw)
+        assert torch.equal(got[i][0], one[0]) and torch.equal(got[i][1], one[1]), i
+
+
+def test_positions_beyond_the_initial_table_grow_it_like_extend_pe():
+    """the sinusoidal table started at 8192 rows and was read unguarded. A text of 8,300 phonemes has positions past
+    it: the table must grow (reference: SinePositionalEmbedding.extend_pe, embedding.py:66-92) and the tokens still equal the oracle's."""
+    args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
+    m = _model(args, 45)
+    g = torch.Generator().manual_seed(10)
+    L, T, steps = 8300, 24, 6
+    x = torch.randint(0, 30, (1, L), generator=g)
+    y = torch.randint(0, 64, (1, T, 4), generator=g)
+    mi = torch.LongTensor([[[T, T]]])
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, silence_tokens=[3, 7, 11], cfg_coef=1.5, cfg_stride=1, aug_text=False)
+    out = m.inference(x.cuda(), torch.LongTensor([L]), x.cuda(), torch.LongTensor([L]), y.cuda(), y.cuda(), mi.cuda(), max_new_steps=steps, **kw)
+    assert out is None and m._arena.max_pos > 8192
+    eng = next(iter(m._engines.values()))
+    trace = {}
+    O.inference(O.reference_params(W.lm_state_dict(args, seed=45)), args, x, y, mi, max_steps=steps, trace=trace, kvcache=1, **kw)
+    assert np.array_equal(eng.generated[0, :steps].cpu().numpy(), torch.stack(trace["samples"]).numpy())
