@@ -13,6 +13,13 @@ afterwards, timed separately).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the weight-streaming GEMV, HBM-bound) and
 `cpu_baseline` (the oracle = CPU restatement of the reference, timed on this box's host cores, bounded sample).
+
+Extras on the same line (never `value`):
+  rtf_10s_tts  wav -> wav through the public API (`inference_one_sample`: codec encode of the prompt wav, prefill, sampled AR
+               decode with the host-side torch RNG stream, wmencodec decode), ~10 s generated; + time to the first 16 frames.
+  dp64         BASELINE config 4: 64 utterances (L=67, 150-frame prompts, seeds 1000+i / 2000+i, greedy) through `dp.generate`
+               (shard -> lock-step decode of 8 utterances x CFG per engine pass -> ONE all-gather), tokens/s/GPU + checksum.
+  codec256     BASELINE config 5: wmencodec encode + decode of 256 clips x 30 s, 256/N clips per rank.
 """
 import argparse
 import dataclasses
@@ -30,6 +37,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 TRAFFIC_BYTES_PER_GEMV_LAUNCH = 50.6e6   # measured with PMC counters, see profiles/r01_pmc_fetch_size.md (not re-measured live)
+TRAFFIC_SOURCE = "profiles/r01_pmc_fetch_size.md + profiles/r01_pmc_write_size.md (rocprofv3 --pmc passes, gfx950 x2 FETCH_SIZE correction)"
 
 
 def synth_inputs(args_lm, rank, L=130, N=160):
@@ -125,6 +133,148 @@ def codec_leg(dev, with_cpu):
     return out
 
 
+class CharPhonemizer:
+    """Stands in for espeak in the API leg: one 'phoneme' per character (the front-end is out of scope)."""
+
+    def __call__(self, texts):
+        return [[c for c in t if c != " "] for t in texts]
+
+
+def build_api_model(args_lm, sd, dev):
+    """`SSR_Speech` (the drop-in class) on the 830M-shape weights. The second head Linear's bias is pushed to -30 for the special
+    ids (>= 2048) so that a random-weight LM emits only codec ids the RVQ decoder accepts (the reference would raise on them
+    too); generation then ends by the reference's own length cap (`y_len > 10 * L`, ssr.py:739)."""
+    from ssr_speech_amd.models.ssr import SSR_Speech
+    sd2 = dict(sd)
+    for k in range(args_lm.n_codebooks):
+        b = sd[f"predict_layer.{k}.2.bias"].clone()
+        b[int(args_lm.audio_vocab_size):] = -30.0
+        sd2[f"predict_layer.{k}.2.bias"] = b
+    m = SSR_Speech(args_lm)
+    m.load_state_dict({k: v.cpu() for k, v in sd2.items()})
+    return m.to(dev).eval()
+
+
+def rtf_leg(model, args_lm, dev, tmpdir):
+    """RTF of one ~10 s zero-shot TTS THROUGH THE API: `inference_one_sample(wav file -> wav)`, sampling mode (top_k=40,
+    top_p=0.8, cfg_stride=5, CFG), seeded by `torch.manual_seed` like the reference's CLI. L=67 phonemes and a 160-frame
+    (3.2 s) prompt give ~505 generated frames (10.1 s) under the length cap."""
+    import argparse as ap_
+    from ssr_speech_amd import weights as W
+    from ssr_speech_amd.data.tokenizer import AudioTokenizer, write_wav
+    from ssr_speech_amd.inference_scale import inference_one_sample
+    ccfg = W.codec_config_full()
+    tok = AudioTokenizer(device=dev, config=ccfg, state_dict=W.codec_state_dict(ccfg, seed=0))
+    g = torch.Generator().manual_seed(7)
+    n_prompt = 160
+    fn = os.path.join(tmpdir, "bench_prompt.wav")
+    write_wav(fn, torch.randn(1, n_prompt * 320, generator=g) * 0.1, 16000)
+    symbols = [chr(ord("a") + i) for i in range(26)] + [chr(ord("A") + i) for i in range(26)]
+    phn2num = {c: i for i, c in enumerate(symbols)}
+    prompt_text = "".join(symbols[int(i)] for i in torch.randint(0, 52, (20,), generator=g))
+    target_text = prompt_text + " " + "".join(symbols[int(i)] for i in torch.randint(0, 52, (47,), generator=g))      # 67 phonemes
+    decode_config = {"top_k": 40, "top_p": 0.8, "temperature": 1, "stop_repetition": 2, "kvcache": 1, "codec_audio_sr": 16000, "codec_sr": 50}
+    mi = torch.LongTensor([[n_prompt, n_prompt]])
+    margs = ap_.Namespace(**vars(args_lm))
+    call = lambda: inference_one_sample(model, margs, phn2num, CharPhonemizer(), tok, fn, prompt_text, target_text, mi, 1.5, 5, True, False,
+                                        False, True, dev, decode_config)
+    torch.manual_seed(1)
+    call()                                         # warm-up: engine + graph capture + codec buffers
+    torch.cuda.synchronize()
+    best = None
+    for rep in range(2):
+        torch.manual_seed(1 + rep)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wav = call()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        lr = model.last_run
+        rec = {"wall_ms": round(1000 * (t1 - t0), 2), "generated_s": round(wav.shape[-1] / 16000.0, 3), "steps": int(lr["steps"]),
+               "rtf": round((t1 - t0) / (wav.shape[-1] / 16000.0), 4),
+               "time_to_first_16_frames_ms": round(1000 * (lr["t_first_chunk"] - t0), 2),
+               "lm_inference_ms": round(1000 * (lr["t_end"] - lr["t_start"]), 2)}
+        if best is None or rec["rtf"] < best["rtf"]:
+            best = rec
+    best["note"] = ("inference_one_sample(wav -> wav): read wav, wmencodec encode of the 3.2 s prompt, prefill, sampled decode with the torch CPU RNG "
+                    "stream drawn 16 steps ahead of the GPU, wmencodec decode of all frames; the prompt part is cut from the output (tts)")
+    return best
+
+
+def dp64_leg(model, args_lm, dev, world, rank, dist):
+    """BASELINE config 4 through `dp.generate`: the code path tests/test_dp_gloo.py covers."""
+    from ssr_speech_amd import dp
+    import zlib
+    utts = []
+    for i in range(64):
+        gx = torch.Generator().manual_seed(1000 + i)
+        gy = torch.Generator().manual_seed(2000 + i)
+        utts.append({"x": torch.randint(0, 100, (1, 67), generator=gx), "y": torch.randint(0, 2048, (1, 150, 4), generator=gy),
+                     "mask_interval": torch.LongTensor([[[150, 150]]])})
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, cfg_coef=1.5, cfg_stride=5, aug_text=True)
+    stats = {}
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    toks, (lo, hi, _) = dp.generate(model, utts, seed=0, device=dev, stats=stats, **kw)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([wall, stats["decode_s"]], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, dec = float(tt[0]), float(tt[1])
+    else:
+        dec = stats["decode_s"]
+    n_new = sum(int(t.shape[1]) - 150 for t in toks)
+    crc = 0
+    for t in toks:
+        crc = zlib.crc32(t.cpu().numpy().astype("<i8").tobytes(), crc)
+    return {"workload": "64 utterances, L=67, 150-frame prompts, greedy + CFG (stride 5), <= 8 utterances x 2 rows per engine pass",
+            "n_gpus": world, "utterances_per_gpu": (64 + world - 1) // world, "new_frames_total": n_new,
+            "wall_ms": round(1000 * wall, 1), "decode_ms_max_rank": round(1000 * dec, 1), "allgather_ms": round(1000 * stats["allgather_s"], 3),
+            "codec_tokens_per_s_per_gpu": round(4 * n_new / dec / world, 1), "codec_tokens_per_s_total": round(4 * n_new / wall, 1),
+            "tokens_crc32": f"{crc:08x}"}
+
+
+def codec256_leg(dev, world, rank, dist):
+    """BASELINE config 5: encode + decode of 256 clips x 30 s (16 kHz), 256 / N clips per rank, no collective."""
+    from ssr_speech_amd import dp, weights as W
+    from ssr_speech_amd.codec.wmencodec import WMEncodecModel
+    cfg = W.codec_config_full()
+    m = WMEncodecModel(cfg, W.codec_state_dict(cfg, seed=0), dev)
+    lo, hi = dp.shard_range(256, world, rank)
+    B, n = hi - lo, 480000
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    wav = torch.randn(B, 1, n, generator=g, device=dev) * 0.1
+    c, _, _ = m.encode(wav[: min(B, 8)])               # warm-up on a slice
+    m.decode(c)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    codes, _, _ = m.encode(wav)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    out = m.decode(codes)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    enc, dec = t1 - t0, t2 - t1
+    if dist is not None:
+        tt = torch.tensor([enc, dec], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        enc, dec = float(tt[0]), float(tt[1])
+    GF, audio_s = 6.97e9, 256 * 30.0
+    return {"workload": f"256 clips x 30 s, {B} per GPU, full wmencodec config, synthetic weights", "n_gpus": world,
+            "encode_ms": round(1000 * enc, 1), "decode_ms": round(1000 * dec, 1),
+            "encode_audio_s_per_s": round(audio_s / enc, 1), "decode_audio_s_per_s": round(audio_s / dec, 1),
+            "encode_tflops_per_gpu": round(GF * audio_s / enc / 1e12 / world, 1), "decode_tflops_per_gpu": round(GF * audio_s / dec / 1e12 / world, 1),
+            "mfma_fp32_peak_tflops": 157.3, "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "out_shape": list(out.shape)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +283,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--utts", type=int, default=1, help="utterances decoded in lock-step per GPU (default 1 = the headline configuration)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rtf_10s_tts / dp64 / codec256 / wmencodec legs")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -249,7 +400,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r01_pmc_*.md), gfx950 x2 correction
                          # for wide reads applied: 50.5 MB read + 0.1 MB written per GEMV launch vs 49.85 MB algorithmic
-                         "traffic": TRAFFIC_BYTES_PER_GEMV_LAUNCH if (arena.D == 2048 and arena.L == 16) else None,
+                         "traffic": TRAFFIC_BYTES_PER_GEMV_LAUNCH if (arena.D == 2048 and arena.L == 16 and U == 1) else None,
+                         "traffic_source": TRAFFIC_SOURCE,
                          "kernel": "gemv_fast_kernel<2,*> (fused LN/combine + GEMV + bias/act/residual), all 66 launches of a step",
                          "bytes_per_launch": int(bytes_per_launch), "launches_per_step": n_gemv, "us_per_launch": round(gemv_us, 3),
                          "us_per_launch_eager_event_pair": round(gemv_us_eager, 3),
@@ -258,40 +410,50 @@ def main():
                                         "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
                          "event_timed_us_per_launch": per_shape},
         }
-        # ---- RTF of a whole 10 s zero-shot TTS on this GPU: prefill + 500 decode steps + wmencodec decode of the 500 new frames
-        try:
-            if U != 1:
-                raise RuntimeError("reported for --utts 1 only")
-            torch.cuda.synchronize()
-            p0 = time.perf_counter()
-            eng.start([x[0].numpy(), unc[0].numpy()], [cated], [kn], noise=None)
-            torch.cuda.synchronize()
-            prefill_ms = 1000 * (time.perf_counter() - p0)
-            from ssr_speech_amd.codec.wmencodec import WMEncodecModel
-            ccfg = W.codec_config_full()
-            codec = WMEncodecModel(ccfg, W.codec_state_dict(ccfg, seed=0), dev)
-            codes = torch.randint(0, 2048, (1, 4, 500), device=dev)
-            codec.decode(codes)
-            torch.cuda.synchronize()
-            c0 = time.perf_counter()
-            wav = codec.decode(codes)
-            torch.cuda.synchronize()
-            codec_ms = 1000 * (time.perf_counter() - c0)
-            out["rtf_10s_tts"] = {"prefill_ms": round(prefill_ms, 2), "decode_ms": round(500 * ms_per_step, 2), "codec_decode_ms": round(codec_ms, 2),
-                                  "rtf": round((prefill_ms + 500 * ms_per_step + codec_ms) / 10000.0, 4),
-                                  "note": f"prefill of {2 * (L + T0)} rows (host layout + H2D included), 500 frames = 10 s, SEANet+LSTM decode of {tuple(wav.shape)}"}
-        except Exception as e:  # the headline metric must not depend on this extra
-            out["rtf_10s_tts"] = {"error": repr(e)}
-        if U == 1 and world == 1:
-            try:
-                out["wmencodec"] = codec_leg(dev, with_cpu=not a.no_cpu_baseline)
-            except Exception as e:  # the headline metric must not depend on this extra
-                out["wmencodec"] = {"error": repr(e)}
         if allgather_ms is not None:
             out["allgather_ms"] = round(allgather_ms, 3)
+    else:
+        out = None
+
+    # ---- extras (every rank takes part: dp64 ends in a collective). None of them feeds `value`.
+    extras = {}
+    if not a.no_extras and U == 1:
+        del eng
+        torch.cuda.empty_cache()
+        import tempfile
+
+        def leg(name, fn):
+            try:
+                extras[name] = fn()
+            except Exception as e:      # the headline metric must not depend on an extra
+                if world > 1:
+                    raise               # a rank that skips a collective would hang the others: fail loudly instead
+                extras[name] = {"error": repr(e)}
+
+        model = None
+        try:
+            model = build_api_model(args_lm, sd, dev)
+        except Exception as e:
+            if world > 1:
+                raise
+            extras["rtf_10s_tts"] = extras["dp64"] = {"error": repr(e)}
+        if model is not None:
+            if world == 1:
+                with tempfile.TemporaryDirectory() as td:
+                    leg("rtf_10s_tts", lambda: rtf_leg(model, args_lm, dev, td))
+            leg("dp64", lambda: dp64_leg(model, args_lm, dev, world, rank, dist))
+            model._invalidate()
+            del model
+            torch.cuda.empty_cache()
+        leg("codec256", lambda: codec256_leg(dev, world, rank, dist))
+        if world == 1:
+            leg("wmencodec", lambda: codec_leg(dev, with_cpu=not a.no_cpu_baseline))
+
+    if rank == 0:
+        out.update(extras)
         if world == 1 and not a.no_cpu_baseline and U == 1:
             out["cpu_baseline"] = cpu_baseline(args_lm, sd, x, y, unc)
-            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

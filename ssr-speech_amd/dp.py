@@ -66,7 +66,7 @@ def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token
     return res
 
 
-def generate(model, utterances: Sequence[dict], seed: int = 0, pad_token: int = None, device=None, **decode_kw):
+def generate(model, utterances: Sequence[dict], seed: int = 0, pad_token: int = None, device=None, stats: dict = None, **decode_kw):
     """BASELINE config 4 in one call: shard `utterances` (dicts {x, y, mask_interval}, see `SSR_Speech.inference_batch`)
     over the ranks of the default process group, decode this rank's shard in lock-step (up to 8 utterances x CFG rows per
     engine pass), and all-gather the generated codec tokens so that every rank holds all of them before codec decode.
@@ -76,11 +76,19 @@ def generate(model, utterances: Sequence[dict], seed: int = 0, pad_token: int = 
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     lo, hi = shard_range(len(utterances), world, rank)
+    import time
+    t0 = time.perf_counter()
     outs = model.inference_batch(list(utterances[lo:hi]), seed=seed, first_index=lo, **decode_kw) if hi > lo else []
+    if stats is not None:           # wall time of this rank's lock-step decode (inference_batch ends on a device->host read)
+        stats["decode_s"] = time.perf_counter() - t0
     K = int(model.args.n_codebooks)
     if pad_token is None:
         pad_token = int(model.args.empty_token)
     toks = [o[0][0] for o in outs]                                   # res [1, K, T'] -> [K, T']
     if device is None:
         device = _collective_device(getattr(model, "device", None))
-    return gather_tokens(toks, len(utterances), K, pad_token, device=device), (lo, hi, outs)
+    t1 = time.perf_counter()
+    everyone = gather_tokens(toks, len(utterances), K, pad_token, device=device)
+    if stats is not None:
+        stats["allgather_s"] = time.perf_counter() - t1
+    return everyone, (lo, hi, outs)

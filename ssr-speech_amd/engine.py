@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import time
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -257,6 +258,7 @@ class DecodeEngine:
         self._kv0 = [0] * self.B                 # sequence length of each row after the prefill
         self._steps_enqueued = 0
         self._utt_live = [False] * n_utt
+        self.t_first_chunk = 0.0
         rows = self.B if self.B <= 4 else MAX_ROWS      # > 4 rows: x / q / h are 16-column tiled buffers (include/ssrhip.h SSRHIP_TILED)
         self.x = torch.zeros(rows, D, **f32)
         self.q = torch.zeros(rows, D, **f32)
@@ -517,6 +519,8 @@ class DecodeEngine:
                 ready = stage(ci + 1, total, min(total + chunk, limit))      # host works while the GPU decodes chunk ci
             ci += 1
             states = self.states()                              # blocks until chunk ci-1 has finished
+            if ci == 1:
+                self.t_first_chunk = time.perf_counter()        # first `chunk` frames exist (bench: time to first frames)
             live = [not s_.done for s_ in states]
             for u in range(self.n_utt):
                 if not live[u]:

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import copy
 import logging
+import time
 from argparse import Namespace
 from typing import Dict, List, Optional
 
@@ -160,6 +161,7 @@ class SSR_Speech(nn.Module):
         produces identical tokens for kvcache 0/1).  Keyword-only extras (not in the reference):
         `noise` [steps,K,card] Exp(1) draws replacing the multinomial generator draw, `uncond_x`
         overriding the random CFG text (ssr.py:574), `max_new_steps` (tests), `use_graph`."""
+        t_call = time.perf_counter()
         K = self.args.n_codebooks
         assert cfg_coef >= 1.0, cfg_coef
         assert x.ndim == 2, x.shape
@@ -225,7 +227,8 @@ class SSR_Speech(nn.Module):
         states = eng.run_to_completion(chunk=16, use_graph=use_graph, max_total=cap, feed=feed)
         st = states[0]
         gen = eng.generated[0, : st.n_steps].cpu().numpy().astype(np.int64)
-        self.last_run = dict(steps=st.n_steps, done=st.done, span_end=list(st.span_end), prefill_rows=(L + T0) * (2 if aug_text else 1))
+        self.last_run = dict(steps=st.n_steps, done=st.done, span_end=list(st.span_end), prefill_rows=(L + T0) * (2 if aug_text else 1),
+                             t_start=t_call, t_first_chunk=eng.t_first_chunk, t_end=time.perf_counter())
         if st.done != 1:
             if max_new_steps is not None:
                 return None
