@@ -78,7 +78,17 @@ typedef struct ssrhip_gemv_args {
   /* 5..16 rows only (matrix-core path): activations in the 16-column tiled layout SSRHIP_TILED(b,k) below instead of
    * row-major [B][stride]; x_stride / y_stride are ignored for a tiled operand. QKV_APPEND's q output is always row-major. */
   int32_t x_tiled, y_tiled;
+  /* 5..16 rows only: W is stored in the matrix core's streaming order instead of [N][K] (see SSRHIP_WTILED_INDEX): one
+   * wave-level load then reads 8 full 128-byte lines instead of 64 sixteen-byte pieces of 16 different rows. */
+  int32_t w_tiled;
 } ssrhip_gemv_args;
+
+/* Streaming-order weight layout for the 5..16-row GEMV (`w_tiled`): rows are grouped in 8-row units (the last unit zero-padded),
+ * K in 16-float steps; the 512-byte block of (unit u, k-step t) holds, at float4 index ks*8 + c, the four weights
+ * W[8u + c][16t + 4ks .. 16t + 4ks + 3]   (c = 0..7 row inside the unit, ks = 0..3 k-slot of the 16x16x4 MFMA).
+ * Blocks of one unit are contiguous along t, units follow each other: float index of W[n][k] is
+ *   ((n/8) * (K/16) + k/16) * 128 + (((k%16)/4) * 8 + n%8) * 4 + k%4 ;  a group's matrix takes ceil(N/8)*8*K floats. */
+#define SSRHIP_WTILED_INDEX(n, k, K) ((((size_t)(n) / 8) * ((size_t)(K) / 16) + (size_t)(k) / 16) * 128 + ((((k) % 16) / 4) * 8 + (n) % 8) * 4 + (k) % 4)
 
 /* 16-column tiled activation layout used between the kernels of the 5..16-row decode step: element (row b, feature k) of a
  * [<=16][K] activation lives at float index ((k/4)*16 + b)*4 + k%4, i.e. 4 consecutive features of the 16 rows are 256
@@ -275,6 +285,10 @@ typedef struct ssrhip_lm_weights {      /* device pointers; per-layer arrays hav
   const float* lnf_w; const float* lnf_b;
   const float* head1_w; const float* head1_b;   /* [K*Hh][D], [K*Hh]   (predict_layer.k.0 stacked) */
   const float* head2_w; const float* head2_b;   /* [K][card][Hh], [K][card] (predict_layer.k.2 stacked) */
+  /* optional second copy of the six matrices in the streaming order of the 5..16-row GEMV (SSRHIP_WTILED_INDEX; all NULL = absent).
+   * Used by the decode steps of engines with more than 4 rows; the prefill GEMMs and the <= 4-row GEMV read the [N][K] copies. */
+  const float* const* in_proj_wt; const float* const* out_proj_wt; const float* const* ffn1_wt; const float* const* ffn2_wt;
+  const float* head1_wt; const float* head2_wt;
 } ssrhip_lm_weights;
 
 typedef struct ssrhip_lm_dims {

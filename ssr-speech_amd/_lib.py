@@ -44,7 +44,7 @@ class GemvArgs(C.Structure):
                 ("part_o", C.c_void_p), ("part_ml", C.c_void_p), ("max_splits", C.c_int32),
                 ("row_len", C.c_void_p),
                 ("kv", KV), ("layer", C.c_int32), ("kv_pos", C.c_void_p),
-                ("x_tiled", C.c_int32), ("y_tiled", C.c_int32)]
+                ("x_tiled", C.c_int32), ("y_tiled", C.c_int32), ("w_tiled", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -116,7 +116,9 @@ class LMWeights(C.Structure):
                 ("out_proj_w", _PP), ("out_proj_b", _PP), ("ln2_w", _PP), ("ln2_b", _PP),
                 ("ffn1_w", _PP), ("ffn1_b", _PP), ("ffn2_w", _PP), ("ffn2_b", _PP),
                 ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p),
-                ("head1_w", C.c_void_p), ("head1_b", C.c_void_p), ("head2_w", C.c_void_p), ("head2_b", C.c_void_p)]
+                ("head1_w", C.c_void_p), ("head1_b", C.c_void_p), ("head2_w", C.c_void_p), ("head2_b", C.c_void_p),
+                ("in_proj_wt", _PP), ("out_proj_wt", _PP), ("ffn1_wt", _PP), ("ffn2_wt", _PP),
+                ("head1_wt", C.c_void_p), ("head2_wt", C.c_void_p)]
 
 
 class LMDims(C.Structure):

@@ -48,7 +48,7 @@ struct ssrhip_lm {
   ssrhip_lm_dims d;
   ssrhip_lm_weights w;
   ssrhip_lm_buffers b;
-  std::vector<const float*> ptrs[12];
+  std::vector<const float*> ptrs[16];
   hipStream_t cap_stream = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -95,6 +95,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
   // 5..16 rows: the residual stream x, the combined attention output and the hidden h live in the 16-column tiled layout
   // (include/ssrhip.h SSRHIP_TILED) so that the matrix-core GEMV's operand loads are contiguous KiBs
   const int tiled = B > 4 ? 1 : 0;
+  const bool wt = tiled && w.in_proj_wt;      // streaming-order weight copies for the matrix-core GEMV (include/ssrhip.h w_tiled)
 
   if (tm) tm->slot = 0;
 
@@ -109,6 +110,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.ln_eps = 1e-5f;
     g.kv = b.kv; g.layer = l; g.kv_pos = b.kv_pos;
     g.x_tiled = tiled;                         // q stays row-major for the attention kernel
+    if (wt) { g.W = w.in_proj_wt[l]; g.w_tiled = 1; }
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
 
     ssrhip_attn_args at;
@@ -130,6 +132,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
       at.out_tiled = 1;
       STEP_CALL(CAT_ATTN, ssrhip_attn_combine(&at, b.q, s));
       g.pro = SSRHIP_PRO_NONE; g.x = b.q; g.x_tiled = 1; g.y_tiled = 1;
+      if (wt) { g.W = w.out_proj_wt[l]; g.w_tiled = 1; }
     }
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
 
@@ -141,6 +144,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     if (!d.ln_folded) { g.ln_w = w.ln2_w[l]; g.ln_b = w.ln2_b[l]; }
     g.ln_eps = 1e-5f;
     g.x_tiled = tiled; g.y_tiled = tiled;
+    if (wt) { g.W = w.ffn1_wt[l]; g.w_tiled = 1; }
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
 
     // FFN2 + residual
@@ -149,6 +153,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.B = B; g.N = D; g.K = d.d_ffn; g.groups = 1; g.x_stride = d.d_ffn; g.y_stride = D;
     g.pro = SSRHIP_PRO_NONE; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_RESIDUAL;
     g.x_tiled = tiled; g.y_tiled = tiled;
+    if (wt) { g.W = w.ffn2_wt[l]; g.w_tiled = 1; }
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
   }
   {
@@ -161,6 +166,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     if (!d.ln_folded) { g.ln_w = w.lnf_w; g.ln_b = w.lnf_b; }
     g.ln_eps = 1e-5f;
     g.x_tiled = tiled; g.y_tiled = tiled;
+    if (wt) { g.W = w.head1_wt; g.w_tiled = 1; }
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
     // second Linear of each head: K groups
     memset(&g, 0, sizeof(g));
@@ -168,6 +174,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.B = B; g.N = d.card; g.K = Hh; g.groups = K; g.x_stride = K * Hh; g.y_stride = K * d.card;
     g.pro = SSRHIP_PRO_NONE; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_STORE;
     g.x_tiled = tiled;                         // logits stay row-major for the sampler
+    if (wt) { g.W = w.head2_wt; g.w_tiled = 1; }
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
   }
   ssrhip_sample_args sa;
@@ -208,6 +215,19 @@ extern "C" int ssrhip_lm_create(const ssrhip_lm_dims* d, const ssrhip_lm_weights
     lm->ptrs[f].assign(src, src + d->n_layer);
     *fields[f] = lm->ptrs[f].data();
   }
+  // optional streaming-order copies (all or none)
+  const float* const** opt[4] = {&lm->w.in_proj_wt, &lm->w.out_proj_wt, &lm->w.ffn1_wt, &lm->w.ffn2_wt};
+  const bool has_wt = lm->w.in_proj_wt && lm->w.out_proj_wt && lm->w.ffn1_wt && lm->w.ffn2_wt && lm->w.head1_wt && lm->w.head2_wt;
+  for (int f = 0; f < 4; ++f) {
+    if (has_wt) {
+      const float* const* src = *opt[f];
+      lm->ptrs[12 + f].assign(src, src + d->n_layer);
+      *opt[f] = lm->ptrs[12 + f].data();
+    } else {
+      *opt[f] = nullptr;
+    }
+  }
+  if (!has_wt) lm->w.head1_wt = lm->w.head2_wt = nullptr;
   *out = lm;
   return 0;
 }

@@ -744,7 +744,7 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a->N > 0 && a->groups >= 1 && a->K > 0, "ssrhip_gemv: bad N/K/groups");
   if (a->B > 4) return ssrhip_gemv_mfma_launch(a, (hipStream_t)stream);
   SSR_REQUIRE(a->B == 1 || a->B == 2 || a->B == 4, "ssrhip_gemv: B=%d not in {1,2,4} or 5..16", a->B);
-  SSR_REQUIRE(!a->x_tiled && !a->y_tiled, "ssrhip_gemv: the tiled activation layout is for 5..16 rows only");
+  SSR_REQUIRE(!a->x_tiled && !a->y_tiled && !a->w_tiled, "ssrhip_gemv: the tiled activation / weight layouts are for 5..16 rows only");
   SSR_REQUIRE(a->pro != SSRHIP_PRO_ATTN_COMBINE || (a->kv.head_dim > 0 && a->K <= 2048 && a->B * (a->K / a->kv.head_dim) <= 256), "ssrhip_gemv: combine prologue needs K <= 2048 and B*H <= 256");
   SSR_REQUIRE(a->K > 0 && a->K % 4 == 0 && a->K <= 8192, "ssrhip_gemv: K=%d must be a multiple of 4, <= 8192", a->K);
   SSR_REQUIRE(a->N > 0 && a->groups >= 1, "ssrhip_gemv: bad N/groups");

@@ -44,6 +44,47 @@ __device__ __forceinline__ float kslot_sum(float v) {
   return v;
 }
 
+// Epilogue of one 16x16 output tile: this lane holds rows r0 = row0 + 4*(lane/16) .. r0+3 of batch column c = lane%16
+// (only the first `tile_rows` rows of the tile are real: 16, or 8 when the tile's rows 8..15 duplicate 0..7).
+__device__ __forceinline__ void tile_epilogue(const ssrhip_gemv_args& a, int hd, int grp, int row0, int tile_rows, int lane, f4v acc) {
+  const int c = lane & 15, ks = lane >> 4;
+  const int N = a.N, K = a.K, B = a.B;
+  const int r0 = row0 + ks * 4;
+  if (c >= B || r0 >= N || ks * 4 >= tile_rows) return;
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+  const int nvalid = min(4, N - r0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < nvalid) {
+      if (a.bias) v[j] += a.bias[(size_t)grp * N + r0 + j];
+      if (a.act == SSRHIP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+      else if (a.act == SSRHIP_ACT_GELU_ERF) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752440f));
+    }
+  }
+  float* dst;
+  if (a.epi == SSRHIP_EPI_QKV_APPEND) {
+    const int D = K, which = r0 / D, cc = r0 % D;
+    if (which == 0) dst = a.y + (size_t)c * a.y_stride + cc;
+    else dst = kv_addr(a.kv, c, a.layer, which - 1, cc / hd, a.kv_pos[c]) + (cc % hd);
+  } else if (a.y_tiled) {
+    dst = a.y + (size_t)grp * N * 16 + SSRHIP_TILED(c, r0);
+  } else {
+    dst = a.y + (size_t)c * a.y_stride + (size_t)grp * N + r0;
+  }
+  if (a.epi == SSRHIP_EPI_RESIDUAL) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nvalid) v[j] = dst[j] + v[j];
+  }
+  if (nvalid == 4 && ((reinterpret_cast<size_t>(dst) & 15) == 0)) {
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nvalid) dst[j] = v[j];
+  }
+}
+
 template <int PRO>
 __global__ __launch_bounds__(512) void gemv_mfma_kernel(const GemvM p) {
   __shared__ float red[2][8][16];
@@ -140,40 +181,250 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(const GemvM p) {
     for (int w = 1; w < p.nw; ++w) acc += tile[w][lane];
   }
 
-  // epilogue: this lane holds rows r0..r0+3 of batch column c
-  const int r0 = row0 + ks * 4;
-  if (c >= B || r0 >= N || ks * 4 >= p.rows) return;
-  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-  const int nvalid = min(4, N - r0);
+  tile_epilogue(a, p.hd, grp, row0, p.rows, lane, acc);
+}
+
+
+// =====================================================================================================================
+// Version 2 (default): every workgroup owns a CONTIGUOUS BLOCK OF ROWS sized so that all CUs stream the same number of
+// bytes, and keeps its x operand across those rows.
+//
+// Why: in the per-tile kernel above a workgroup re-reads its 16 x K slice of x for every 16 (or 8) weight rows, so the L2->CU
+// x traffic equals (or doubles) the weight traffic, and N/16 workgroups rarely divide evenly over 256 CUs (QKV: 384 -> half
+// of the CUs stream twice as much as the others). rocprofv3 at 16 rows: QKV 20.3 us, FFN1 20.5 us, FFN2 26 us per launch for
+// 50 / 67 / 67 MB (2.5..3.3 TB/s).
+//
+//   * rows are dealt in 8-row units: workgroup b of `wgs` gets units [b*U/wgs, (b+1)*U/wgs) (counts differ by at most one);
+//     two units form a full 16-row MFMA tile, an odd last unit runs as an 8-row tile whose rows 8..15 duplicate 0..7
+//     (costs matrix-core cycles, no HBM bytes);
+//   * the NW <= 8 waves of the workgroup split K; `gemv_rows_xreg_kernel` (K <= 2048, and every LayerNorm launch up to K = 4096) keeps the wave's
+//     x slice in VGPRs for ALL of the workgroup's tiles (loaded once per launch: 128 KB per CU at K = 2048 instead of one
+//     slice per 16 rows); `gemv_rows_stream_kernel` (larger K: FFN2) streams x beside W with its own rolling loads, one
+//     uninterrupted pipeline over the whole K range (the per-tile kernel drained and refilled it per 4096-float chunk);
+//   * the weight pipeline never drains between tiles: the refill of k-step t+DEPTH crosses into the next tile; the last tile is
+//     a separate code path without the cross-tile refills, so no load is predicated and none is wasted;
+//   * per-tile partial sums of the waves go to LDS once (no barrier inside the row loop); after ONE barrier the waves run the
+//     epilogues of different tiles in parallel, adding the K-slices in wave order (deterministic).
+// =====================================================================================================================
+struct GemvR {
+  ssrhip_gemv_args a;
+  int nw;       // waves per workgroup (K split)
+  int steps;    // K / 16 MFMA k-steps in total
+  int spw;      // k-steps per wave (stream kernel: multiple of 16)
+  int units;    // ceil(N / 8) 8-row units per group
+  int wgs;      // workgroups per group (gridDim.x)
+  int hd;
+};
+
+constexpr int MAXT = 4;     // 16-row tiles per workgroup (LDS: MAXT x 8 waves x 1 KiB of partial sums)
+
+__device__ __forceinline__ f4v mfma4(float a, float b, f4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// per-lane pointer to (row of this lane in tile `tile`, k-slot of this lane) of the weight matrix
+__device__ __forceinline__ const float* tile_wptr(const float* wbase, int row_lo, int nun, int tile, int c, int ks, int N, int K, int w_tiled) {
+  const int rows = (2 * tile + 1 < nun) ? 16 : 8;
+  const int rr = row_lo + tile * 16 + (c & (rows - 1));
+  if (w_tiled) return wbase + (size_t)(rr >> 3) * 8 * K + (ks * 8 + (rr & 7)) * 4;   // streaming order: see SSRHIP_WTILED_INDEX (units are zero-padded)
+  return wbase + (size_t)min(rr, N - 1) * K + ks * 4;
+}
+
+template <int PRO, int SPWX, int DEP = 16>
+__global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
+  static_assert(SPWX >= DEP && SPWX % DEP == 0, "SPWX must be a multiple of the pipeline depth");
+  __shared__ float red[2][8][16];
+  __shared__ f4v part[MAXT][8][64];
+  const ssrhip_gemv_args& a = p.a;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, ks = lane >> 4;
+  const int grp = blockIdx.y;
+  const int N = a.N, K = a.K, B = a.B;
+  const int u_lo = (int)((long long)blockIdx.x * p.units / p.wgs), u_hi = (int)((long long)(blockIdx.x + 1) * p.units / p.wgs);
+  const int nun = u_hi - u_lo;
+  if (nun <= 0) return;                                                 // uniform; only when wgs > units
+  const int ntile = (nun + 1) >> 1;
+  const int row_lo = u_lo * 8;
+  const int last = p.steps - 1;
+  const int tbase = wave * SPWX;
+  const float* wbase = a.W + (size_t)grp * (a.w_tiled ? (size_t)p.units * 8 : (size_t)N) * K;
+  const int wstep = a.w_tiled ? 128 : 16;        // floats between consecutive k-steps of one lane
+  const float* xbase = a.x_tiled ? a.x + (size_t)grp * K * 16 : a.x + (size_t)grp * K;
+  const unsigned xvoff = a.x_tiled ? (unsigned)(ks * 16 + c) * 4 : (unsigned)min(c, B - 1) * (unsigned)a.x_stride + ks * 4;
+  const int xstep = a.x_tiled ? 256 : 16;
+
+  float4 w[DEP];
+  float4 xr[SPWX];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (j < nvalid) {
-      if (a.bias) v[j] += a.bias[(size_t)grp * N + r0 + j];
-      if (a.act == SSRHIP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-      else if (a.act == SSRHIP_ACT_GELU_ERF) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752440f));
+  for (int t = 0; t < SPWX; ++t) xr[t] = ld4(xbase + min(tbase + t, last) * xstep + xvoff);
+  __builtin_amdgcn_sched_barrier(0);
+  const float* wp = tile_wptr(wbase, row_lo, nun, 0, c, ks, N, K, a.w_tiled);
+#pragma unroll
+  for (int i = 0; i < DEP; ++i) w[i] = ld_nt(wp + min(tbase + i, last) * wstep);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < SPWX; ++t) asm volatile("" : "+v"(xr[t].x), "+v"(xr[t].y), "+v"(xr[t].z), "+v"(xr[t].w));
+#pragma unroll
+  for (int t = 0; t < SPWX; ++t)
+    if (tbase + t > last) xr[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  if (PRO == SSRHIP_PRO_LAYERNORM) {
+    // the reference's two-pass LayerNorm on the register-resident x (gamma / beta folded into W / bias by the caller);
+    // the first DEP weight loads are in flight meanwhile
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < SPWX; ++t) s += (xr[t].x + xr[t].y) + (xr[t].z + xr[t].w);
+    s = kslot_sum(s);
+    if (ks == 0) red[0][wave][c] = s;
+    __syncthreads();
+    float mean = 0.f;
+    for (int v = 0; v < p.nw; ++v) mean += red[0][v][c];
+    mean /= (float)K;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < SPWX; ++t) {
+      if (tbase + t <= last) {
+        const float dx = xr[t].x - mean, dy = xr[t].y - mean, dz = xr[t].z - mean, dw = xr[t].w - mean;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+    }
+    q = kslot_sum(q);
+    if (ks == 0) red[1][wave][c] = q;
+    __syncthreads();
+    float var = 0.f;
+    for (int v = 0; v < p.nw; ++v) var += red[1][v][c];
+    var /= (float)K;
+    const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+#pragma unroll
+    for (int t = 0; t < SPWX; ++t) {
+      if (tbase + t <= last) {
+        xr[t].x = (xr[t].x - mean) * rstd;
+        xr[t].y = (xr[t].y - mean) * rstd;
+        xr[t].z = (xr[t].z - mean) * rstd;
+        xr[t].w = (xr[t].w - mean) * rstd;
+      }
     }
   }
-  float* dst;
-  if (a.epi == SSRHIP_EPI_QKV_APPEND) {
-    const int D = K, which = r0 / D, cc = r0 % D;
-    if (which == 0) dst = a.y + (size_t)c * a.y_stride + cc;
-    else dst = kv_addr(a.kv, c, a.layer, which - 1, cc / p.hd, a.kv_pos[c]) + (cc % p.hd);
-  } else if (a.y_tiled) {
-    dst = a.y + (size_t)grp * N * 16 + SSRHIP_TILED(c, r0);
-  } else {
-    dst = a.y + (size_t)c * a.y_stride + (size_t)grp * N + r0;
-  }
-  if (a.epi == SSRHIP_EPI_RESIDUAL) {
+
+  // all tiles but the last: the refills past this tile's k-range fetch the head of the next tile
+  for (int tile = 0; tile < ntile - 1; ++tile) {
+    const float* wn = tile_wptr(wbase, row_lo, nun, tile + 1, c, ks, N, K, a.w_tiled);
+    f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < nvalid) v[j] = dst[j] + v[j];
+    for (int t = 0; t < SPWX; ++t) {
+      const float4 wv = w[t % DEP], xv = xr[t];
+      a0 = mfma4(wv.x, xv.x, a0);
+      a1 = mfma4(wv.y, xv.y, a1);
+      a0 = mfma4(wv.z, xv.z, a0);
+      a1 = mfma4(wv.w, xv.w, a1);
+      if (t + DEP < SPWX) w[t % DEP] = ld_nt(wp + min(tbase + t + DEP, last) * wstep);
+      else w[t % DEP] = ld_nt(wn + min(tbase + t + DEP - SPWX, last) * wstep);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    part[tile][wave][lane] = a0 + a1;
+    wp = wn;
   }
-  if (nvalid == 4 && ((reinterpret_cast<size_t>(dst) & 15) == 0)) {
-    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-  } else {
+  {
+    f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < nvalid) dst[j] = v[j];
+    for (int t = 0; t < SPWX; ++t) {
+      const float4 wv = w[t % DEP], xv = xr[t];
+      a0 = mfma4(wv.x, xv.x, a0);
+      a1 = mfma4(wv.y, xv.y, a1);
+      a0 = mfma4(wv.z, xv.z, a0);
+      a1 = mfma4(wv.w, xv.w, a1);
+      if (t + DEP < SPWX) w[t % DEP] = ld_nt(wp + min(tbase + t + DEP, last) * wstep);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    part[ntile - 1][wave][lane] = a0 + a1;
+  }
+  __syncthreads();
+  for (int tile = wave; tile < ntile; tile += p.nw) {
+    f4v acc = part[tile][0][lane];
+    for (int v = 1; v < p.nw; ++v) acc += part[tile][v][lane];
+    tile_epilogue(a, p.hd, grp, row_lo + tile * 16, (2 * tile + 1 < nun) ? 16 : 8, lane, acc);
+  }
+}
+
+// K > 2048 without a LayerNorm prologue (FFN2, K = 8192): x no longer fits the registers of 8 waves, so it is streamed like W: per k-step one KiB of W (HBM) and one
+// KiB of x (L2; the tiled layout makes it one contiguous KiB per wave instruction), 16 of each in flight per wave.
+__global__ __launch_bounds__(512) void gemv_rows_stream_kernel(const GemvR p) {
+  constexpr int DEP = 16;
+  __shared__ f4v part[MAXT][8][64];
+  const ssrhip_gemv_args& a = p.a;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, ks = lane >> 4;
+  const int grp = blockIdx.y;
+  const int N = a.N, K = a.K, B = a.B;
+  const int u_lo = (int)((long long)blockIdx.x * p.units / p.wgs), u_hi = (int)((long long)(blockIdx.x + 1) * p.units / p.wgs);
+  const int nun = u_hi - u_lo;
+  if (nun <= 0) return;
+  const int ntile = (nun + 1) >> 1;
+  const int row_lo = u_lo * 8;
+  const int last = p.steps - 1;
+  const int tbase = wave * p.spw;
+  const int ngrp = p.spw / DEP;                  // groups of DEP k-steps per tile for this wave
+  const float* wbase = a.W + (size_t)grp * (a.w_tiled ? (size_t)p.units * 8 : (size_t)N) * K;
+  const int wstep = a.w_tiled ? 128 : 16;
+  const float* xp = (a.x_tiled ? a.x + (size_t)grp * K * 16 : a.x + (size_t)grp * K) +
+                    (a.x_tiled ? (unsigned)(ks * 16 + c) * 4 : (unsigned)min(c, B - 1) * (unsigned)a.x_stride + ks * 4);
+  const int xstep = a.x_tiled ? 256 : 16;
+
+  float4 w[DEP], xr[DEP];
+  const float* wp = tile_wptr(wbase, row_lo, nun, 0, c, ks, N, K, a.w_tiled);
+#pragma unroll
+  for (int i = 0; i < DEP; ++i) {
+    const int kk = min(tbase + i, last);
+    xr[i] = ld4(xp + kk * xstep);
+    w[i] = ld_nt(wp + kk * wstep);
+  }
+  const int total = ntile * ngrp;
+  f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  int tile = 0, kg = 0;
+  for (int g = 0; g < total - 1; ++g) {
+    // group g = (tile, kg); the refills fetch group g + 1
+    int tile_n = tile, kg_n = kg + 1;
+    if (kg_n == ngrp) { kg_n = 0; tile_n = tile + 1; }
+    const float* wn = (tile_n == tile) ? wp : tile_wptr(wbase, row_lo, nun, tile_n, c, ks, N, K, a.w_tiled);
+    const int kb = tbase + kg * DEP, kbn = tbase + kg_n * DEP;
+#pragma unroll
+    for (int t = 0; t < DEP; ++t) {
+      const float4 wv = w[t];
+      float4 xv = xr[t];
+      if (kb + t > last) xv = make_float4(0.f, 0.f, 0.f, 0.f);           // uniform: k-steps past the end of K contribute nothing
+      a0 = mfma4(wv.x, xv.x, a0);
+      a1 = mfma4(wv.y, xv.y, a1);
+      a0 = mfma4(wv.z, xv.z, a0);
+      a1 = mfma4(wv.w, xv.w, a1);
+      const int kk = min(kbn + t, last);
+      xr[t] = ld4(xp + kk * xstep);
+      w[t] = ld_nt(wn + kk * wstep);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kg_n == 0) {                                                      // uniform: tile finished
+      part[tile][wave][lane] = a0 + a1;
+      a0 = (f4v){0.f, 0.f, 0.f, 0.f};
+      a1 = (f4v){0.f, 0.f, 0.f, 0.f};
+    }
+    tile = tile_n; kg = kg_n; wp = wn;
+  }
+  {
+    const int kb = tbase + kg * DEP;
+#pragma unroll
+    for (int t = 0; t < DEP; ++t) {
+      const float4 wv = w[t];
+      float4 xv = xr[t];
+      if (kb + t > last) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+      a0 = mfma4(wv.x, xv.x, a0);
+      a1 = mfma4(wv.y, xv.y, a1);
+      a0 = mfma4(wv.z, xv.z, a0);
+      a1 = mfma4(wv.w, xv.w, a1);
+    }
+    part[ntile - 1][wave][lane] = a0 + a1;
+  }
+  __syncthreads();
+  for (int t2 = wave; t2 < ntile; t2 += p.nw) {
+    f4v acc = part[t2][0][lane];
+    for (int v = 1; v < p.nw; ++v) acc += part[t2][v][lane];
+    tile_epilogue(a, p.hd, grp, row_lo + t2 * 16, (2 * t2 + 1 < nun) ? 16 : 8, lane, acc);
   }
 }
 
@@ -187,24 +438,66 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s) {
               "ssrhip_gemv (B>4): the split-KV combine prologue is not fused; run ssrhip_attn_combine first");
   SSR_REQUIRE(a->x, "ssrhip_gemv: x is null");
   SSR_REQUIRE(!a->y_tiled || (a->N % 4 == 0 && a->epi != SSRHIP_EPI_QKV_APPEND), "ssrhip_gemv: tiled y needs N %% 4 == 0 and is not available for the q output");
-  GemvM p;
-  p.a = *a;
-  p.steps = a->K / 16;
-  p.nw = (p.steps + SPW - 1) / SPW;
-  if (p.nw > 8) p.nw = 8;
-  p.nchunk = (p.steps + p.nw * SPW - 1) / (p.nw * SPW);
-  p.hd = a->kv.head_dim > 0 ? a->kv.head_dim : 1;
+  static int g_ver = -1, g_cus = 0, g_wpc = 0, g_dep8 = 0;
+  if (g_ver < 0) {
+    const char* e = getenv("SSRHIP_GEMVM_V");          // 1: the per-tile kernel (round 1), 2: rows-per-workgroup kernels (default)
+    g_ver = (e && atoi(e) == 1) ? 1 : 2;
+    int dev = 0, cu = 0;
+    g_cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) ? cu : 256;
+    const char* w = getenv("SSRHIP_GEMVM_WPC");        // tuning knob: 512-thread workgroups per CU (default 1)
+    g_wpc = (w && atoi(w) >= 1 && atoi(w) <= 4) ? atoi(w) : 1;
+    g_dep8 = getenv("SSRHIP_GEMVM_DEP8") != nullptr;   // experiment: 8 instead of 16 weight loads in flight per wave (LayerNorm launches)
+  }
+  const int hd = a->kv.head_dim > 0 ? a->kv.head_dim : 1;
   if (a->pro == SSRHIP_PRO_LAYERNORM) {
-    SSR_REQUIRE(p.nchunk == 1, "ssrhip_gemv (B>4): LayerNorm prologue needs K <= 4096");
+    SSR_REQUIRE(a->K <= 4096, "ssrhip_gemv (B>4): LayerNorm prologue needs K <= 4096");
     SSR_REQUIRE(!a->ln_w && !a->ln_b, "ssrhip_gemv (B>4): LayerNorm gamma/beta must be folded into W/bias (ln_w == ln_b == NULL)");
   }
   if (a->epi == SSRHIP_EPI_QKV_APPEND) {
     SSR_REQUIRE(a->N == 3 * a->K && a->groups == 1 && a->kv.pool && a->kv.table && a->kv_pos && a->kv.head_dim > 0 && a->kv.head_dim % 4 == 0,
                 "ssrhip_gemv: QKV epilogue needs N==3K and a kv cache");
   }
-  // 16-row tiles unless that gives fewer workgroups than CUs (out-proj, FFN2: N/16 = 128) — then 8-row tiles: the duplicate
-  // tile rows cost MFMA cycles (not the bound) but no HBM bytes. Measured (tools/gemvm_bench): out-proj 8.7 -> 7.6 us,
-  // FFN2 31 -> 26 us; for N/16 >= 256 the 16-row tile is faster (QKV 17 vs 21 us).
+  SSR_REQUIRE(!a->w_tiled || g_ver == 2, "ssrhip_gemv (B>4): the streaming-order weight layout needs the rows-per-workgroup kernels (SSRHIP_GEMVM_V=2)");
+  if (g_ver == 2) {
+    GemvR r;
+    r.a = *a;
+    r.steps = a->K / 16;
+    r.hd = hd;
+    r.units = (a->N + 7) / 8;
+    const bool xreg = a->K <= 2048 || a->pro == SSRHIP_PRO_LAYERNORM;   // x slice of every wave in registers; else streamed beside W
+    const int spwx = a->K <= 2048 ? 16 : 32;             // k-steps of x a wave keeps in registers
+    if (xreg) {
+      r.nw = (r.steps + spwx - 1) / spwx;
+      r.spw = spwx;
+    } else {
+      r.nw = 8;
+      r.spw = ((r.steps + 7) / 8 + 15) / 16 * 16;
+    }
+    // one 512-thread workgroup per CU (two when the K split leaves it <= 4 waves), all groups together
+    int target = g_cus * g_wpc * (r.nw <= 4 ? 2 : 1) / a->groups;
+    if (target < 1) target = 1;
+    r.wgs = r.units < target ? r.units : target;
+    const int need = (r.units + 2 * MAXT - 1) / (2 * MAXT);   // LDS holds MAXT tiles of partials per workgroup
+    if (r.wgs < need) r.wgs = need;
+    SSR_REQUIRE(r.wgs <= 65535 * 32, "ssrhip_gemv (B>4): N too large");
+    dim3 grid(r.wgs, a->groups), block(r.nw * 64);
+    if (!xreg) hipLaunchKernelGGL(gemv_rows_stream_kernel, grid, block, 0, s, r);
+    else if (g_dep8 && a->pro == SSRHIP_PRO_LAYERNORM && spwx == 16) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_LAYERNORM, 16, 8>), grid, block, 0, s, r);
+    else if (a->pro == SSRHIP_PRO_LAYERNORM && spwx == 16) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_LAYERNORM, 16>), grid, block, 0, s, r);
+    else if (a->pro == SSRHIP_PRO_LAYERNORM) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_LAYERNORM, 32>), grid, block, 0, s, r);
+    else if (spwx == 16) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_NONE, 16>), grid, block, 0, s, r);
+    else hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_NONE, 32>), grid, block, 0, s, r);
+    SSR_LAUNCH_CHECK();
+    return 0;
+  }
+  GemvM p;
+  p.a = *a;
+  p.steps = a->K / 16;
+  p.nw = (p.steps + SPW - 1) / SPW;
+  if (p.nw > 8) p.nw = 8;
+  p.nchunk = (p.steps + p.nw * SPW - 1) / (p.nw * SPW);
+  p.hd = hd;
+  // 16-row tiles unless that gives fewer workgroups than CUs (out-proj, FFN2: N/16 = 128) — then 8-row tiles
   p.rows = (a->N / 16) * a->groups >= 256 ? 16 : 8;
   if (const char* e = getenv("SSRHIP_GEMVM_ROWS")) { const int v = atoi(e); if (v == 8 || v == 16) p.rows = v; }   // tuning knob
   dim3 grid((a->N + p.rows - 1) / p.rows, a->groups);

@@ -46,6 +46,17 @@ class DecodeKnobs:
     seed: int = 0
 
 
+def to_streaming_order(W: torch.Tensor) -> torch.Tensor:
+    """[.., N, K] row-major -> the matrix-core GEMV's streaming order (include/ssrhip.h SSRHIP_WTILED_INDEX): rows in 8-row
+    units (zero-padded), K in 16-float steps, each (unit, k-step) a 512-byte block indexed [k-slot 0..3][row 0..7][4 floats]."""
+    *lead, N, K = W.shape
+    assert K % 16 == 0, K
+    U = (N + 7) // 8
+    if U * 8 != N:
+        W = torch.cat([W, W.new_zeros(*lead, U * 8 - N, K)], dim=-2)
+    return W.reshape(*lead, U, 8, K // 16, 4, 4).permute(*range(len(lead)), -5, -3, -2, -4, -1).contiguous()
+
+
 class LMWeightsArena:
     """Device-resident fp32 weights in the layout the kernels want (one-time repack at load)."""
 
@@ -99,6 +110,20 @@ class LMWeightsArena:
         self.head2_w = torch.stack([g(f"predict_layer.{k}.2.weight") for k in range(self.K)]).contiguous()
         self.head2_b = torch.stack([g(f"predict_layer.{k}.2.bias") for k in range(self.K)]).contiguous()
 
+    def ensure_streaming_copies(self) -> bool:
+        """Second copy of the six matrices of a decode step in the streaming order of the 5..16-row GEMV (one-time repack; used
+        only by engines with more than 4 rows, +3.3 GB at 830M). Returns True when the copies were created now."""
+        if getattr(self, "_wt_ready", False):
+            return False
+        for lay in self.layers:
+            for name in ("in_proj", "out_proj", "ffn1", "ffn2"):
+                lay[name + "_wt"] = to_streaming_order(lay[name + "_w"])
+        self.head1_wt = to_streaming_order(self.head1_w)
+        self.head2_wt = to_streaming_order(self.head2_w)
+        self._wt_ready = True
+        self.generation += 1
+        return True
+
     def ensure_positions(self, n: int) -> bool:
         """Grow the sinusoidal table so that positions [0, n) exist, like `SinePositionalEmbedding.extend_pe` does on demand
         (models/modules/embedding.py:66-92: no length limit in the reference). Returns True when the table was rebuilt
@@ -114,7 +139,7 @@ class LMWeightsArena:
         """Algorithmic weight bytes one decode step must stream."""
         n = 0
         for lay in self.layers:
-            n += sum(t.numel() for k, t in lay.items())     # incl. the (now constant) LayerNorm vectors, as SURVEY §8d counts them
+            n += sum(t.numel() for k, t in lay.items() if not k.endswith("_wt"))     # incl. the (now constant) LayerNorm vectors, as SURVEY §8d counts them
         n += self.lnf_w.numel() + self.lnf_b.numel()
         n += self.head1_w.numel() + self.head1_b.numel() + self.head2_w.numel() + self.head2_b.numel()
         n += (self.K + 1) * self.D  # K embedding rows + one pe row
@@ -133,6 +158,12 @@ class LMWeightsArena:
         w.lnf_w, w.lnf_b = self.lnf_w.data_ptr(), self.lnf_b.data_ptr()
         w.head1_w, w.head1_b = self.head1_w.data_ptr(), self.head1_b.data_ptr()
         w.head2_w, w.head2_b = self.head2_w.data_ptr(), self.head2_b.data_ptr()
+        if getattr(self, "_wt_ready", False):
+            for name in ("in_proj_wt", "out_proj_wt", "ffn1_wt", "ffn2_wt"):
+                arr = (C.c_void_p * self.L)(*[lay[name].data_ptr() for lay in self.layers])
+                self._arrays[name] = arr
+                setattr(w, name, C.cast(arr, C.POINTER(C.c_void_p)))
+            w.head1_wt, w.head2_wt = self.head1_wt.data_ptr(), self.head2_wt.data_ptr()
         return w
 
     def dims(self):
@@ -243,6 +274,8 @@ class DecodeEngine:
         self.max_pages = (max_seq + PAGE - 1) // PAGE
         self.max_seq = self.max_pages * PAGE
         arena.ensure_positions(self.max_seq)      # every text / audio position of a row is < its sequence capacity
+        if self.B > 4:
+            arena.ensure_streaming_copies()       # the matrix-core GEMV streams W in its own order
         self.max_steps = max_steps
         D, H, L, K = arena.D, arena.H, arena.L, arena.K
         self.hd = D // H

@@ -81,8 +81,11 @@ def test_gemv_grouped_heads(L):
 @pytest.mark.parametrize("B", [5, 8, 16])
 @pytest.mark.parametrize("N,K", [(512, 2048), (96, 8192), (100, 1024), (77, 128), (2056, 1024), (130, 4096), (48, 16)])
 @pytest.mark.parametrize("pro,act,epi", [(0, 0, 0), (1, 1, 0), (1, 2, 0), (0, 0, 1)])
-def test_gemv_mfma_rows_matches_torch(L, B, N, K, pro, act, epi):
-    """B > 4 rows go to gemv_mfma.hip (v_mfma_f32_16x16x4_f32); LayerNorm gamma/beta must be folded by the caller."""
+@pytest.mark.parametrize("wt", [0, 1])
+def test_gemv_mfma_rows_matches_torch(L, B, N, K, pro, act, epi, wt):
+    """B > 4 rows go to gemv_mfma.hip (v_mfma_f32_16x16x4_f32); LayerNorm gamma/beta must be folded by the caller.
+    wt=1: W handed over in the streaming order (SSRHIP_WTILED_INDEX, `engine.to_streaming_order`) the decode engine uses."""
+    from ssr_speech_amd.engine import to_streaming_order
     if pro == 1 and K > 4096:
         pytest.skip("LayerNorm prologue is only used with K = d_model")
     g = torch.Generator().manual_seed(B * 1000 + N + K + pro + act + epi)
@@ -100,12 +103,13 @@ def test_gemv_mfma_rows_matches_torch(L, B, N, K, pro, act, epi):
         bf = (bias.double() + Wt.double() @ lb.double()).float()
     else:
         Wf, bf = Wt, bias
-    dW, db, dx, dy = dev(Wf), dev(bf), dev(x), dev(y0.clone())
+    dW, db, dx, dy = dev(to_streaming_order(Wf) if wt else Wf), dev(bf), dev(x), dev(y0.clone())
     a = _lib.GemvArgs()
     a.W, a.bias, a.x, a.y = dW.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr()
     a.B, a.N, a.K, a.groups, a.x_stride, a.y_stride = B, N, K, 1, K, N
     a.pro, a.act, a.epi = pro, act, epi
     a.ln_eps = 1e-5
+    a.w_tiled = wt
     _lib.check(L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()))
     sync()
     torch.testing.assert_close(dy.cpu(), ref, rtol=3e-5, atol=3e-5)
@@ -125,8 +129,10 @@ def _from_tiled(t, B, K):
 
 @pytest.mark.parametrize("B", [6, 16])
 @pytest.mark.parametrize("G,N,K,pro,act,epi", [(1, 512, 2048, 1, 1, 0), (1, 2048, 8192, 0, 0, 1), (4, 72, 1024, 0, 0, 0), (1, 4096, 2048, 1, 2, 0)])
-def test_gemv_mfma_tiled_activations(L, B, G, N, K, pro, act, epi):
-    """x and/or y in the tiled layout the 5..16-row decode step keeps its activations in."""
+@pytest.mark.parametrize("wt", [0, 1])
+def test_gemv_mfma_tiled_activations(L, B, G, N, K, pro, act, epi, wt):
+    """x and/or y in the tiled layout the 5..16-row decode step keeps its activations in; wt=1: grouped W in streaming order."""
+    from ssr_speech_amd.engine import to_streaming_order
     g = torch.Generator().manual_seed(B + N + K)
     Wt = torch.randn(G, N, K, generator=g) / math.sqrt(K)
     bias = torch.randn(G, N, generator=g)
@@ -136,14 +142,14 @@ def test_gemv_mfma_tiled_activations(L, B, G, N, K, pro, act, epi):
     ref = torch.stack([F.linear(xin[:, k], Wt[k], bias[k]) for k in range(G)], 1)
     ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
     ref = y0 + ref if epi == 1 else ref
-    dW, db = dev(Wt), dev(bias)
+    dW, db = dev(to_streaming_order(Wt) if wt else Wt), dev(bias)
     dx = dev(_to_tiled(x.reshape(B, G * K)))
     dy = dev(_to_tiled(y0.reshape(B, G * N)))
     a = _lib.GemvArgs()
     a.W, a.bias, a.x, a.y = dW.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr()
     a.B, a.N, a.K, a.groups, a.x_stride, a.y_stride = B, N, K, G, 0, 0
     a.pro, a.act, a.epi, a.ln_eps = pro, act, epi, 1e-5
-    a.x_tiled, a.y_tiled = 1, 1
+    a.x_tiled, a.y_tiled, a.w_tiled = 1, 1, wt
     _lib.check(L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()))
     sync()
     got = _from_tiled(dy.cpu(), B, G * N).reshape(B, G, N)
@@ -409,6 +415,7 @@ def _run_sampler_script(L, args, logits_seq, knobs, noise_seq, text_len, audio_p
     cfg.text_len, cfg.n_spans = text_len, n_spans
     cfg.empty_token, cfg.eog, cfg.eos, cfg.sos, cfg.mts, cfg.max_n_spans = args.empty_token, args.eog, args.eos, args.sos, args.mts, args.max_n_spans
     cfg.max_steps = S
+    cfg.use_noise = int(noise_seq is not None)
     st = _lib.SamplerState()
     st.num_cfg_tag, st.prev_token, st.audio_pos = 1, -1, audio_pos0
     dcfg = torch.frombuffer(bytearray(bytes(cfg)), dtype=torch.uint8).cuda()
