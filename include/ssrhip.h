@@ -119,6 +119,11 @@ typedef struct ssrhip_attn_args {
 
 int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t stream);
 int ssrhip_attn_combine(const ssrhip_attn_args* a, float* out /* [R][n_head*head_dim] */, ssrhip_stream_t stream);
+/* The same attention (activation.py:634, tgt_len == 1) WITHOUT splitting over pages: one workgroup per (row, head) walks the
+ * row's pages with an online softmax and writes the normalised output row directly (part_o / part_ml unused, may be NULL;
+ * `out` must not alias q; out_tiled as for ssrhip_attn_combine). Meant for many rows (rows x heads >= the number of CUs): the
+ * 5..16-row decode step. */
+int ssrhip_attn_rows(const ssrhip_attn_args* a, float* out /* [R][n_head*head_dim] */, ssrhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Token embedding + sinusoidal position: replaces embed_y (models/ssr.py:191-198, :655-660, :757-761),

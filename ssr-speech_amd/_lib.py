@@ -152,6 +152,7 @@ SYMBOLS = [
     ("ssrhip_gemv", C.c_int, [C.POINTER(GemvArgs), C.c_void_p]),
     ("ssrhip_attn_decode", C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     ("ssrhip_attn_combine", C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_void_p]),
+    ("ssrhip_attn_rows", C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_void_p]),
     ("ssrhip_embed", C.c_int, [C.POINTER(EmbedArgs), C.c_void_p]),
     ("ssrhip_sample", C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     ("ssrhip_gemm", C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),

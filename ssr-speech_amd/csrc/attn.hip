@@ -168,8 +168,132 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const ssrhip_attn_args
   *reinterpret_cast<float4*>(dst) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused single-query attention for MANY rows (the 5..16-row decode step: 16 rows x 16 heads = 256 (row, head) pairs = one
+// workgroup per CU). One 8-wave workgroup owns a whole (row, head): it walks the row's pages itself, so there are no
+// per-page partials, no merge launch and every CU streams the same number of bytes (rows of a lock-step batch have similar
+// lengths). rocprofv3 at 16 rows, context ~520: the split kernel + combine took 40 + 6.7 us per layer for 136 MB of K/V
+// (3.4 TB/s); here the workgroup keeps two pages in flight (wave w owns keys [16w, 16w+16) of every page: 16 KB of K/V per
+// page per wave, double-buffered = 256 KB per CU) and folds them into a running (m, l, o) — the online softmax — so K/V stream
+// at the HBM rate. The 8 waves' states are merged once through LDS and the normalised output row is written directly in
+// the layout the out-projection GEMV wants (row-major or SSRHIP_TILED).
+// Loads are never predicated (see above): keys past the row's length re-read key 0 of the last page and are masked to -inf.
+constexpr int ATTN_ROWS_MAX_PAGES = 256;       // 32,768 positions per row
+
+template <int HD>
+__global__ __launch_bounds__(512) void attn_rows_kernel(const ssrhip_attn_args a, float* out) {
+  constexpr int LPK = HD / 4, KPI = 64 / LPK, NW = 8, KPW = SSRHIP_PAGE / NW, NI = KPW / KPI;
+  __shared__ __attribute__((aligned(16))) float sm[NW][HD + 4];
+  const int h = blockIdx.x, r = blockIdx.y;
+  const int len = __builtin_amdgcn_readfirstlane(a.row_len[r]);
+  const int seq = __builtin_amdgcn_readfirstlane(a.row_seq ? a.row_seq[r] : r);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane / LPK, c4 = (lane % LPK) * 4;
+  const int H = a.kv.n_head;
+  const int npages = (len + SSRHIP_PAGE - 1) / SSRHIP_PAGE;           // >= 1: a decode row always sees its own key
+  // the row's page ids live in 4 VGPRs (lane i of register b holds page 64b + i) and are picked with v_readlane: a table
+  // lookup inside the loop would be a VECTOR load (the compiler cannot prove the table is not written by this kernel), and
+  // waiting for it — or for an LDS copy of it — drains every K/V load in flight (seen in the ISA: s_waitcnt vmcnt(0))
+  int pid[ATTN_ROWS_MAX_PAGES / 64];
+#pragma unroll
+  for (int b = 0; b < ATTN_ROWS_MAX_PAGES / 64; ++b)
+    pid[b] = (b * 64 < npages) ? a.kv.table[(size_t)seq * a.kv.max_pages + min(b * 64 + lane, npages - 1)] : 0;
+  const size_t head_off = (size_t)h * SSRHIP_PAGE * HD, v_off = (size_t)H * SSRHIP_PAGE * HD;
+  const size_t page_stride = (size_t)a.kv.n_layer * 2 * H * SSRHIP_PAGE * HD;
+  const float* pool = a.kv.pool + (size_t)a.layer * 2 * H * SSRHIP_PAGE * HD + head_off;
+  const float4 q = ld4(a.q + (size_t)r * (a.q_stride ? a.q_stride : H * HD) + h * HD + c4);
+
+  float4 kk[2][NI], vv[2][NI];
+  float m = -INFINITY, l = 0.f;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#define ATTN_ISSUE(BUF, PG)                                                                           \
+  {                                                                                                   \
+    const int pg_ = min((PG), npages - 1);                                                            \
+    const int pb_ = pg_ >> 6;                                                                         \
+    const int pv_ = pb_ == 0 ? pid[0] : (pb_ == 1 ? pid[1] : (pb_ == 2 ? pid[2] : pid[3]));           \
+    const float* kp_ = pool + (size_t)__builtin_amdgcn_readlane(pv_, pg_ & 63) * page_stride;         \
+    const int jmax_ = ((PG) < npages) ? min(len - pg_ * SSRHIP_PAGE, SSRHIP_PAGE) - 1 : 0;            \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                  \
+      const int j_ = min(wave * KPW + i * KPI + sub, jmax_);                                          \
+      kk[BUF][i] = ld4(kp_ + (size_t)j_ * HD + c4);                                                   \
+    }                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                  \
+      const int j_ = min(wave * KPW + i * KPI + sub, jmax_);                                          \
+      vv[BUF][i] = ld4(kp_ + v_off + (size_t)j_ * HD + c4);                                           \
+    }                                                                                                 \
+  }
+#define ATTN_FOLD(BUF, PG)                                                                            \
+  {                                                                                                   \
+    float s_[NI];                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) s_[i] = dot4(q, kk[BUF][i], 0.f);                  \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) s_[i] = (LPK == 32) ? half32_sum(s_[i]) : row16_sum(s_[i]); \
+    float mloc_ = -INFINITY;                                                                          \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                  \
+      const int pos_ = (PG) * SSRHIP_PAGE + wave * KPW + i * KPI + sub;                               \
+      s_[i] = (pos_ < len) ? s_[i] * a.scale : -INFINITY;                                             \
+      mloc_ = fmaxf(mloc_, s_[i]);                                                                    \
+    }                                                                                                 \
+    if (LPK == 16) mloc_ = fmaxf(mloc_, xor16_f(mloc_));                                              \
+    mloc_ = fmaxf(mloc_, xor32_f(mloc_));                                                             \
+    const float mnew_ = fmaxf(m, mloc_);                                                              \
+    if (mnew_ > -INFINITY) {                                                                          \
+      const float al_ = (m > -INFINITY) ? expf(m - mnew_) : 0.f;                                      \
+      l *= al_; o.x *= al_; o.y *= al_; o.z *= al_; o.w *= al_;                                       \
+      _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                \
+        const float p_ = expf(s_[i] - mnew_);                                                         \
+        l += p_;                                                                                      \
+        o.x = fmaf(p_, vv[BUF][i].x, o.x); o.y = fmaf(p_, vv[BUF][i].y, o.y);                         \
+        o.z = fmaf(p_, vv[BUF][i].z, o.z); o.w = fmaf(p_, vv[BUF][i].w, o.w);                         \
+      }                                                                                               \
+      m = mnew_;                                                                                      \
+    }                                                                                                 \
+  }
+
+  ATTN_ISSUE(0, 0)
+  for (int pg = 0; pg < npages; pg += 2) {
+    ATTN_ISSUE(1, pg + 1)
+    ATTN_FOLD(0, pg)
+    ATTN_ISSUE(0, pg + 2)
+    ATTN_FOLD(1, pg + 1)
+  }
+#undef ATTN_ISSUE
+#undef ATTN_FOLD
+  // the KPI key-row groups of the wave share m: their (l, o) simply add
+  if (LPK == 16) {
+    l += xor16_f(l);
+    o.x += xor16_f(o.x); o.y += xor16_f(o.y); o.z += xor16_f(o.z); o.w += xor16_f(o.w);
+  }
+  l += xor32_f(l);
+  o.x += xor32_f(o.x); o.y += xor32_f(o.y); o.z += xor32_f(o.z); o.w += xor32_f(o.w);
+  if (lane < LPK) *reinterpret_cast<float4*>(&sm[wave][c4]) = o;
+  if (lane == 0) { sm[wave][HD] = m; sm[wave][HD + 1] = l; }
+  __syncthreads();
+  if (threadIdx.x < LPK) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w][HD]);
+    float L = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {                                   // fixed wave order: deterministic
+      const float mw = sm[w][HD];
+      const float f = (mw > -INFINITY) ? expf(mw - M) : 0.f;
+      L = fmaf(f, sm[w][HD + 1], L);
+      acc.x = fmaf(f, sm[w][c4 + 0], acc.x);
+      acc.y = fmaf(f, sm[w][c4 + 1], acc.y);
+      acc.z = fmaf(f, sm[w][c4 + 2], acc.z);
+      acc.w = fmaf(f, sm[w][c4 + 3], acc.w);
+    }
+    const float inv = 1.0f / L;
+    const int e = h * HD + c4;
+    float* dst = a.out_tiled ? out + SSRHIP_TILED(r, e) : out + (size_t)r * H * HD + e;
+    *reinterpret_cast<float4*>(dst) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+}
+
 int check(const ssrhip_attn_args* a, const char* who) {
-  SSR_REQUIRE(a && a->q && a->kv.pool && a->kv.table && a->row_len && a->part_o && a->part_ml, "%s: null argument", who);
+  SSR_REQUIRE(a && a->q && a->kv.pool && a->kv.table && a->row_len, "%s: null argument", who);
   SSR_REQUIRE(a->kv.head_dim == 64 || a->kv.head_dim == 128, "%s: head_dim %d not in {64,128}", who, a->kv.head_dim);
   SSR_REQUIRE(a->R > 0 && a->max_splits > 0 && a->max_splits <= a->kv.max_pages, "%s: bad R/max_splits", who);
   return 0;
@@ -192,8 +316,22 @@ static ssrhip_attn_args row_slice(const ssrhip_attn_args& a, int r0, int n) {
 }
 enum { MAX_GRID_ROWS = 65535 };
 
+extern "C" int ssrhip_attn_rows(const ssrhip_attn_args* a, float* out, ssrhip_stream_t stream) {
+  if (int e = check(a, "ssrhip_attn_rows")) return e;
+  SSR_REQUIRE(out && out != a->q, "ssrhip_attn_rows: out is null or aliases q");
+  SSR_REQUIRE(!a->out_tiled || a->R <= 16, "ssrhip_attn_rows: tiled output needs R <= 16");
+  SSR_REQUIRE(a->R <= MAX_GRID_ROWS, "ssrhip_attn_rows: R too large");
+  SSR_REQUIRE(a->kv.max_pages <= ATTN_ROWS_MAX_PAGES, "ssrhip_attn_rows: more than %d pages per row", ATTN_ROWS_MAX_PAGES);
+  dim3 grid(a->kv.n_head, a->R);
+  if (a->kv.head_dim == 128) hipLaunchKernelGGL(attn_rows_kernel<128>, grid, dim3(512), 0, (hipStream_t)stream, *a, out);
+  else hipLaunchKernelGGL(attn_rows_kernel<64>, grid, dim3(512), 0, (hipStream_t)stream, *a, out);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t stream) {
   if (int e = check(a, "ssrhip_attn_decode")) return e;
+  SSR_REQUIRE(a->part_o && a->part_ml, "ssrhip_attn_decode: null partial buffers");
   SSR_REQUIRE(a->R <= MAX_GRID_ROWS || a->row_seq, "ssrhip_attn_decode: more than %d rows need an explicit row_seq", MAX_GRID_ROWS);
   for (int r0 = 0; r0 < a->R; r0 += MAX_GRID_ROWS) {
     const int n = min(a->R - r0, (int)MAX_GRID_ROWS);
@@ -208,7 +346,7 @@ extern "C" int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t str
 
 extern "C" int ssrhip_attn_combine(const ssrhip_attn_args* a, float* out, ssrhip_stream_t stream) {
   if (int e = check(a, "ssrhip_attn_combine")) return e;
-  SSR_REQUIRE(out, "ssrhip_attn_combine: out is null");
+  SSR_REQUIRE(out && a->part_o && a->part_ml, "ssrhip_attn_combine: out or the partial buffers are null");
   SSR_REQUIRE(!a->out_tiled || a->R <= 16, "ssrhip_attn_combine: tiled output needs R <= 16");
   const size_t D = (size_t)a->kv.n_head * a->kv.head_dim;
   for (int r0 = 0; r0 < a->R; r0 += MAX_GRID_ROWS) {

@@ -10,6 +10,7 @@
 // (positions, tokens, stop flags all live in device memory).
 // Replaces the per-iteration body of SSR_Speech.inference (models/ssr.py:671-770).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <vector>
@@ -57,6 +58,11 @@ struct ssrhip_lm {
 namespace {
 
 enum { CAT_GEMV = 0, CAT_ATTN = 1, CAT_SAMPLE = 2 };
+
+bool getenv_flag(const char* name) {      // tuning / A-B knobs, read once per process
+  const char* e = getenv(name);
+  return e && e[0] && e[0] != '0';
+}
 
 struct Timer {   // optional per-launch event timing: one accumulator per launch slot of a step
   bool on = false;
@@ -118,7 +124,15 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     at.q = b.q; at.kv = b.kv; at.layer = l; at.row_seq = nullptr; at.row_len = b.row_len;
     at.R = B; at.max_splits = b.max_splits; at.scale = 1.0f / sqrtf((float)(D / d.n_head));
     at.part_o = b.part_o; at.part_ml = b.part_ml;
-    STEP_CALL(CAT_ATTN, ssrhip_attn_decode(&at, s));
+    // 5..16 rows with enough (row, head) pairs to give every CU one: the fused walk over the pages (no partials, no merge
+    // launch); its output goes to b.h (free until FFN1 of this layer) because q is still being read by other workgroups
+    const bool fused_attn = B > 4 && B * d.n_head >= 192 && !getenv_flag("SSRHIP_ATTN_SPLIT");
+    if (fused_attn) {
+      at.out_tiled = 1;
+      STEP_CALL(CAT_ATTN, ssrhip_attn_rows(&at, b.h, s));
+    } else {
+      STEP_CALL(CAT_ATTN, ssrhip_attn_decode(&at, s));
+    }
 
     // split-KV combine + out-proj + residual
     memset(&g, 0, sizeof(g));
@@ -128,10 +142,15 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.part_o = b.part_o; g.part_ml = b.part_ml; g.max_splits = b.max_splits; g.row_len = b.row_len;
     g.kv = b.kv;
     if (B > 4) {
-      // 5..16 rows (matrix-core GEMV): the combine is its own small launch; q is dead after the attention, reuse it
-      at.out_tiled = 1;
-      STEP_CALL(CAT_ATTN, ssrhip_attn_combine(&at, b.q, s));
-      g.pro = SSRHIP_PRO_NONE; g.x = b.q; g.x_tiled = 1; g.y_tiled = 1;
+      if (fused_attn) {
+        g.x = b.h;
+      } else {
+        // the combine is its own small launch; q is dead after the attention, reuse it
+        at.out_tiled = 1;
+        STEP_CALL(CAT_ATTN, ssrhip_attn_combine(&at, b.q, s));
+        g.x = b.q;
+      }
+      g.pro = SSRHIP_PRO_NONE; g.x_tiled = 1; g.y_tiled = 1;
       if (wt) { g.W = w.out_proj_wt[l]; g.w_tiled = 1; }
     }
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));

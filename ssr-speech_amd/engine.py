@@ -190,6 +190,7 @@ class PagePool:
     def reset(self):
         self._free = self._order[::-1]          # pop() hands out order[0] first
         self._owner = {}
+        self.handed_out = []                    # (page, owner) in hand-out order since the last reset (tests / debugging)
 
     @property
     def n_free(self) -> int:
@@ -200,6 +201,7 @@ class PagePool:
             raise RuntimeError(f"KV page pool exhausted ({self.n_pages} pages of {PAGE} positions): raise pool_pages")
         p = self._free.pop()
         self._owner[p] = owner
+        self.handed_out.append((p, owner))
         return p
 
     def give_back(self, pages: Sequence[int]):

@@ -224,7 +224,7 @@ def _gather(pool, table, seq, layer, which, h, length):
 def test_attention_decode_and_combine(L, hd):
     g = torch.Generator().manual_seed(hd)
     H, n_layer, max_pages, layer = 4, 2, 4, 1
-    lens = [1, 5, 128, 129, 300, 512]
+    lens = [1, 5, 128, 129, 300, 512, 16, 17, 255, 256, 257, 385]
     R = len(lens)
     pool, table = _make_cache(R, max_pages, n_layer, H, hd, g)
     q = torch.randn(R, H * hd, generator=g)
@@ -249,6 +249,16 @@ def test_attention_decode_and_combine(L, hd):
     _lib.check(L.ssrhip_attn_combine(C.byref(a), out.data_ptr(), _lib.stream_ptr()))
     sync()
     torch.testing.assert_close(out.cpu(), ref, rtol=2e-5, atol=2e-5)
+    # the fused walk over the pages (one workgroup per (row, head), online softmax, no partials): same result, row-major and tiled
+    for tiled in (0, 1):
+        out2 = torch.full((16 * H * hd,), float("nan"), device="cuda")
+        a.out_tiled, a.part_o, a.part_ml = tiled, 0, 0
+        _lib.check(L.ssrhip_attn_rows(C.byref(a), out2.data_ptr(), _lib.stream_ptr()))
+        sync()
+        got2 = _from_tiled(out2.cpu(), R, H * hd) if tiled else out2.cpu()[: R * H * hd].view(R, H * hd)
+        torch.testing.assert_close(got2, ref, rtol=2e-5, atol=2e-5)
+    a.out_tiled, a.part_o, a.part_ml = 0, part_o.data_ptr(), part_ml.data_ptr()
+    assert L.ssrhip_attn_rows(C.byref(a), dq.data_ptr(), _lib.stream_ptr()) != 0          # out must not alias q
     # the same partials merged inside the out-projection GEMV prologue
     Wt = torch.randn(48, H * hd, generator=g) / math.sqrt(H * hd)
     for r0 in (0, 2, 4):
