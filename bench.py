@@ -378,8 +378,14 @@ def main():
         achieved = bytes_per_launch / (gemv_us * 1e-6) / 1e9
         # per-shape view of one layer (slots 0..4 = QKV, attention, out-proj, FFN1, FFN2 of layer 0.., averaged over layers)
         nl = arena.L
-        shape_names = ["ln1+qkv", "attn", "combine+out_proj", "ln2+ffn1", "ffn2"] if 2 * U <= 4 else \
-                      ["ln1+qkv", "attn", "combine", "out_proj", "ln2+ffn1", "ffn2"]       # > 4 rows: the combine is its own launch
+        ns_slots = (len(slots) - 3) // nl                 # launches per layer as the engine enqueued them
+        if 2 * U <= 4:
+            shape_names = ["ln1+qkv", "attn", "combine+out_proj", "ln2+ffn1", "ffn2"]
+        elif ns_slots == 5:                               # > 4 rows, fused walk over the pages (ssrhip_attn_rows): no combine launch
+            shape_names = ["ln1+qkv", "attn_rows", "out_proj", "ln2+ffn1", "ffn2"]
+        else:                                             # > 4 rows, split attention: the combine is its own launch
+            shape_names = ["ln1+qkv", "attn", "combine", "out_proj", "ln2+ffn1", "ffn2"]
+        assert ns_slots == len(shape_names), (ns_slots, shape_names)
         ns = len(shape_names)
         per_shape = {shape_names[j]: round(sum(slots[l * ns + j][1] for l in range(nl)) / nl, 3) for j in range(ns)}
         per_shape.update({"lnf+head1": round(slots[nl * ns][1], 3), "head2": round(slots[nl * ns + 1][1], 3), "sample+embed": round(slots[nl * ns + 2][1], 3)})
@@ -402,7 +408,8 @@ def main():
                          # for wide reads applied: 50.5 MB read + 0.1 MB written per GEMV launch vs 49.85 MB algorithmic
                          "traffic": TRAFFIC_BYTES_PER_GEMV_LAUNCH if (arena.D == 2048 and arena.L == 16 and U == 1) else None,
                          "traffic_source": TRAFFIC_SOURCE,
-                         "kernel": "gemv_fast_kernel<2,*> (fused LN/combine + GEMV + bias/act/residual), all 66 launches of a step",
+                         "kernel": ("gemv_fast_kernel<2,*> (fused LN/combine + GEMV + bias/act/residual), all 66 launches of a step" if 2 * U <= 4 else
+                                    "gemv_rows_xreg_kernel / gemv_rows_stream_kernel (matrix-core GEMV, streaming-order weights), all 66 launches of a step"),
                          "bytes_per_launch": int(bytes_per_launch), "launches_per_step": n_gemv, "us_per_launch": round(gemv_us, 3),
                          "us_per_launch_eager_event_pair": round(gemv_us_eager, 3),
                          "other_kernels_us_per_launch": {"attn_decode": round(attn_us, 3), "sample+embed": round(samp_us, 3)},

@@ -46,43 +46,67 @@ __device__ __forceinline__ float kslot_sum(float v) {
 
 // Epilogue of one 16x16 output tile: this lane holds rows r0 = row0 + 4*(lane/16) .. r0+3 of batch column c = lane%16
 // (only the first `tile_rows` rows of the tile are real: 16, or 8 when the tile's rows 8..15 duplicate 0..7).
-__device__ __forceinline__ void tile_epilogue(const ssrhip_gemv_args& a, int hd, int grp, int row0, int tile_rows, int lane, f4v acc) {
+// Split in two so that everything the epilogue has to FETCH — bias, the residual, and for the QKV launch the cache address
+// (kv_pos -> page table -> pool: two dependent loads) — is requested before the weight loop and has long arrived when the
+// last MFMA retires; otherwise that latency chain (1-2 us) sits in the tail of every launch with the HBM idle.
+struct TileEpi {
+  float* dst;
+  float bias[4], res[4];
+  int nvalid;        // 0: this lane stores nothing
+};
+
+__device__ __forceinline__ TileEpi tile_epilogue_fetch(const ssrhip_gemv_args& a, int hd, int grp, int row0, int tile_rows, int lane) {
+  TileEpi e;
   const int c = lane & 15, ks = lane >> 4;
   const int N = a.N, K = a.K, B = a.B;
   const int r0 = row0 + ks * 4;
-  if (c >= B || r0 >= N || ks * 4 >= tile_rows) return;
-  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-  const int nvalid = min(4, N - r0);
+  e.dst = nullptr;
+  e.nvalid = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (j < nvalid) {
-      if (a.bias) v[j] += a.bias[(size_t)grp * N + r0 + j];
-      if (a.act == SSRHIP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-      else if (a.act == SSRHIP_ACT_GELU_ERF) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752440f));
-    }
-  }
-  float* dst;
+  for (int j = 0; j < 4; ++j) { e.bias[j] = 0.f; e.res[j] = 0.f; }
+  if (c >= B || r0 >= N || ks * 4 >= tile_rows) return e;
+  e.nvalid = min(4, N - r0);
   if (a.epi == SSRHIP_EPI_QKV_APPEND) {
     const int D = K, which = r0 / D, cc = r0 % D;
-    if (which == 0) dst = a.y + (size_t)c * a.y_stride + cc;
-    else dst = kv_addr(a.kv, c, a.layer, which - 1, cc / hd, a.kv_pos[c]) + (cc % hd);
+    if (which == 0) e.dst = a.y + (size_t)c * a.y_stride + cc;
+    else e.dst = kv_addr(a.kv, c, a.layer, which - 1, cc / hd, a.kv_pos[c]) + (cc % hd);
   } else if (a.y_tiled) {
-    dst = a.y + (size_t)grp * N * 16 + SSRHIP_TILED(c, r0);
+    e.dst = a.y + (size_t)grp * N * 16 + SSRHIP_TILED(c, r0);
   } else {
-    dst = a.y + (size_t)c * a.y_stride + (size_t)grp * N + r0;
+    e.dst = a.y + (size_t)c * a.y_stride + (size_t)grp * N + r0;
   }
-  if (a.epi == SSRHIP_EPI_RESIDUAL) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < e.nvalid) {
+      if (a.bias) e.bias[j] = a.bias[(size_t)grp * N + r0 + j];
+      if (a.epi == SSRHIP_EPI_RESIDUAL) e.res[j] = e.dst[j];
+    }
+  }
+  return e;
+}
+
+__device__ __forceinline__ void tile_epilogue_finish(const ssrhip_gemv_args& a, const TileEpi& e, f4v acc) {
+  if (e.nvalid == 0) return;
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] += e.bias[j];
+    if (a.act == SSRHIP_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+    else if (a.act == SSRHIP_ACT_GELU_ERF) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752440f));
+    v[j] = e.res[j] + v[j];                         // res == 0 unless EPI_RESIDUAL (same operand order as the fused add: y + v)
+  }
+  if (e.nvalid == 4 && ((reinterpret_cast<size_t>(e.dst) & 15) == 0)) {
+    *reinterpret_cast<float4*>(e.dst) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (j < nvalid) v[j] = dst[j] + v[j];
+      if (j < e.nvalid) e.dst[j] = v[j];
   }
-  if (nvalid == 4 && ((reinterpret_cast<size_t>(dst) & 15) == 0)) {
-    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < nvalid) dst[j] = v[j];
-  }
+}
+
+__device__ __forceinline__ void tile_epilogue(const ssrhip_gemv_args& a, int hd, int grp, int row0, int tile_rows, int lane, f4v acc) {
+  const TileEpi e = tile_epilogue_fetch(a, hd, grp, row0, tile_rows, lane);
+  tile_epilogue_finish(a, e, acc);
 }
 
 template <int PRO>
@@ -260,6 +284,10 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
 #pragma unroll
   for (int i = 0; i < DEP; ++i) w[i] = ld_nt(wp + min(tbase + i, last) * wstep);
   __builtin_amdgcn_sched_barrier(0);
+  // what this wave's epilogue (tile `wave`) will need, requested now (behind the first weight loads, used after the last MFMA)
+  const bool epi_mine = wave < ntile;
+  const TileEpi epi0 = tile_epilogue_fetch(a, p.hd, grp, row_lo + wave * 16, epi_mine ? ((2 * wave + 1 < nun) ? 16 : 8) : 0, lane);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = 0; t < SPWX; ++t) asm volatile("" : "+v"(xr[t].x), "+v"(xr[t].y), "+v"(xr[t].z), "+v"(xr[t].w));
 #pragma unroll
@@ -267,30 +295,35 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
     if (tbase + t > last) xr[t] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   if (PRO == SSRHIP_PRO_LAYERNORM) {
-    // the reference's two-pass LayerNorm on the register-resident x (gamma / beta folded into W / bias by the caller);
-    // the first DEP weight loads are in flight meanwhile
+    // LayerNorm on the register-resident x (gamma / beta folded into W / bias by the caller) with ONE workgroup barrier: every
+    // wave computes the two-pass mean / sum of squared deviations of ITS K-slice, the slices are merged with the exact
+    // pairwise-update identity  M2 = sum_w M2_w + sum_w n_w (mean_w - mean)^2  (Chan et al.) — as accurate as the reference's
+    // two-pass over the whole row. The first DEP weight loads are in flight meanwhile.
+    const int nval = max(0, min(SPWX, last + 1 - tbase)) * 16;       // floats of K in this wave's slice (uniform)
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < SPWX; ++t) s += (xr[t].x + xr[t].y) + (xr[t].z + xr[t].w);
     s = kslot_sum(s);
-    if (ks == 0) red[0][wave][c] = s;
-    __syncthreads();
-    float mean = 0.f;
-    for (int v = 0; v < p.nw; ++v) mean += red[0][v][c];
-    mean /= (float)K;
+    const float mw = nval > 0 ? s / (float)nval : 0.f;
     float q = 0.f;
 #pragma unroll
     for (int t = 0; t < SPWX; ++t) {
       if (tbase + t <= last) {
-        const float dx = xr[t].x - mean, dy = xr[t].y - mean, dz = xr[t].z - mean, dw = xr[t].w - mean;
+        const float dx = xr[t].x - mw, dy = xr[t].y - mw, dz = xr[t].z - mw, dw = xr[t].w - mw;
         q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
       }
     }
     q = kslot_sum(q);
-    if (ks == 0) red[1][wave][c] = q;
+    if (ks == 0) { red[0][wave][c] = mw; red[1][wave][c] = q; }
     __syncthreads();
+    float mean = 0.f;
+    for (int v = 0; v < p.nw; ++v) mean += red[0][v][c] * (float)(max(0, min(SPWX, last + 1 - v * SPWX)) * 16);
+    mean /= (float)K;
     float var = 0.f;
-    for (int v = 0; v < p.nw; ++v) var += red[1][v][c];
+    for (int v = 0; v < p.nw; ++v) {
+      const float d = red[0][v][c] - mean;
+      var += red[1][v][c] + (float)(max(0, min(SPWX, last + 1 - v * SPWX)) * 16) * d * d;
+    }
     var /= (float)K;
     const float rstd = 1.0f / sqrtf(var + a.ln_eps);
 #pragma unroll
@@ -340,7 +373,8 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
   for (int tile = wave; tile < ntile; tile += p.nw) {
     f4v acc = part[tile][0][lane];
     for (int v = 1; v < p.nw; ++v) acc += part[tile][v][lane];
-    tile_epilogue(a, p.hd, grp, row_lo + tile * 16, (2 * tile + 1 < nun) ? 16 : 8, lane, acc);
+    if (tile == wave) tile_epilogue_finish(a, epi0, acc);
+    else tile_epilogue(a, p.hd, grp, row_lo + tile * 16, (2 * tile + 1 < nun) ? 16 : 8, lane, acc);
   }
 }
 
@@ -376,6 +410,10 @@ __global__ __launch_bounds__(512) void gemv_rows_stream_kernel(const GemvR p) {
     xr[i] = ld4(xp + kk * xstep);
     w[i] = ld_nt(wp + kk * wstep);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  const bool epi_mine = wave < ntile;
+  const TileEpi epi0 = tile_epilogue_fetch(a, p.hd, grp, row_lo + wave * 16, epi_mine ? ((2 * wave + 1 < nun) ? 16 : 8) : 0, lane);
+  __builtin_amdgcn_sched_barrier(0);
   const int total = ntile * ngrp;
   f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   int tile = 0, kg = 0;
@@ -424,7 +462,8 @@ __global__ __launch_bounds__(512) void gemv_rows_stream_kernel(const GemvR p) {
   for (int t2 = wave; t2 < ntile; t2 += p.nw) {
     f4v acc = part[t2][0][lane];
     for (int v = 1; v < p.nw; ++v) acc += part[t2][v][lane];
-    tile_epilogue(a, p.hd, grp, row_lo + t2 * 16, (2 * t2 + 1 < nun) ? 16 : 8, lane, acc);
+    if (t2 == wave) tile_epilogue_finish(a, epi0, acc);
+    else tile_epilogue(a, p.hd, grp, row_lo + t2 * 16, (2 * t2 + 1 < nun) ? 16 : 8, lane, acc);
   }
 }
 
