@@ -224,6 +224,10 @@ int ssrhip_gemm(const ssrhip_gemm_args* a, ssrhip_stream_t stream);
 /* first conv of SEANet (Cin == 1): out[b][t][co] = bias[co] + sum_kk w[co][kk] * x[b][t*stride + kk]  (x pre-padded) */
 int ssrhip_conv_cin1(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t T_out, int32_t k,
                      int32_t stride, int32_t Cout, int64_t x_bstride, int64_t out_bstride, ssrhip_stream_t stream);
+/* convolution with at most 4 OUTPUT channels on a time-major, pre-padded input (SEANet's last layer, 64 -> 1, k = 7; conv.py:185-201):
+ * out[b][t][co] = bias[co] + sum_{kk, ci} w[co][kk][ci] * act_in(x[b][t + kk][ci]);  w is [Cout][k][Cin]; act_in NONE or ELU */
+int ssrhip_conv_few_out(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t T_out, int32_t k,
+                        int32_t Cin, int32_t Cout, int32_t act_in, int64_t x_bstride, int64_t out_bstride, ssrhip_stream_t stream);
 /* reflect padding of a time-major buffer (conv.py:71-88): rows [0,padL) and [padL+T, padL+T+padR) mirror the interior */
 int ssrhip_pad_reflect(float* buf, int32_t B, int32_t T, int32_t padL, int32_t padR, int32_t C, int64_t bstride,
                        ssrhip_stream_t stream);

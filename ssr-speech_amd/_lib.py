@@ -156,6 +156,7 @@ SYMBOLS = [
     ("ssrhip_embed", C.c_int, [C.POINTER(EmbedArgs), C.c_void_p]),
     ("ssrhip_sample", C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     ("ssrhip_gemm", C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    ("ssrhip_conv_few_out", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     ("ssrhip_conv_cin1", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     ("ssrhip_pad_reflect", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     ("ssrhip_lstm_layer", C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),

@@ -17,7 +17,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* x, const float* w, const float* bias, float* out, int T_out,
                                                         int k, int stride, int Cout, long x_bstride, long out_bstride) {
-  // thread -> (t, co) with co fastest: coalesced stores; x reads are broadcast within a row of threads
+  // generic fallback (C_out not a multiple of 4 or k > 8): thread -> (t, co) with co fastest
   const long total = (long)T_out * Cout;
   const float* xb = x + (size_t)blockIdx.y * x_bstride;
   float* ob = out + (size_t)blockIdx.y * out_bstride;
@@ -26,6 +26,84 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(const float* x, const fl
     float acc = 0.f;
     for (int kk = 0; kk < k; ++kk) acc = fmaf(w[co * k + kk], xb[(size_t)t * stride + kk], acc);
     ob[i] = acc + bias[co];
+  }
+}
+
+// The same convolution as a store-bound streaming kernel (SEANet's first layer writes B x T x 64 floats: 3.9 GB at 32 clips x
+// 30 s; the generic kernel above spent 5.8 ms there in 64-bit index arithmetic and scalar stores). A 256-thread workgroup
+// owns TT consecutive output times: the input window goes to LDS once, a thread keeps the K taps of its 4 output channels
+// in registers and writes one float4 per time step (C_out/4 threads cover a row: 256 contiguous bytes at C_out = 64).
+template <int KT>
+__global__ __launch_bounds__(256) void conv_cin1_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int T_out,
+                                                            int stride, int Cout, long x_bstride, long out_bstride, int TT) {
+  extern __shared__ float xs[];                       // (TT - 1) * stride + KT input samples
+  const float* xb = x + (size_t)blockIdx.y * x_bstride;
+  float* ob = out + (size_t)blockIdx.y * out_bstride;
+  const int t0 = blockIdx.x * TT;
+  const int nt = min(TT, T_out - t0);
+  const int nin = (nt - 1) * stride + KT;
+  for (int i = threadIdx.x; i < nin; i += 256) xs[i] = xb[(size_t)t0 * stride + i];
+  const int tpr = Cout >> 2;                           // threads per output row
+  const int co = (threadIdx.x % tpr) * 4, tl = threadIdx.x / tpr, tstep = 256 / tpr;
+  float wr[4][KT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) wr[j][kk] = w[(co + j) * KT + kk];
+  const float4 b4 = make_float4(bias[co], bias[co + 1], bias[co + 2], bias[co + 3]);
+  __syncthreads();
+  for (int t = tl; t < nt; t += tstep) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+      const float xv = xs[t * stride + kk];
+      a0 = fmaf(wr[0][kk], xv, a0);
+      a1 = fmaf(wr[1][kk], xv, a1);
+      a2 = fmaf(wr[2][kk], xv, a2);
+      a3 = fmaf(wr[3][kk], xv, a3);
+    }
+    *reinterpret_cast<float4*>(ob + (size_t)(t0 + t) * Cout + co) = make_float4(a0 + b4.x, a1 + b4.y, a2 + b4.z, a3 + b4.w);
+  }
+}
+
+// Convolution with very few OUTPUT channels (SEANet's last layer: 64 -> 1, k = 7, at the full sample rate) on a time-major input:
+// the im2col row of output t is the CONTIGUOUS window x[t*C_in .. (t+k)*C_in) — a dot product of K = k*C_in floats per output.
+// A GEMM tile wastes 31/32 of its columns on it (7.4 ms per call at 32 x 30 s); this is the read-bound form: a workgroup stages
+// TT + k - 1 input rows in LDS with the ELU applied once per element (rows padded to C_in + 1 floats: lane t reads row t, so
+// consecutive lanes hit consecutive banks), a lane owns one output time and walks the window against the weights (uniform
+// addresses: scalar loads).
+__global__ __launch_bounds__(256) void conv_few_out_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int T_out,
+                                                           int k, int Cin, int Cout, int act_in, long x_bstride, long out_bstride, int TT) {
+  extern __shared__ float xs[];                       // (TT + k - 1) rows of C_in + 1
+  const float* xb = x + (size_t)blockIdx.y * x_bstride;
+  float* ob = out + (size_t)blockIdx.y * out_bstride;
+  const int t0 = blockIdx.x * TT;
+  const int nt = min(TT, T_out - t0);
+  const int rows = nt + k - 1, ldr = Cin + 1;
+  const int c4n = Cin >> 2;
+  for (int i = threadIdx.x; i < rows * c4n; i += 256) {
+    const int r = i / c4n, c = (i % c4n) * 4;
+    float4 v = ld4(xb + ((size_t)(t0 + r)) * Cin + c);
+    if (act_in == SSRHIP_ACT_ELU) {
+      v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);       // same ELU as the GEMM's operand load (common.h)
+    }
+    float* d = xs + r * ldr + c;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const int K = k * Cin;
+  for (int t = threadIdx.x; t < nt; t += 256) {
+    for (int co = 0; co < Cout; ++co) {
+      const float* wr = w + (size_t)co * K;           // [k][C_in] (the GEMM layout of the same layer)
+      float acc = 0.f;
+      for (int kk = 0; kk < k; ++kk) {
+        const float* xr = xs + (t + kk) * ldr;
+        for (int c = 0; c < Cin; ++c) acc = fmaf(wr[kk * Cin + c], xr[c], acc);
+      }
+      ob[(size_t)(t0 + t) * Cout + co] = acc + bias[co];
+    }
   }
 }
 
@@ -397,8 +475,35 @@ inline int nblocks(long total, int cap = 4096) {
 extern "C" int ssrhip_conv_cin1(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t T_out, int32_t k,
                                 int32_t stride, int32_t Cout, int64_t x_bstride, int64_t out_bstride, ssrhip_stream_t stream) {
   SSR_REQUIRE(x && w && bias && out && B > 0 && T_out > 0 && k > 0 && stride > 0 && Cout > 0, "ssrhip_conv_cin1: bad argument");
-  dim3 grid(nblocks((long)T_out * Cout, 16384), B);
-  hipLaunchKernelGGL(conv_cin1_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, T_out, k, stride, Cout, (long)x_bstride, (long)out_bstride);
+  SSR_REQUIRE(B <= 65535, "ssrhip_conv_cin1: batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout % 4 == 0 && Cout <= 1024 && (256 % (Cout / 4)) == 0 && (k == 7 || k == 3 || k == 5) && stride <= 4) {
+    const int TT = 512;
+    dim3 grid((T_out + TT - 1) / TT, B);
+    const size_t smem = ((size_t)(TT - 1) * stride + k) * sizeof(float);
+    if (k == 7) hipLaunchKernelGGL(conv_cin1_vec_kernel<7>, grid, dim3(256), smem, s, x, w, bias, out, T_out, stride, Cout, (long)x_bstride, (long)out_bstride, TT);
+    else if (k == 5) hipLaunchKernelGGL(conv_cin1_vec_kernel<5>, grid, dim3(256), smem, s, x, w, bias, out, T_out, stride, Cout, (long)x_bstride, (long)out_bstride, TT);
+    else hipLaunchKernelGGL(conv_cin1_vec_kernel<3>, grid, dim3(256), smem, s, x, w, bias, out, T_out, stride, Cout, (long)x_bstride, (long)out_bstride, TT);
+  } else {
+    dim3 grid(nblocks((long)T_out * Cout, 16384), B);
+    hipLaunchKernelGGL(conv_cin1_kernel, grid, dim3(256), 0, s, x, w, bias, out, T_out, k, stride, Cout, (long)x_bstride, (long)out_bstride);
+  }
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ssrhip_conv_few_out(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t T_out, int32_t k,
+                                   int32_t Cin, int32_t Cout, int32_t act_in, int64_t x_bstride, int64_t out_bstride, ssrhip_stream_t stream) {
+  SSR_REQUIRE(x && w && bias && out && B > 0 && T_out > 0 && k > 0 && Cin > 0 && Cout > 0, "ssrhip_conv_few_out: bad argument");
+  SSR_REQUIRE(Cin % 4 == 0 && Cout <= 4 && B <= 65535, "ssrhip_conv_few_out: needs C_in %% 4 == 0 and C_out <= 4");
+  SSR_REQUIRE(act_in == SSRHIP_ACT_NONE || act_in == SSRHIP_ACT_ELU, "ssrhip_conv_few_out: act_in must be NONE or ELU");
+  int TT = 256;
+  while (TT > 32 && (size_t)(TT + k - 1) * (Cin + 1) * sizeof(float) > 72 * 1024) TT >>= 1;     // two workgroups per CU
+  const size_t smem = (size_t)(TT + k - 1) * (Cin + 1) * sizeof(float);
+  SSR_REQUIRE(smem <= 160 * 1024, "ssrhip_conv_few_out: C_in * k too large");
+  dim3 grid((T_out + TT - 1) / TT, B);
+  hipLaunchKernelGGL(conv_few_out_kernel, grid, dim3(256), smem, (hipStream_t)stream, x, w, bias, out, T_out, k, Cin, Cout, act_in,
+                     (long)x_bstride, (long)out_bstride, TT);
   SSR_LAUNCH_CHECK();
   return 0;
 }

@@ -131,6 +131,16 @@ __device__ __forceinline__ float4 ld_nt(const float* p) {
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// nn.ELU(alpha=1) on operand load. libm's expm1f costs ~40 VALU ops and the convolution views re-load every input element
+// k (taps) x N-tiles times — it made the narrow SEANet layers VALU-bound. exp(v)-1 for v <= 0 as: degree-6 Taylor for
+// v > -0.25 (truncation 1.2e-8), else v_exp_f32 - 1 (abs error <= 1.2e-7 on a result >= 0.22 in magnitude).
+__device__ __forceinline__ float elu1(float v) {
+  const float p = v * (1.0f + v * (0.5f + v * (0.16666667f + v * (0.041666668f + v * (0.0083333338f + v * 0.0013888889f)))));
+  const float e = __expf(v) - 1.0f;
+  const float neg = v > -0.25f ? p : e;
+  return v > 0.f ? v : neg;
+}
+
 // address of element (pos, d) of head h, k(0)/v(1), layer, in sequence `seq`'s paged cache
 __device__ __forceinline__ float* kv_addr(const ssrhip_kv& kv, int seq, int layer, int which, int h, int pos) {
   const int page = kv.table[(size_t)seq * kv.max_pages + (pos / SSRHIP_PAGE)];

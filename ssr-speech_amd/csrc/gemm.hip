@@ -23,16 +23,6 @@ __device__ __forceinline__ float act_fn(float v, int act) {
   return v;
 }
 
-// nn.ELU(alpha=1) on operand load. libm's expm1f costs ~40 VALU ops and the convolution views re-load every input element
-// k (taps) x N-tiles times — it made the narrow SEANet layers VALU-bound. exp(v)-1 for v <= 0 as: degree-6 Taylor for
-// v > -0.25 (truncation 1.2e-8), else v_exp_f32 - 1 (abs error <= 1.2e-7 on a result >= 0.22 in magnitude).
-__device__ __forceinline__ float elu1(float v) {
-  const float p = v * (1.0f + v * (0.5f + v * (0.16666667f + v * (0.041666668f + v * (0.0083333338f + v * 0.0013888889f)))));
-  const float e = __expf(v) - 1.0f;
-  const float neg = v > -0.25f ? p : e;
-  return v > 0.f ? v : neg;
-}
-
 // 4 waves arranged MW x NW; each wave owns MT x NT accumulator blocks of 32x32. Block tile = (MW*MT*32) x (NW*NT*32) x 16.
 //   <1,4,2,1>  64 x 128 : the general shape (prefill, wide convolutions, LSTM input GEMM)
 //   <2,2,1,1>  64 x  64 : when 64 x 128 tiles would not even give one workgroup per CU (prefill of a single prompt: M ~ 600,
