@@ -48,6 +48,8 @@ LM_CASES = [
 ]
 
 
+PRESENT_CASES = {"tts_greedy_cfg5", "edit_2span_greedy", "tts_greedy_hd128", "tts_greedy_nocfg"}     # fixtures that also carry the prefill K/V
+
 _G = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5)
 LM_CTX_CASES = [
     # aug_context (prompt_x/prompt prepended, ssr.py:563-594,607-608,806-810) and cfg_pretrained (:576,:631-634)
@@ -96,6 +98,18 @@ def make_lm(cases=None):
             return tok
 
         ssr.topk_sampling = spy
+        # G3: what the reference's first dec_forward (the prefill over [text || prompt audio || mask token], ssr.py:673-684)
+        # returns as `present` — the K/V of every layer, [n_layer, 2, B, H, S0, head_dim]
+        first_present = {}
+        real_dec_forward = m.dec_forward
+
+        def dec_spy(*a, **k):
+            r = real_dec_forward(*a, **k)
+            if "present" not in first_present and r[1] is not None:
+                first_present["present"] = r[1].detach().clone()
+            return r
+
+        m.dec_forward = dec_spy
         try:
             torch.manual_seed(seed)
             ctx_on = bool(kw.get("aug_context")) and sum(b - a for a, b in mi) < 100
@@ -116,7 +130,8 @@ def make_lm(cases=None):
             weight_seed=np.asarray(seed), torch_seed=np.asarray(seed), x=x.numpy(), y=y.numpy(), mask_interval=mask_interval.numpy(),
             prompt_x=prompt_x.numpy(), prompt=prompt.numpy(), uncond_x=uncond.numpy(), res=res.numpy(), marks=marks.numpy(), masks=np.asarray(masks), non_mask_intervals=np.asarray(nmi),
             step_logits=torch.stack(rec["logits"]).numpy(), step_samples=torch.stack(rec["samples"]).numpy(),
-            step_noise=torch.stack(rec["noise"]).numpy(), torch_version=np.asarray(torch.__version__), **kwn)
+            step_noise=torch.stack(rec["noise"]).numpy(), torch_version=np.asarray(torch.__version__),
+            **({"prefill_present": first_present["present"].numpy()} if "present" in first_present and name in PRESENT_CASES else {}), **kwn)
         print(f"  lm/{name}: res {tuple(res.shape)} steps {len(rec['logits'])}")
     for name, d in out.items():
         np.savez_compressed(os.path.join(GOLD, f"lm_{name}.npz"), **d)
@@ -185,6 +200,102 @@ def make_sampler():
     print("  sampler ok")
 
 
+SCRIPT_CASES = ["greedy_cfg", "topk_topp", "topp_temp", "silence", "nocfg_topk"]
+
+
+def script_knobs(case):
+    knobs = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, silence_tokens=[3, 7, 11], cfg_coef=1.5, cfg_stride=3, aug_text=True)
+    if case == "topk_topp":
+        knobs.update(top_k=12, top_p=0.8)
+    elif case == "topp_temp":
+        knobs.update(top_k=0, top_p=0.7, temperature=2.0, cfg_stride=1, cfg_coef=1.3)
+    elif case == "silence":
+        knobs.update(top_k=1, stop_repetition=1, cfg_stride=1)
+    elif case == "nocfg_topk":
+        knobs.update(top_k=5, top_p=0.95, aug_text=False)
+    return knobs
+
+
+def make_state_machine():
+    """G4: the logit state machine of `inference()` (ssr.py:689-761: CFG combine with the stride counter, special-token
+    edits, eog cascade, silence penalty, length cap, argmax-eog stop, sampling) driven by SCRIPTED logits through the reference's
+    OWN loop: the four prediction heads are replaced by modules that return the script, everything else is the real code.
+    Records what the reference handed to `topk_sampling`, the Exp(1) noise torch.multinomial consumed, and the sampled tokens."""
+    ssr = ref_import.import_lm()
+    out = {}
+    for ci, case in enumerate(SCRIPT_CASES):
+        args = W.lm_args_tiny()
+        K = args.n_codebooks
+        card = args.audio_vocab_size + args.n_special + args.max_n_spans
+        knobs = script_knobs(case)
+        g = torch.Generator().manual_seed(ci + 1)
+        S, L, T = 40, 3, 4                     # 3 phonemes: the 10*L length cap ends the script if nothing else does
+        B = 2 if knobs["aug_text"] else 1
+        logits_seq = []
+        for s_ in range(S):
+            lg = torch.randn(B, K, 1, card, generator=g) * 2.0
+            if case == "silence" and 2 <= s_ < 12:
+                lg[:, 0, 0, 7] = 9.0           # keep emitting silence token 7 until the penalty bites
+            if case == "greedy_cfg" and s_ == 15:
+                lg[:, 0, 0, args.eog] = 50.0   # argmax == eog stop rule
+            logits_seq.append(lg)
+        m, _ = _ref_model(ssr, args, seed=50 + ci)
+        counter = {"step": 0}
+
+        class Scripted(torch.nn.Module):
+            def __init__(self, k):
+                super().__init__()
+                self.k = k
+
+            def forward(self, y_out):
+                s_ = min(counter["step"], S - 1)
+                r = logits_seq[s_][:, self.k].clone()            # [B, 1, card]
+                if self.k == K - 1:
+                    counter["step"] += 1
+                return r
+
+        m.predict_layer = torch.nn.ModuleList([Scripted(k) for k in range(K)])
+        rec = {"logits": [], "samples": [], "noise": [], "ylen": []}
+        orig = ssr.topk_sampling
+        real_dec_forward = m.dec_forward
+
+        def dec_spy(*a, **k):
+            rec["ylen"].append(int(a[4].shape[1]))                # y_input length of this step (drives the length cap :739)
+            return real_dec_forward(*a, **k)
+
+        def spy(logits, top_k=10, top_p=1.0, temperature=1.0):
+            rec["logits"].append(logits.detach().clone())
+            st = torch.get_rng_state()
+            q = torch.empty_like(logits).exponential_(1)
+            torch.set_rng_state(st)
+            rec["noise"].append(q)
+            tok = orig(logits, top_k=top_k, top_p=top_p, temperature=temperature)
+            rec["samples"].append(tok)        # NOT a copy: the loop overrides entries of this very tensor afterwards (eog cascade, stop
+            return tok                        # rules :716-718,:741); reading it after inference() gives the step's FINAL tokens
+
+        m.dec_forward = dec_spy
+        ssr.topk_sampling = spy
+        try:
+            torch.manual_seed(70 + ci)
+            x = torch.randint(0, args.text_vocab_size, (1, L), generator=g)
+            y = torch.randint(0, args.audio_vocab_size, (1, T, K), generator=g)
+            with torch.no_grad():
+                m.inference(x, torch.LongTensor([L]), x, torch.LongTensor([L]), y, y, torch.LongTensor([[[T, T]]]), kvcache=1, **knobs)
+        finally:
+            ssr.topk_sampling = orig
+        n = len(rec["samples"])
+        out[f"{case}_logits"] = torch.stack(logits_seq[:n]).squeeze(3).numpy()          # [n, B, K, card]
+        out[f"{case}_noise"] = torch.stack(rec["noise"]).numpy()                         # [n, K, card]
+        out[f"{case}_samples"] = torch.stack([t.detach().clone() for t in rec["samples"]]).squeeze(-1).numpy()   # [n, K] final tokens
+        out[f"{case}_edited_logits"] = torch.stack(rec["logits"]).numpy()                # [n, K, card] as handed to topk_sampling
+        out[f"{case}_text_len"] = np.asarray(L)
+        out[f"{case}_audio_pos0"] = np.asarray(rec["ylen"][0] - 1)
+        assert rec["ylen"] == list(range(rec["ylen"][0], rec["ylen"][0] + n)), rec["ylen"]
+        print(f"  script/{case}: {n} steps, y_len0 {rec['ylen'][0]}, last tokens {rec['samples'][-1].view(-1).tolist()}")
+    out["torch_version"] = np.asarray(torch.__version__)
+    np.savez_compressed(os.path.join(GOLD, "sampler_script.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["layout", "sampler", "lm", "codec"]
@@ -193,6 +304,8 @@ if __name__ == "__main__":
         make_layout()
     if "sampler" in which:
         make_sampler()
+    if "script" in which or "sampler" in which:
+        make_state_machine()
     if "lm" in which:
         make_lm()
     if "lm_ctx" in which or "lm" in which:

@@ -46,6 +46,47 @@ CASES = [
 ]
 
 
+LAYER_CASES = [
+    # name, pad_mode, samples (odd: every strided layer sees a length that needs the extra-padding rule, conv.py:47-53), seed
+    ("full_const", "constant", 320 * 2 + 37, 41),
+    ("full_reflect", "reflect", 320 * 3 - 111, 42),
+]
+
+
+def make_layers(gold, only=None):
+    """G7: the output of EVERY module of the full-config SEANet encoder and decoder of the reference on one short,
+    odd-length clip — i.e. one vector per distinct (C_in, C_out, k, stride) convolution, transposed convolution, residual block
+    and the LSTM, at the widths of the real model. Weights are not stored (regenerated from the seed)."""
+    for name, pad_mode, n, seed in LAYER_CASES:
+        if only and name not in only:
+            continue
+        cfg = W.codec_config_full()
+        cfg.pad_mode = pad_mode
+        m, sd = ref_model(cfg, seed)
+        g = torch.Generator().manual_seed(seed)
+        wav = torch.randn(1, 1, n, generator=g) * 0.3
+        out = {"wav": wav.numpy(), "weight_seed": np.asarray(seed), "pad_mode": np.asarray(pad_mode), "torch_version": np.asarray(torch.__version__)}
+        hooks = []
+
+        def tap(prefix, seq):
+            for i, mod in enumerate(seq):
+                if type(mod).__name__ == "ELU":          # the activation is folded into the next layer's operand load: nothing to compare
+                    continue
+                hooks.append(mod.register_forward_hook(lambda _m, _i, o, key=f"{prefix}{i}": out.__setitem__(key, o.detach().numpy().copy())))
+
+        tap("enc_", m.encoder.model)
+        tap("dec_", m.decoder.model)
+        with torch.no_grad():
+            codes, scale, emb = m.encode(wav)
+            dec = m.decode(codes, scale)
+        for h in hooks:
+            h.remove()
+        out["codes"], out["emb"], out["decoded"] = codes.numpy(), emb.numpy(), dec.numpy()
+        np.savez_compressed(os.path.join(gold, f"layers_{name}.npz"), **out)
+        shapes = {k: v.shape for k, v in out.items() if k.startswith(("enc_", "dec_"))}
+        print(f"  layers/{name}: {len(shapes)} module outputs, e.g. enc_3 {shapes['enc_3']}, dec_4 {shapes['dec_4']}")
+
+
 def main(gold, only=None):
     for name, mk, pad_mode, B, n, seed in CASES:
         if only and name not in only:
@@ -87,4 +128,6 @@ def main(gold, only=None):
 
 
 if __name__ == "__main__":
-    main(os.path.join(ROOT, "tests", "golden"), only=sys.argv[1:] or None)
+    only_ = sys.argv[1:] or None
+    main(os.path.join(ROOT, "tests", "golden"), only=only_)
+    make_layers(os.path.join(ROOT, "tests", "golden"), only=only_)

@@ -120,30 +120,31 @@ class _SeaNet:
 
     def __init__(self, sd, pfx: str, cfg: CodecConfig, decoder: bool, dev):
         self.cfg, self.dev = cfg, dev
-        self.nodes: List[tuple] = []     # (model index of the node's first module, kind, obj)
+        # (model index of the node's first module, kind, obj, model index of the module whose OUTPUT the node produces)
+        self.nodes: List[tuple] = []
         i = 0
         if not decoder:                  # seanet.py:113-150
-            self.nodes.append((i, "conv", _Conv(sd, f"{pfx}model.{i}.", 1, 0, dev)))
+            self.nodes.append((i, "conv", _Conv(sd, f"{pfx}model.{i}.", 1, 0, dev), i))
             i += 1
             for r in reversed(cfg.ratios):
-                self.nodes.append((i, "res", (_Conv(sd, f"{pfx}model.{i}.block.1.", 1, 1, dev), _Conv(sd, f"{pfx}model.{i}.block.3.", 1, 1, dev))))
-                self.nodes.append((i + 1, "conv", _Conv(sd, f"{pfx}model.{i + 2}.", r, 1, dev)))      # ELU (i+1) folded in
+                self.nodes.append((i, "res", (_Conv(sd, f"{pfx}model.{i}.block.1.", 1, 1, dev), _Conv(sd, f"{pfx}model.{i}.block.3.", 1, 1, dev)), i))
+                self.nodes.append((i + 1, "conv", _Conv(sd, f"{pfx}model.{i + 2}.", r, 1, dev), i + 2))      # ELU (i+1) folded in
                 i += 3
             if cfg.lstm:
-                self.nodes.append((i, "lstm", _Lstm(sd, f"{pfx}model.{i}.", cfg.lstm, dev)))
+                self.nodes.append((i, "lstm", _Lstm(sd, f"{pfx}model.{i}.", cfg.lstm, dev), i))
                 i += 1
-            self.nodes.append((i, "conv", _Conv(sd, f"{pfx}model.{i + 1}.", 1, 1, dev)))
+            self.nodes.append((i, "conv", _Conv(sd, f"{pfx}model.{i + 1}.", 1, 1, dev), i + 1))
         else:                            # seanet.py:209-254
-            self.nodes.append((i, "conv", _Conv(sd, f"{pfx}model.{i}.", 1, 0, dev)))
+            self.nodes.append((i, "conv", _Conv(sd, f"{pfx}model.{i}.", 1, 0, dev), i))
             i += 1
             if cfg.lstm:
-                self.nodes.append((i, "lstm", _Lstm(sd, f"{pfx}model.{i}.", cfg.lstm, dev)))
+                self.nodes.append((i, "lstm", _Lstm(sd, f"{pfx}model.{i}.", cfg.lstm, dev), i))
                 i += 1
             for r in cfg.ratios:
-                self.nodes.append((i, "convtr", _ConvTr(sd, f"{pfx}model.{i + 1}.", r, dev)))      # ELU (i) folded in
-                self.nodes.append((i + 2, "res", (_Conv(sd, f"{pfx}model.{i + 2}.block.1.", 1, 1, dev), _Conv(sd, f"{pfx}model.{i + 2}.block.3.", 1, 1, dev))))
+                self.nodes.append((i, "convtr", _ConvTr(sd, f"{pfx}model.{i + 1}.", r, dev), i + 1))      # ELU (i) folded in
+                self.nodes.append((i + 2, "res", (_Conv(sd, f"{pfx}model.{i + 2}.block.1.", 1, 1, dev), _Conv(sd, f"{pfx}model.{i + 2}.block.3.", 1, 1, dev)), i + 2))
                 i += 3
-            self.nodes.append((i, "conv", _Conv(sd, f"{pfx}model.{i + 1}.", 1, 1, dev)))
+            self.nodes.append((i, "conv", _Conv(sd, f"{pfx}model.{i + 1}.", 1, 1, dev), i + 1))
 
     def slice_nodes(self, lo: int, hi: Optional[int]):
         return [n for n in self.nodes if n[0] >= lo and (hi is None or n[0] < hi)]
@@ -223,7 +224,7 @@ class WMEncodecModel:
             assert c.act_in == 0
             _lib.check(self.lib.ssrhip_conv_cin1(x.base, c.Wraw.data_ptr(), c.b.data_ptr(), out.interior, B, T_out, c.k, c.s, c.Cout,
                                                  x.bstride, out.bstride, self._s()), "ssrhip_conv_cin1")
-        elif c.Cout <= 4 and c.s == 1 and R is None and c.Cin % 4 == 0 and (T_out >= 4096 or self.force_few_out):
+        elif c.Cout <= 4 and c.s == 1 and R is None and c.Cin % 8 == 0 and (T_out >= 4096 or self.force_few_out):
             # the 1-channel output layer at the sample rate: a read-bound dot-product kernel instead of a GEMM tile with 1 useful column
             _lib.check(self.lib.ssrhip_conv_few_out(x.base, c.W.data_ptr(), c.b.data_ptr(), out.interior, B, T_out, c.k, c.Cin, c.Cout,
                                                     (_lib.ACT_ELU if c.act_in else 0), x.bstride, out.bstride, self._s()), "ssrhip_conv_few_out")

@@ -76,33 +76,40 @@ __global__ __launch_bounds__(256) void conv_cin1_vec_kernel(const float* __restr
 __global__ __launch_bounds__(256) void conv_few_out_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out, int T_out,
                                                            int k, int Cin, int Cout, int act_in, long x_bstride, long out_bstride, int TT) {
-  extern __shared__ float xs[];                       // (TT + k - 1) rows of C_in + 1
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // (TT + k - 1) rows of C_in + 4, then C_out * k * C_in weights
   const float* xb = x + (size_t)blockIdx.y * x_bstride;
   float* ob = out + (size_t)blockIdx.y * out_bstride;
   const int t0 = blockIdx.x * TT;
   const int nt = min(TT, T_out - t0);
-  const int rows = nt + k - 1, ldr = Cin + 1;
-  const int c4n = Cin >> 2;
+  // rows padded to C_in + 4 floats: 16-byte aligned, and the 16 lanes a ds_read_b128 services together (rows t, t+1, ..)
+  // start 4 banks apart -> conflict-free float4 reads of a lane's own row
+  const int rows = nt + k - 1, ldr = Cin + 4;
+  const int c4n = Cin >> 2, K = k * Cin;
+  float* ws = xs + (size_t)(TT + k - 1) * ldr;
+  for (int i = threadIdx.x; i < Cout * K / 4; i += 256) *reinterpret_cast<float4*>(ws + 4 * i) = ld4(w + 4 * i);
   for (int i = threadIdx.x; i < rows * c4n; i += 256) {
     const int r = i / c4n, c = (i % c4n) * 4;
     float4 v = ld4(xb + ((size_t)(t0 + r)) * Cin + c);
-    if (act_in == SSRHIP_ACT_ELU) {
-      v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);       // same ELU as the GEMM's operand load (common.h)
-    }
-    float* d = xs + r * ldr + c;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    if (act_in == SSRHIP_ACT_ELU) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }   // the GEMM's operand-load ELU (common.h)
+    *reinterpret_cast<float4*>(xs + r * ldr + c) = v;
   }
   __syncthreads();
-  const int K = k * Cin;
   for (int t = threadIdx.x; t < nt; t += 256) {
     for (int co = 0; co < Cout; ++co) {
-      const float* wr = w + (size_t)co * K;           // [k][C_in] (the GEMM layout of the same layer)
-      float acc = 0.f;
+      const float* wr = ws + co * K;                  // [k][C_in] (the GEMM layout of the same layer); uniform address: LDS broadcast
+      float a0 = 0.f, a1 = 0.f;
       for (int kk = 0; kk < k; ++kk) {
         const float* xr = xs + (t + kk) * ldr;
-        for (int c = 0; c < Cin; ++c) acc = fmaf(wr[kk * Cin + c], xr[c], acc);
+        const float* wk = wr + kk * Cin;
+#pragma unroll 4
+        for (int c = 0; c < Cin; c += 8) {
+          const float4 x0 = *reinterpret_cast<const float4*>(xr + c), x1 = *reinterpret_cast<const float4*>(xr + c + 4);
+          const float4 w0 = *reinterpret_cast<const float4*>(wk + c), w1 = *reinterpret_cast<const float4*>(wk + c + 4);
+          a0 = dot4(w0, x0, a0);
+          a1 = dot4(w1, x1, a1);
+        }
       }
-      ob[(size_t)(t0 + t) * Cout + co] = acc + bias[co];
+      ob[(size_t)(t0 + t) * Cout + co] = (a0 + a1) + bias[co];
     }
   }
 }
@@ -495,11 +502,12 @@ extern "C" int ssrhip_conv_cin1(const float* x, const float* w, const float* bia
 extern "C" int ssrhip_conv_few_out(const float* x, const float* w, const float* bias, float* out, int32_t B, int32_t T_out, int32_t k,
                                    int32_t Cin, int32_t Cout, int32_t act_in, int64_t x_bstride, int64_t out_bstride, ssrhip_stream_t stream) {
   SSR_REQUIRE(x && w && bias && out && B > 0 && T_out > 0 && k > 0 && Cin > 0 && Cout > 0, "ssrhip_conv_few_out: bad argument");
-  SSR_REQUIRE(Cin % 4 == 0 && Cout <= 4 && B <= 65535, "ssrhip_conv_few_out: needs C_in %% 4 == 0 and C_out <= 4");
+  SSR_REQUIRE(Cin % 8 == 0 && Cout <= 4 && B <= 65535, "ssrhip_conv_few_out: needs C_in %% 8 == 0 and C_out <= 4");
   SSR_REQUIRE(act_in == SSRHIP_ACT_NONE || act_in == SSRHIP_ACT_ELU, "ssrhip_conv_few_out: act_in must be NONE or ELU");
+  const size_t wbytes = (size_t)Cout * k * Cin * sizeof(float);
   int TT = 256;
-  while (TT > 32 && (size_t)(TT + k - 1) * (Cin + 1) * sizeof(float) > 72 * 1024) TT >>= 1;     // two workgroups per CU
-  const size_t smem = (size_t)(TT + k - 1) * (Cin + 1) * sizeof(float);
+  while (TT > 32 && (size_t)(TT + k - 1) * (Cin + 4) * sizeof(float) + wbytes > 78 * 1024) TT >>= 1;     // two workgroups per CU
+  const size_t smem = (size_t)(TT + k - 1) * (Cin + 4) * sizeof(float) + wbytes;
   SSR_REQUIRE(smem <= 160 * 1024, "ssrhip_conv_few_out: C_in * k too large");
   dim3 grid((T_out + TT - 1) / TT, B);
   hipLaunchKernelGGL(conv_few_out_kernel, grid, dim3(256), smem, (hipStream_t)stream, x, w, bias, out, T_out, k, Cin, Cout, act_in,

@@ -197,3 +197,44 @@ def test_lstm_two_stream_pipeline_equals_sequential_layers(B):
     c0, _, e0 = m.encode(wav)
     d0 = m.decode(c1)
     assert torch.equal(e1, e0) and torch.equal(c1, c0) and torch.equal(d1, d0)
+
+
+@pytest.mark.parametrize("name", ["full_const", "full_reflect"])
+def test_every_seanet_layer_matches_the_reference(golden_dir, name):
+    """the reference's own per-module outputs (forward hooks on SEANetEncoder.model / SEANetDecoder.model at the FULL
+    config, odd input length, both pad modes; tests/golden/layers_*.npz) against this package's fused nodes, one node at a time and
+    each node fed with the REFERENCE's input to it — so an error cannot hide behind (or be blamed on) an earlier layer. Covers every
+    distinct (C_in, C_out, k, stride) convolution, transposed convolution, residual block (64 / 128 / 256 / 512 channels) and the LSTM."""
+    from ssr_speech_amd.codec.wmencodec import TM
+    g = np.load(os.path.join(golden_dir, f"layers_{name}.npz"))
+    cfg = W.codec_config_full()
+    cfg.pad_mode = str(g["pad_mode"])
+    sd = W.codec_state_dict(cfg, seed=int(g["weight_seed"]))
+    m = WMEncodecModel(cfg, sd, "cuda")
+
+    def as_tm(arr, nxt):                       # reference activation [1, C, T] -> time-major buffer with the halo `nxt` wants
+        t = torch.from_numpy(arr)
+        buf = m._alloc_for(1, t.shape[2], t.shape[1], nxt)
+        buf.data[:, buf.padL: buf.padL + buf.T] = t.permute(0, 2, 1).cuda()
+        m._fill_pads(buf, structural_zero=(nxt is not None and nxt[1] == "convtr"))
+        return buf
+
+    checked = 0
+    for pfx, net, first_in in (("enc_", m.encoder, None), ("dec_", m.decoder, None)):
+        nodes = net.nodes
+        for idx, node in enumerate(nodes):
+            nxt = nodes[idx + 1] if idx + 1 < len(nodes) else None
+            if idx == 0:
+                if pfx == "enc_":
+                    x = m._input_tm(torch.from_numpy(g["wav"]).cuda(), node)
+                else:
+                    x = m._dequant(torch.from_numpy(g["codes"]).cuda(), node)
+            else:
+                x = as_tm(g[f"{pfx}{nodes[idx - 1][3]}"], node)          # the reference's output of the previous node
+            y = m._run([node], x, after=nxt)
+            want = g[f"{pfx}{node[3]}"]
+            got = y.interior_view().permute(0, 2, 1).cpu().numpy()
+            assert got.shape == want.shape, (pfx, node[0], node[1], got.shape, want.shape)
+            np.testing.assert_allclose(got, want, rtol=0, atol=5e-5, err_msg=f"{pfx}{node[3]} ({node[1]})")
+            checked += 1
+    assert checked == len(m.encoder.nodes) + len(m.decoder.nodes) >= 22

@@ -501,6 +501,22 @@ def test_sampler_state_machine_matches_oracle(L, case):
         torch.testing.assert_close(dbgs[s], rec["edited_logits"][s], rtol=0, atol=0)   # edits + CFG combine are exact
 
 
+@pytest.mark.parametrize("case", ["greedy_cfg", "topk_topp", "topp_temp", "silence", "nocfg_topk"])
+def test_sampler_state_machine_matches_reference_script(L, golden_dir, case):
+    """the same five scripts, but the expected tokens / edited logits come from the REFERENCE's own decode loop
+    (tests/golden/sampler_script.npz, oracle/make_golden.py::make_state_machine), not from the oracle."""
+    from tests_script_knobs import SCRIPT_KNOBS
+    g = np.load(os.path.join(golden_dir, "sampler_script.npz"))
+    args = W.lm_args_tiny()
+    knobs = dict(SCRIPT_KNOBS[case], silence_tokens=[3, 7, 11])
+    logits, noise = torch.from_numpy(g[f"{case}_logits"]), torch.from_numpy(g[f"{case}_noise"])
+    got, dbgs, state = _run_sampler_script(L, args, [l for l in logits], knobs, [n for n in noise], int(g[f"{case}_text_len"]), int(g[f"{case}_audio_pos0"]))
+    assert state.done == 1 and state.n_steps == logits.shape[0]
+    assert np.array_equal(got.numpy(), g[f"{case}_samples"]), (got, g[f"{case}_samples"])
+    for s in range(logits.shape[0]):
+        np.testing.assert_array_equal(dbgs[s].numpy(), g[f"{case}_edited_logits"][s])     # CFG combine + edits are exact
+
+
 def _full_card_script(case, top_k, S=8):
     args = W.lm_args_830m()
     K = args.n_codebooks

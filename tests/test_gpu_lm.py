@@ -359,3 +359,36 @@ def test_positions_beyond_the_initial_table_grow_it_like_extend_pe():
     trace = {}
     O.inference(O.reference_params(W.lm_state_dict(args, seed=45)), args, x, y, mi, max_steps=steps, trace=trace, kvcache=1, **kw)
     assert np.array_equal(eng.generated[0, :steps].cpu().numpy(), torch.stack(trace["samples"]).numpy())
+
+
+@pytest.mark.parametrize("name", ["tts_greedy_cfg5", "edit_2span_greedy", "tts_greedy_hd128", "tts_greedy_nocfg"])
+def test_prefill_kv_cache_equals_reference_present(golden_dir, name):
+    """the K/V the reference's first dec_forward returns as `present` (every layer, both CFG rows, all of
+    [text || prompt audio || mask token]) against the paged cache after `start()` (prefill) + the first decode step (which
+    appends the mask token's K/V). Gathered through the page table the allocator filled."""
+    from ssr_speech_amd import layout as LY
+    from ssr_speech_amd.engine import DecodeEngine, DecodeKnobs, LMWeightsArena
+    from ssr_speech_amd._lib import PAGE
+    g, args, kw = _load(golden_dir, name)
+    ref = g["prefill_present"]                                   # [n_layer, 2, B, H, S0, hd]
+    nl, _, B, H, S0, hd = ref.shape
+    sd = W.lm_state_dict(args, seed=int(g["weight_seed"]), device="cuda")
+    arena = LMWeightsArena(args, sd, torch.device("cuda"))
+    eng = DecodeEngine(arena, 1, bool(kw["aug_text"]), 256, 64)
+    cated, mp, num_task, nmi = LY.build_layout(g["y"][0].T, g["mask_interval"][0], args)
+    rows = [g["x"][0]] + ([g["uncond_x"][0]] if kw["aug_text"] else [])
+    kn = DecodeKnobs(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=kw["stop_repetition"], cfg_coef=kw["cfg_coef"], cfg_stride=kw["cfg_stride"],
+                     use_cfg=bool(kw["aug_text"]), text_len=g["x"].shape[1], n_spans=num_task)
+    eng.start(rows, [cated], [kn])
+    eng.decode(1, use_graph=False)
+    torch.cuda.synchronize()
+    assert eng.B == B and int(eng.kv_pos[0]) == S0
+    pool = eng.kv_pool.view(-1, nl, 2, H, PAGE, hd).cpu()
+    table = eng._table_host
+    worst = 0.0
+    for b in range(B):
+        got = torch.cat([pool[int(table[b, p])] for p in range((S0 + PAGE - 1) // PAGE)], dim=3)[:, :, :, :S0]     # [nl, 2, H, S0, hd]
+        want = torch.from_numpy(ref[:, :, b])
+        worst = max(worst, float((got - want).abs().max()))
+        torch.testing.assert_close(got, want, rtol=0, atol=2e-5)
+    print(f"{name}: prefill K/V max |diff| vs reference present = {worst:.2e}")

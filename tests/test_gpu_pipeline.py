@@ -99,7 +99,12 @@ def test_glue_hands_the_codec_what_the_reference_glue_does(tmp_path, name):
     m.load_state_dict(W.lm_state_dict(args, seed=int(G[f"{name}_torch_seed"])))
     m = m.to("cuda").eval()
     fn = str(tmp_path / "p.wav")
-    write_wav(fn, torch.from_numpy(G[f"{name}_wav"]), 16000)
+    # IEEE-float WAVE: the reader must return the fixture's samples exactly (a second 16-bit quantisation would move some by one LSB)
+    import struct
+    raw = G[f"{name}_wav"].astype("<f4").tobytes()
+    with open(fn, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 3, 1, 16000, 64000, 4, 32)
+                + b"data" + struct.pack("<I", len(raw)) + raw)
     tok = RecordingTokenizer(torch.from_numpy(G[f"{name}_codes"]))
     phn2num = {c: i for i, c in enumerate("abcdefghijklmnopqrstuvwxyz")}
     decode_config = {"top_k": 1, "top_p": 1.0, "temperature": 1, "stop_repetition": 2, "kvcache": 1, "codec_audio_sr": 16000, "codec_sr": 50}
