@@ -209,6 +209,11 @@ typedef struct ssrhip_gemm_args {
   int64_t strideA, strideC, strideR; /* per-batch element strides */
   int32_t tm_c, tm_lo, tm_hi;       /* tm_c > 0: element (m,n) belongs to time row u = (m*N+n)/tm_c and is stored only
                                        if tm_lo <= u < tm_hi (transposed-conv trimming, modules/conv.py:236-243) */
+  /* per-row CLASS bias (all NULL/0 = off): C[m][n] += rbias[rclass[z * rclass_stride + m / rrep] * N + n]  (z = batch index).
+   * The watermark decoder's label conditioning (modules/seanet.py:577-591): the 1x1 convolution over cat(skip, embed(label))
+   * splits into W_a . ELU(skip) + (W_b . ELU(embed(label))), and the second term takes only as many values as there are labels —
+   * so the concatenated tensor is never built and the GEMM's K shrinks by the embedding width. */
+  const float* rbias; const int32_t* rclass; int32_t rrep, rclass_stride;
 } ssrhip_gemm_args;
 int ssrhip_gemm(const ssrhip_gemm_args* a, ssrhip_stream_t stream);
 
@@ -253,11 +258,6 @@ int ssrhip_rvq_encode(const float* emb, const float* codebooks, const float* e2,
                       int32_t D, int32_t n_q, int32_t bins, int64_t emb_bstride, ssrhip_stream_t stream);
 int ssrhip_rvq_decode(const int32_t* codes, const float* codebooks, float* out, int32_t B, int32_t T, int32_t D,
                       int32_t n_q, int32_t bins, int64_t out_bstride, ssrhip_stream_t stream);
-/* watermark conditioning (modules/seanet.py:577-591): cat[b][t][0:C] = skip[b][t][:], cat[b][t][C:C+E] = table[label[b][t/rep]][:] */
-int ssrhip_wm_concat(const float* skip, const int32_t* labels, const float* table, float* cat, int32_t B, int32_t T,
-                     int32_t C, int32_t E, int32_t rep, int32_t n_labels, int64_t skip_bstride, int64_t cat_bstride,
-                     ssrhip_stream_t stream);
-
 /* Fused SEANetResnetBlock (modules/seanet.py:16-60; true_skip, dilation 1, kernel sizes 3 and 1) for C == 64 channels:
  *   y[b][t][:] = x[b][t][:] + b1 + W1 . ELU(b3 + W3 . ELU(x[b][t-1 : t+2][:]))
  * x points at the row BEFORE t = 0 of item 0 of a time-major buffer [B][1 + T + 1][C] (halo rows hold the zero / reflect

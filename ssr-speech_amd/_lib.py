@@ -90,7 +90,8 @@ class GemmArgs(C.Structure):
                 ("act", C.c_int32), ("residual", C.c_int32),
                 ("act_in", C.c_int32), ("R", C.c_void_p), ("ldr", C.c_int32), ("batch", C.c_int32),
                 ("strideA", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
-                ("tm_c", C.c_int32), ("tm_lo", C.c_int32), ("tm_hi", C.c_int32)]
+                ("tm_c", C.c_int32), ("tm_lo", C.c_int32), ("tm_hi", C.c_int32),
+                ("rbias", C.c_void_p), ("rclass", C.c_void_p), ("rrep", C.c_int32), ("rclass_stride", C.c_int32)]
 
 
 class LstmArgs(C.Structure):
@@ -162,7 +163,6 @@ SYMBOLS = [
     ("ssrhip_lstm_layer", C.c_int, [C.POINTER(LstmArgs), C.c_void_p]),
     ("ssrhip_rvq_encode", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
     ("ssrhip_rvq_decode", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
-    ("ssrhip_wm_concat", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     ("ssrhip_resblock", C.c_int, [C.POINTER(ResblockArgs), C.c_void_p]),
     ("ssrhip_layernorm", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("ssrhip_kv_scatter", C.c_int, [C.c_void_p, C.POINTER(KV), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -173,6 +173,15 @@ class WMEncodecModel:
             w = sd["wmdecoder.wm_embed.weight"]                       # nn.Embedding(2, D/16, max_norm=True) (seanet.py:503)
             norm = w.norm(p=2, dim=1, keepdim=True)
             self.wm_table = torch.where(norm > 1.0, w * (1.0 / (norm + 1e-7)), w).contiguous().to(dev)
+            # label conditioning folded: per projection (W_a [Cout][C_skip], class bias [n_labels][Cout] = W_b . ELU(embed(label)))
+            self.wm_cls = []
+            E = self.wm_table.shape[1]
+            emb_act = torch.nn.functional.elu(self.wm_table.cpu().double())
+            for c in self.wm_proj:
+                assert c.k == 1, "wm_proj is a 1x1 convolution (seanet.py:513-539)"
+                Wfull = c.W.cpu()                                                  # [Cout][C_skip + E]
+                Cs = Wfull.shape[1] - E
+                self.wm_cls.append((Wfull[:, :Cs].contiguous().to(dev), (emb_act @ Wfull[:, Cs:].double().t()).float().contiguous().to(dev)))
         self.codebooks = torch.stack([sd[f"quantizer.vq.layers.{q}._codebook.embed"] for q in range(cfg.n_q)]).contiguous().to(dev)
         self.e2 = self.codebooks.pow(2).sum(-1).contiguous()          # |e|^2 (core_vq.py:169)
         self.sample_rate, self.channels, self.frame_rate = cfg.sample_rate, cfg.channels, cfg.frame_rate
@@ -181,13 +190,15 @@ class WMEncodecModel:
     def _s(self):
         return _lib.stream_ptr()
 
-    def _gemm(self, A, W, bias, Cp, M, N, K, lda, ldc, act_in=0, R=0, ldr=0, batch=1, sA=0, sC=0, sR=0, tm=(0, 0, 0)):
+    def _gemm(self, A, W, bias, Cp, M, N, K, lda, ldc, act_in=0, R=0, ldr=0, batch=1, sA=0, sC=0, sR=0, tm=(0, 0, 0), rowcls=None):
         a = _lib.GemmArgs()
         a.A, a.W, a.bias, a.C = A, W.data_ptr(), (bias.data_ptr() if bias is not None else 0), Cp
         a.M, a.N, a.K, a.lda, a.ldc = M, N, K, lda, ldc
         a.act_in, a.R, a.ldr, a.batch = act_in, R, ldr, batch
         a.strideA, a.strideC, a.strideR = sA, sC, sR
         a.tm_c, a.tm_lo, a.tm_hi = tm
+        if rowcls is not None:           # (class bias [n_class][N], class ids int32 [batch][n], rows per id)
+            a.rbias, a.rclass, a.rrep, a.rclass_stride = rowcls[0].data_ptr(), rowcls[1].data_ptr(), int(rowcls[2]), int(rowcls[1].shape[1])
         _lib.check(self.lib.ssrhip_gemm(C.byref(a), self._s()), "ssrhip_gemm")
 
     def _fill_pads(self, buf: TM, structural_zero: bool = False):
@@ -375,6 +386,14 @@ class WMEncodecModel:
         self._fill_pads(out)
         return out
 
+    @staticmethod
+    def _channel_major(y: TM) -> torch.Tensor:
+        """[B][T][C] time-major result -> the reference's [B, C, T]. A 1-channel waveform without halo rows is the same memory
+        either way (a view, no copy); anything else is one transposing copy of a small tensor (latents, detector output)."""
+        if y.C == 1 and y.padL == 0 and y.padR == 0:
+            return y.data.view(y.B, 1, y.T)
+        return y.interior_view().transpose(1, 2).contiguous()
+
     @torch.no_grad()
     def decode_latent(self, codes: torch.Tensor) -> torch.Tensor:
         return self._dequant(codes, None).interior_view().transpose(1, 2).contiguous()
@@ -384,17 +403,19 @@ class WMEncodecModel:
         assert scale is None, "renormalize=False codec: scale must be None (wmencodec.py:199-203)"
         z = self._dequant(codes, self.decoder.nodes[0])
         y = self._run(self.decoder.nodes, z)
-        return y.interior_view().transpose(1, 2).contiguous()
+        return self._channel_major(y)
 
     def _concat_proj(self, j: int, skip: TM, labels32: torch.Tensor, rep: int, x: TM, nxt) -> TM:
-        """wm_proj_j(ELU(cat(skip, wm_embed(labels upsampled)))) + x   (seanet.py:577-591)."""
-        c = self.wm_proj[j]
-        E = self.wm_table.shape[1]
-        assert skip.T == x.T and skip.C + E == c.Cin, (skip.T, x.T, skip.C, E, c.Cin)
-        cat = TM(skip.B, skip.T, skip.C + E, 0, 0, self.device)
-        _lib.check(self.lib.ssrhip_wm_concat(skip.interior, labels32.data_ptr(), self.wm_table.data_ptr(), cat.interior, skip.B, skip.T,
-                                             skip.C, E, rep, labels32.shape[1], skip.bstride, cat.bstride, self._s()), "ssrhip_wm_concat")
-        return self._conv(c, cat, nxt, R=x)
+        """wm_proj_j(ELU(cat(skip, wm_embed(labels upsampled)))) + x   (seanet.py:577-591) without building the concatenation:
+        the 1x1 convolution splits into W_a . ELU(skip) + W_b . ELU(embed(label)); the second term has one value per label
+        (`self.wm_cls[j]`, computed at load) and enters the GEMM's epilogue as a per-row class bias (include/ssrhip.h rbias)."""
+        c, (Wa, cls) = self.wm_proj[j], self.wm_cls[j]
+        assert skip.T == x.T and skip.C == Wa.shape[1] and labels32.shape[1] * rep >= skip.T, (skip.T, x.T, skip.C, Wa.shape, labels32.shape, rep)
+        out = self._alloc_for(skip.B, skip.T, c.Cout, nxt)
+        self._gemm(skip.interior, Wa, c.b, out.interior, skip.T, c.Cout, skip.C, skip.C, c.Cout, act_in=_lib.ACT_ELU, R=x.interior, ldr=x.C,
+                   batch=skip.B, sA=skip.bstride, sC=out.bstride, sR=x.bstride, rowcls=(cls, labels32, rep))
+        self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
+        return out
 
     @torch.no_grad()
     def wmdecode(self, codes: torch.Tensor, labels: torch.Tensor, wavform: torch.Tensor, scale=None, with_mark: bool = True):
@@ -420,7 +441,7 @@ class WMEncodecModel:
             skip, rep = sk[3 - j], reps[3 - j]
             out = self._concat_proj(j, skip, lab, rep, x, dn[j][0])
             x = self._run(dn[j], out, after=None)
-        wav = x.interior_view().transpose(1, 2).contiguous()
+        wav = self._channel_major(x)
         if not with_mark:
             return wav, None
         m = self._run(self.wm_encoder.nodes, self._input_tm(wav, self.wm_encoder.nodes[0]), after=None)

@@ -9,7 +9,6 @@
 //     (16.8 MB at C=1024) is re-read every step from L2/Infinity Cache,
 //   * residual vector quantisation: nearest codebook row per frame (block per frame, scores in the
 //     reference's arithmetic form, first-max tie rule) and the gather-sum dequantiser,
-//   * the watermark-label concat.
 #include <string.h>
 #include "common.h"
 
@@ -459,18 +458,6 @@ __global__ __launch_bounds__(128) void rvq_decode_kernel(const int* codes, const
   }
 }
 
-__global__ __launch_bounds__(256) void wm_concat_kernel(const float* skip, const int* labels, const float* table, float* cat, int T, int C,
-                                                        int E, int rep, int n_labels, long skip_bstride, long cat_bstride) {
-  const int W = C + E;
-  const long total = (long)T * W;
-  const float* sb = skip + (size_t)blockIdx.y * skip_bstride;
-  float* cbp = cat + (size_t)blockIdx.y * cat_bstride;
-  const int* lb = labels + (size_t)blockIdx.y * n_labels;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int t = (int)(i / W), c = (int)(i % W);
-    cbp[i] = (c < C) ? sb[(size_t)t * C + c] : table[lb[t / rep] * E + (c - C)];
-  }
-}
 
 inline int nblocks(long total, int cap = 4096) {
   long n = (total + 255) / 256;
@@ -599,11 +586,3 @@ extern "C" int ssrhip_rvq_decode(const int32_t* codes, const float* codebooks, f
   return 0;
 }
 
-extern "C" int ssrhip_wm_concat(const float* skip, const int32_t* labels, const float* table, float* cat, int32_t B, int32_t T, int32_t C,
-                                int32_t E, int32_t rep, int32_t n_labels, int64_t skip_bstride, int64_t cat_bstride, ssrhip_stream_t stream) {
-  SSR_REQUIRE(skip && labels && table && cat && B > 0 && T > 0 && C > 0 && E > 0 && rep > 0 && n_labels * rep >= T, "ssrhip_wm_concat: bad argument");
-  dim3 grid(nblocks((long)T * (C + E), 16384), B);
-  hipLaunchKernelGGL(wm_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, skip, labels, table, cat, T, C, E, rep, n_labels, (long)skip_bstride, (long)cat_bstride);
-  SSR_LAUNCH_CHECK();
-  return 0;
-}

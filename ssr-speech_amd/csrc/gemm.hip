@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
     a.A += z * (size_t)a.strideA;
     a.C += z * (size_t)a.strideC;
     if (a.R) a.R += z * (size_t)a.strideR;
+    if (a.rclass) a.rclass += z * (size_t)a.rclass_stride;
   }
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / NW, wn = wave % NW;
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
           float* c = a.C + (size_t)m * a.ldc + n;
           if (a.residual) v += *c;
           if (a.R) v += a.R[(size_t)m * a.ldr + n];
+          if (a.rbias) v += a.rbias[(size_t)a.rclass[m / a.rrep] * N + n];
           *c = v;
         }
       }
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(256) void kv_scatter_kernel(const float* qkv, const
 extern "C" int ssrhip_gemm(const ssrhip_gemm_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->A && a->W && a->C, "ssrhip_gemm: null argument");
   SSR_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 4 == 0 && a->lda % 4 == 0, "ssrhip_gemm: K and lda must be multiples of 4");
+  SSR_REQUIRE(!a->rbias || (a->rclass && a->rrep > 0), "ssrhip_gemm: rbias needs rclass and rrep > 0");
   int bm = a->N <= 64 ? 256 : 64, bn = a->N <= 32 ? 32 : (a->N <= 64 ? 64 : 128);
   const long wide_wgs = (long)((a->N + 127) / 128) * ((a->M + 63) / 64) * (a->batch > 1 ? a->batch : 1);
   const bool small_grid = a->N > 64 && wide_wgs < 256;

@@ -2,6 +2,7 @@
 same op (and, for the sampler, against the oracle's state machine). Tolerances are written per test:
 fp32 everywhere, differences come only from summation order."""
 import ctypes as C
+import os
 import math
 
 import numpy as np
