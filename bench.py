@@ -36,8 +36,13 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
-TRAFFIC_BYTES_PER_GEMV_LAUNCH = 50.6e6   # measured with PMC counters, see profiles/r01_pmc_fetch_size.md (not re-measured live)
-TRAFFIC_SOURCE = "profiles/r01_pmc_fetch_size.md + profiles/r01_pmc_write_size.md (rocprofv3 --pmc passes, gfx950 x2 FETCH_SIZE correction)"
+# HBM bytes per GEMV launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950
+# corrections of MI355X_MICROARCH.md: FETCH_SIZE x2 for wide coalesced reads), launch-weighted over the 66 GEMV launches of a step.
+# Not re-measured live (counters need rocprofv3): the constants are this round's profiles, named in `traffic_source`.
+#   2 rows : (67.95 x16 + 59.22 x32 + 17.60 x16 + 34.31 + 33.97) / 66 = 50.5 MB read + 0.1 MB written
+#   16 rows: (59.30 x33 + 71.66 x16 + 18.17 x16 + 36.04) / 66 = 52.0 MB read + 0.3 MB written (x re-read through L2 by the streamed-x kernel)
+TRAFFIC_BYTES_PER_GEMV_LAUNCH = {2: 50.6e6, 16: 52.3e6}
+TRAFFIC_SOURCE = {2: "profiles/r02_pmc_fetch_size.md + profiles/r02_pmc_write_size.md", 16: "profiles/r02_pmc_fetch_size_16rows.md + profiles/r02_pmc_write_size_16rows.md"}
 
 
 def synth_inputs(args_lm, rank, L=130, N=160):
@@ -406,8 +411,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r01_pmc_*.md), gfx950 x2 correction
                          # for wide reads applied: 50.5 MB read + 0.1 MB written per GEMV launch vs 49.85 MB algorithmic
-                         "traffic": TRAFFIC_BYTES_PER_GEMV_LAUNCH if (arena.D == 2048 and arena.L == 16 and U == 1) else None,
-                         "traffic_source": TRAFFIC_SOURCE,
+                         "traffic": TRAFFIC_BYTES_PER_GEMV_LAUNCH.get(2 * U) if (arena.D == 2048 and arena.L == 16) else None,
+                         "traffic_source": TRAFFIC_SOURCE.get(2 * U, "not measured for this row count") + " (rocprofv3 --pmc passes of this command, gfx950 x2 FETCH_SIZE correction)",
                          "kernel": ("gemv_fast_kernel<2,*> (fused LN/combine + GEMV + bias/act/residual), all 66 launches of a step" if 2 * U <= 4 else
                                     "gemv_rows_xreg_kernel / gemv_rows_stream_kernel (matrix-core GEMV, streaming-order weights), all 66 launches of a step"),
                          "bytes_per_launch": int(bytes_per_launch), "launches_per_step": n_gemv, "us_per_launch": round(gemv_us, 3),
