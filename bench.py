@@ -245,29 +245,40 @@ def dp64_leg(model, args_lm, dev, world, rank, dist):
             "tokens_crc32": f"{crc:08x}"}
 
 
-def codec256_leg(dev, world, rank, dist):
+def codec256_leg(dev, world, rank, dist, all_ok=lambda ok: ok):
     """BASELINE config 5: encode + decode of 256 clips x 30 s (16 kHz), 256 / N clips per rank, no collective."""
     from ssr_speech_amd import dp, weights as W
     from ssr_speech_amd.codec.wmencodec import WMEncodecModel
     cfg = W.codec_config_full()
-    m = WMEncodecModel(cfg, W.codec_state_dict(cfg, seed=0), dev)
     lo, hi = dp.shard_range(256, world, rank)
     B, n = hi - lo, 480000
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    wav = torch.randn(B, 1, n, generator=g, device=dev) * 0.1
-    c, _, _ = m.encode(wav[: min(B, 8)])               # warm-up on a slice
-    m.decode(c)
-    torch.cuda.synchronize()
+    err, enc, dec, out = None, 0.0, 0.0, None
+    try:
+        m = WMEncodecModel(cfg, W.codec_state_dict(cfg, seed=0), dev)
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        wav = torch.randn(B, 1, n, generator=g, device=dev) * 0.1
+        c, _, _ = m.encode(wav[: min(B, 8)])               # warm-up on a slice
+        m.decode(c)
+        torch.cuda.synchronize()
+    except Exception as e:                                 # noqa: BLE001
+        err = e
+    if not all_ok(err is None):
+        raise RuntimeError(f"codec256 set-up failed on {'this' if err is not None else 'another'} rank: {err!r}")
     if dist is not None:
         dist.barrier()
-    t0 = time.perf_counter()
-    codes, _, _ = m.encode(wav)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    out = m.decode(codes)
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    enc, dec = t1 - t0, t2 - t1
+    try:
+        t0 = time.perf_counter()
+        codes, _, _ = m.encode(wav)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        out = m.decode(codes)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        enc, dec = t1 - t0, t2 - t1
+    except Exception as e:                                 # noqa: BLE001
+        err = e
+    if not all_ok(err is None):
+        raise RuntimeError(f"codec256 failed on {'this' if err is not None else 'another'} rank: {err!r}")
     if dist is not None:
         tt = torch.tensor([enc, dec], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -434,21 +445,33 @@ def main():
         torch.cuda.empty_cache()
         import tempfile
 
+        def all_ok(ok: bool) -> bool:
+            """Every rank reports whether its LOCAL part of a leg worked; the leg's collective only runs when all did."""
+            if dist is None:
+                return ok
+            t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
         def leg(name, fn):
+            # the headline metric must not depend on an extra: a failure becomes an "error" entry. dp64's collective is guarded
+            # inside dp.generate (ranks agree on success before the all-gather); codec256's only collective is a timing all-reduce
+            # behind all_ok().
             try:
                 extras[name] = fn()
-            except Exception as e:      # the headline metric must not depend on an extra
-                if world > 1:
-                    raise               # a rank that skips a collective would hang the others: fail loudly instead
+            except Exception as e:
                 extras[name] = {"error": repr(e)}
 
         model = None
         try:
             model = build_api_model(args_lm, sd, dev)
         except Exception as e:
-            if world > 1:
-                raise
             extras["rtf_10s_tts"] = extras["dp64"] = {"error": repr(e)}
+        if not all_ok(model is not None):
+            if model is not None:
+                model._invalidate()
+            model = None
+            extras.setdefault("dp64", {"error": "model build failed on another rank"})
         if model is not None:
             if world == 1:
                 with tempfile.TemporaryDirectory() as td:
@@ -457,7 +480,7 @@ def main():
             model._invalidate()
             del model
             torch.cuda.empty_cache()
-        leg("codec256", lambda: codec256_leg(dev, world, rank, dist))
+        leg("codec256", lambda: codec256_leg(dev, world, rank, dist, all_ok))
         if world == 1:
             leg("wmencodec", lambda: codec_leg(dev, with_cpu=not a.no_cpu_baseline))
 

@@ -78,9 +78,21 @@ def generate(model, utterances: Sequence[dict], seed: int = 0, pad_token: int = 
     lo, hi = shard_range(len(utterances), world, rank)
     import time
     t0 = time.perf_counter()
-    outs = model.inference_batch(list(utterances[lo:hi]), seed=seed, first_index=lo, **decode_kw) if hi > lo else []
+    failure = None
+    try:
+        outs = model.inference_batch(list(utterances[lo:hi]), seed=seed, first_index=lo, **decode_kw) if hi > lo else []
+    except Exception as e:              # noqa: BLE001 — re-raised below, on EVERY rank
+        failure, outs = e, []
     if stats is not None:           # wall time of this rank's lock-step decode (inference_batch ends on a device->host read)
         stats["decode_s"] = time.perf_counter() - t0
+    # A rank that failed must not leave the others waiting in the all-gather: agree on success first (one tiny MIN all-reduce).
+    if world > 1:
+        ok = torch.tensor([0 if failure is not None else 1], dtype=torch.int32, device=_collective_device(device if device is not None else getattr(model, "device", None)))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            raise RuntimeError(f"dp.generate: the decode failed on {'this' if failure is not None else 'another'} rank" + (f": {failure!r}" if failure is not None else ""))
+    elif failure is not None:
+        raise failure
     K = int(model.args.n_codebooks)
     if pad_token is None:
         pad_token = int(model.args.empty_token)

@@ -106,3 +106,41 @@ def test_generate_world2_equals_single_process(n_total):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+class _FailsOnRank1(_StubModel):
+    def inference_batch(self, utterances, seed=0, first_index=0, **kw):
+        if first_index > 0:
+            raise ValueError("boom")
+        return super().inference_batch(utterances, seed=seed, first_index=first_index, **kw)
+
+
+def _fail_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    utts = [dict(x=torch.zeros(1, 4 + i, dtype=torch.long)) for i in range(6)]
+    try:
+        dp.generate(_FailsOnRank1(), utts, seed=1)
+        q.put((rank, "returned"))
+    except RuntimeError as e:
+        q.put((rank, "this" if "this rank" in str(e) else "another"))
+    dist.barrier()                       # both ranks are still in step: nobody is stuck in the all-gather
+    dist.destroy_process_group()
+
+
+def test_generate_failure_on_one_rank_raises_on_all_ranks():
+    """A rank whose decode throws must not strand the others in the token all-gather: every rank raises instead."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fail_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, "another"), (1, "this")]
