@@ -124,6 +124,13 @@ int ssrhip_attn_combine(const ssrhip_attn_args* a, float* out /* [R][n_head*head
  * `out` must not alias q; out_tiled as for ssrhip_attn_combine). Meant for many rows (rows x heads >= the number of CUs): the
  * 5..16-row decode step. */
 int ssrhip_attn_rows(const ssrhip_attn_args* a, float* out /* [R][n_head*head_dim] */, ssrhip_stream_t stream);
+/* Causal attention of whole PROMPTS (activation.py:634 with the mask of ssr.py:227-255, tgt_len = prompt length): the rows of
+ * sequence s are rows seq_start[s] .. seq_start[s+1]-1 of q / out (positions 0 .. len-1, in order); K/V are read from the paged
+ * cache (already scattered there), a query at position i sees keys 0..i. K/V tiles are staged in LDS once per 128 queries and
+ * both products run on the matrix core (fp32). Uses a->q, q_stride, kv, layer, scale; `seq_start` is a DEVICE array of n_seq+1
+ * ints, `max_len` an upper bound of the sequence lengths (grid size). out is row-major [R][n_head*head_dim]. */
+int ssrhip_attn_prefill(const ssrhip_attn_args* a, const int32_t* seq_start, int32_t n_seq, int32_t max_len, float* out,
+                        ssrhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Token embedding + sinusoidal position: replaces embed_y (models/ssr.py:191-198, :655-660, :757-761),
@@ -333,6 +340,9 @@ typedef struct ssrhip_prefill_args {
   const int32_t* row_seq; const int32_t* row_pos; const int32_t* row_len; /* cache coordinates, [R] */
   int32_t R, max_splits;
   float* x; float* xn; float* qkv; float* o; float* h; float* part_o; float* part_ml;
+  /* optional (NULL/0 = per-row attention through part_o / part_ml): the rows of sequence s are seq_start[s] .. seq_start[s+1]-1,
+   * in position order -> the tiled prefill attention (ssrhip_attn_prefill); part_o / part_ml may then be NULL */
+  const int32_t* seq_start; int32_t n_seq, max_len;
 } ssrhip_prefill_args;
 int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ssrhip_stream_t stream);
 

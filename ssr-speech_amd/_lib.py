@@ -142,7 +142,8 @@ class PrefillArgs(C.Structure):
                 ("row_seq", C.c_void_p), ("row_pos", C.c_void_p), ("row_len", C.c_void_p),
                 ("R", C.c_int32), ("max_splits", C.c_int32),
                 ("x", C.c_void_p), ("xn", C.c_void_p), ("qkv", C.c_void_p), ("o", C.c_void_p), ("h", C.c_void_p),
-                ("part_o", C.c_void_p), ("part_ml", C.c_void_p)]
+                ("part_o", C.c_void_p), ("part_ml", C.c_void_p),
+                ("seq_start", C.c_void_p), ("n_seq", C.c_int32), ("max_len", C.c_int32)]
 
 
 # every symbol include/ssrhip.h declares: (name, restype, argtypes)
@@ -154,6 +155,7 @@ SYMBOLS = [
     ("ssrhip_attn_decode", C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     ("ssrhip_attn_combine", C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_void_p]),
     ("ssrhip_attn_rows", C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_void_p]),
+    ("ssrhip_attn_prefill", C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     ("ssrhip_embed", C.c_int, [C.POINTER(EmbedArgs), C.c_void_p]),
     ("ssrhip_sample", C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     ("ssrhip_gemm", C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),

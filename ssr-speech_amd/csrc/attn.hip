@@ -292,6 +292,139 @@ __global__ __launch_bounds__(512) void attn_rows_kernel(const ssrhip_attn_args a
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Causal PREFILL attention with K/V tile reuse (flash-style, fp32 on the matrix core). The decode kernel run once per query
+// row re-reads a row's whole K/V prefix per row (28,704 workgroups, 97 us per layer for the bench prompt); here a workgroup owns
+// 128 consecutive queries of one (sequence, head) — 4 waves x 32 queries — and walks the key tiles (32 keys) up to its diagonal:
+//   * the K and V tiles are fetched ONCE per workgroup, coalesced, from the paged cache (the prefill scattered them there just
+//     before) into LDS, one tile ahead in registers, and shared by the 4 waves;
+//   * S^T = K . Q^T on v_mfma_f32_32x32x2_f32 (keys as M, queries as N, head_dim as K; the wave's Q slice lives in registers),
+//     so that a lane holds 16 scores of ITS query column: the running max / sum of the online softmax are per-lane scalars
+//     (one xor-32 exchange between the two half-waves), and the probabilities sit exactly where the B operand of the second
+//     product wants them:  O^T = V^T . P^T  (head_dim as M, queries as N, keys as K) — no shuffle, no LDS round trip for P
+//     (the k order of the second product follows the accumulator's row order; V is read from LDS in that order);
+//   * the output row is normalised and stored straight into the [R][D] buffer the out-projection GEMM reads: no partials.
+// Exact fp32 (v_mfma_f32 is an fmaf chain). Replaces F.scaled_dot_product_attention with the causal mask of ssr.py:227-255 for
+// the prompt rows (activation.py:634).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const ssrhip_attn_args a, const int32_t* __restrict__ seq_start, float* __restrict__ out) {
+  constexpr int KT = 32, LDK = HD + 4, F4 = HD / 4, NLD = KT * F4 / 256;     // float4 loads per thread per tile (HD 128: 4, 64: 2)
+  constexpr int NJ = HD / 8, NMB = HD / 32;
+  __shared__ __attribute__((aligned(16))) float Ks[KT * LDK];
+  __shared__ __attribute__((aligned(16))) float Vs[KT * LDK];
+  const int qb = blockIdx.x, h = blockIdx.y, seq = blockIdx.z;
+  const int r0 = seq_start[seq], S = seq_start[seq + 1] - r0;
+  if (qb * 128 >= S) return;                                               // uniform
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int H = a.kv.n_head, D = H * HD;
+  const int qstride = a.q_stride ? a.q_stride : D;
+  const int q0 = qb * 128 + wave * 32;                                     // this wave's first query position
+  const int qi = q0 + li;                                                  // this lane's query (column of both products)
+  const int last_q_wg = min(qb * 128 + 127, S - 1);
+  const int ntile = last_q_wg / KT + 1;                                    // key tiles the workgroup walks
+  const int my_last = (q0 < S) ? min(q0 + 31, S - 1) / KT : -1;            // last tile this wave needs (-1: no live query)
+
+  // Q slice: lane (query li, half lh) holds Q[qi][8j + 4lh .. +3], j = 0..NJ-1 — the k order both operands of S^T use
+  float4 qr[NJ];
+  {
+    const float* qp = a.q + (size_t)(r0 + min(qi, S - 1)) * qstride + h * HD + 4 * lh;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) qr[j] = ld4(qp + 8 * j);
+  }
+  const int32_t* tab = a.kv.table + (size_t)seq * a.kv.max_pages;
+  const size_t page_stride = (size_t)a.kv.n_layer * 2 * H * SSRHIP_PAGE * HD;
+  const float* pool = a.kv.pool + ((size_t)a.layer * 2 * H + h) * SSRHIP_PAGE * HD;
+  const size_t v_off = (size_t)H * SSRHIP_PAGE * HD;
+
+  float4 kreg[NLD], vreg[NLD];
+  auto gload = [&](int kt) {                                               // tile kt -> registers (rows past S: clamped, masked later)
+    const int key0 = kt * KT;
+    const float* base = pool + (size_t)tab[key0 / SSRHIP_PAGE] * page_stride + (size_t)(key0 % SSRHIP_PAGE) * HD;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = i * 256 + t, row = idx / F4, c4 = idx % F4;
+      const int rr = min(row, S - 1 - key0);                               // key0 + row < S (>= 0: key0 <= last query < S)
+      kreg[i] = ld4(base + (size_t)rr * HD + c4 * 4);
+      vreg[i] = ld4(base + v_off + (size_t)rr * HD + c4 * 4);
+    }
+  };
+  f32x16 accO[NMB];
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accO[mb][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  gload(0);
+  for (int kt = 0; kt < ntile; ++kt) {
+    __syncthreads();                                                       // the previous tile is fully consumed
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = i * 256 + t, row = idx / F4, c4 = idx % F4;
+      *reinterpret_cast<float4*>(Ks + row * LDK + c4 * 4) = kreg[i];
+      *reinterpret_cast<float4*>(Vs + row * LDK + c4 * 4) = vreg[i];
+    }
+    __syncthreads();
+    if (kt + 1 < ntile) gload(kt + 1);                                     // next tile under the MFMAs
+    if (kt > my_last) continue;                                            // beyond this wave's diagonal (uniform per wave)
+    // ---- S^T[key][query] = sum_k K[key][k] Q[query][k]
+    f32x16 accS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accS[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float4 kf = *reinterpret_cast<const float4*>(Ks + li * LDK + 8 * j + 4 * lh);
+      accS = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qr[j].x, accS, 0, 0, 0);
+      accS = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qr[j].y, accS, 0, 0, 0);
+      accS = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qr[j].z, accS, 0, 0, 0);
+      accS = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qr[j].w, accS, 0, 0, 0);
+    }
+    // ---- online softmax down the lane's query column: register r holds key kt*32 + (r&3) + 8(r>>2) + 4lh
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * KT + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      accS[r] = (key <= qi && key < S) ? accS[r] * a.scale : -INFINITY;     // causal: a query sees keys at positions <= its own
+      mloc = fmaxf(mloc, accS[r]);
+    }
+    mloc = fmaxf(mloc, xor32_f(mloc));
+    const float mnew = fmaxf(m, mloc);                                     // finite for every live query: key 0 is always visible
+    const float alpha = (m > -INFINITY) ? expf(m - mnew) : 0.f;
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      accS[r] = (mnew > -INFINITY) ? expf(accS[r] - mnew) : 0.f;
+      lsum += accS[r];
+    }
+    lsum += xor32_f(lsum);
+    l = l * alpha + lsum;
+    m = mnew;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accO[mb][r] *= alpha;
+    // ---- O^T[d][query] += sum_key V[key][d] P[key][query]: step s consumes the keys of accumulator register s (both halves)
+#pragma unroll
+    for (int sidx = 0; sidx < 16; ++sidx) {
+      const float* vrow = Vs + ((sidx & 3) + 8 * (sidx >> 2) + 4 * lh) * LDK + li;
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) accO[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[mb * 32], accS[sidx], accO[mb], 0, 0, 0);
+    }
+  }
+  if (qi >= S) return;
+  const float inv = 1.0f / l;
+  float* orow = out + (size_t)(r0 + qi) * D + h * HD;
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)                                            // registers 4g..4g+3 = head_dim mb*32 + 8g + 4lh + 0..3
+      *reinterpret_cast<float4*>(orow + mb * 32 + 8 * g + 4 * lh) =
+          make_float4(accO[mb][4 * g] * inv, accO[mb][4 * g + 1] * inv, accO[mb][4 * g + 2] * inv, accO[mb][4 * g + 3] * inv);
+}
+
 int check(const ssrhip_attn_args* a, const char* who) {
   SSR_REQUIRE(a && a->q && a->kv.pool && a->kv.table && a->row_len, "%s: null argument", who);
   SSR_REQUIRE(a->kv.head_dim == 64 || a->kv.head_dim == 128, "%s: head_dim %d not in {64,128}", who, a->kv.head_dim);
@@ -315,6 +448,19 @@ static ssrhip_attn_args row_slice(const ssrhip_attn_args& a, int r0, int n) {
   return s;
 }
 enum { MAX_GRID_ROWS = 65535 };
+
+extern "C" int ssrhip_attn_prefill(const ssrhip_attn_args* a, const int32_t* seq_start, int32_t n_seq, int32_t max_len, float* out,
+                                   ssrhip_stream_t stream) {
+  SSR_REQUIRE(a && a->q && a->kv.pool && a->kv.table && seq_start && out, "ssrhip_attn_prefill: null argument");
+  SSR_REQUIRE(a->kv.head_dim == 64 || a->kv.head_dim == 128, "ssrhip_attn_prefill: head_dim %d not in {64,128}", a->kv.head_dim);
+  SSR_REQUIRE(n_seq > 0 && n_seq <= 65535 && max_len > 0 && a->kv.n_head <= 65535, "ssrhip_attn_prefill: bad n_seq / max_len");
+  SSR_REQUIRE((a->q_stride ? a->q_stride : a->kv.n_head * a->kv.head_dim) % 4 == 0, "ssrhip_attn_prefill: q_stride must be a multiple of 4");
+  dim3 grid((max_len + 127) / 128, a->kv.n_head, n_seq);
+  if (a->kv.head_dim == 128) hipLaunchKernelGGL(attn_prefill_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, *a, seq_start, out);
+  else hipLaunchKernelGGL(attn_prefill_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, *a, seq_start, out);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int ssrhip_attn_rows(const ssrhip_attn_args* a, float* out, ssrhip_stream_t stream) {
   if (int e = check(a, "ssrhip_attn_rows")) return e;

@@ -340,7 +340,8 @@ extern "C" int ssrhip_lm_time_category(ssrhip_lm* lm, int32_t category, int32_t 
 
 extern "C" int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ssrhip_stream_t stream) {
   SSR_REQUIRE(lm && p && p->tok && p->pos && p->kind && p->row_seq && p->row_pos && p->row_len, "ssrhip_lm_prefill: null argument");
-  SSR_REQUIRE(p->x && p->xn && p->qkv && p->o && p->h && p->part_o && p->part_ml, "ssrhip_lm_prefill: null workspace");
+  const bool tiled_attn = p->seq_start && p->n_seq > 0 && p->max_len > 0 && !getenv_flag("SSRHIP_PREFILL_ATTN_ROWWISE");
+  SSR_REQUIRE(p->x && p->xn && p->qkv && p->o && p->h && (tiled_attn || (p->part_o && p->part_ml)), "ssrhip_lm_prefill: null workspace");
   const ssrhip_lm_dims& d = lm->d;
   const ssrhip_lm_weights& w = lm->w;
   const int D = d.d_model, R = p->R;
@@ -369,8 +370,13 @@ extern "C" int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ss
     at.R = R; at.max_splits = p->max_splits; at.scale = 1.0f / sqrtf((float)(D / d.n_head));
     at.part_o = p->part_o; at.part_ml = p->part_ml;
     at.q = p->qkv; at.q_stride = 3 * D;   // q is the first third of each packed qkv row
-    if (int rc = ssrhip_attn_decode(&at, s)) return rc;
-    if (int rc = ssrhip_attn_combine(&at, p->o, s)) return rc;
+    if (tiled_attn) {
+      // whole prompts: K/V tiles staged in LDS once per 128 queries, both products on the matrix core, no partials
+      if (int rc = ssrhip_attn_prefill(&at, p->seq_start, p->n_seq, p->max_len, p->o, s)) return rc;
+    } else {
+      if (int rc = ssrhip_attn_decode(&at, s)) return rc;
+      if (int rc = ssrhip_attn_combine(&at, p->o, s)) return rc;
+    }
 
     memset(&g, 0, sizeof(g));
     g.A = p->o; g.W = w.out_proj_w[l]; g.bias = w.out_proj_b[l]; g.C = p->x;

@@ -450,16 +450,19 @@ class DecodeEngine:
         D, F, H = a.D, a.F, a.H
         ms = (max(kv0) + PAGE - 1) // PAGE
         ws = dict(x=torch.empty(R, D, **f32), xn=torch.empty(R, D, **f32), qkv=torch.empty(R, 3 * D, **f32),
-                  o=torch.empty(R, D, **f32), h=torch.empty(R, F, **f32),
-                  part_o=torch.empty(R * H * ms * self.hd, **f32), part_ml=torch.empty(R * H * ms * 2, **f32))
+                  o=torch.empty(R, D, **f32), h=torch.empty(R, F, **f32))
+        # rows of sequence b are contiguous and in position order: the tiled prefill attention needs only where each starts
+        starts = np.concatenate([[0], np.cumsum(kv0)]).astype(np.int32)
+        seq_start = torch.from_numpy(starts).to(dev)
         p = _lib.PrefillArgs()
         p.tok, p.pos, p.kind = tok.data_ptr(), pos.data_ptr(), kind.data_ptr()
         p.row_seq, p.row_pos, p.row_len = seq.data_ptr(), rpos.data_ptr(), rlen.data_ptr()
         p.R, p.max_splits = R, ms
         for k, v in ws.items():
             setattr(p, k, v.data_ptr())
+        p.seq_start, p.n_seq, p.max_len = seq_start.data_ptr(), self.B, int(max(kv0))
         _lib.check(self.lib.ssrhip_lm_prefill(self._ctx, C.byref(p), _lib.stream_ptr()), "ssrhip_lm_prefill")
-        self._keep = (tok, pos, kind, seq, rpos, rlen, ws)   # alive until the stream has consumed them
+        self._keep = (tok, pos, kind, seq, rpos, rlen, ws, seq_start)   # alive until the stream has consumed them
         return R
 
     # ------------------------------------------------------------------ KV page bookkeeping

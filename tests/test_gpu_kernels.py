@@ -276,6 +276,44 @@ def test_attention_decode_and_combine(L, hd):
         torch.testing.assert_close(dy.cpu(), F.linear(ref[r0:r0 + 2], Wt), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("hd", [64, 128])
+def test_attention_prefill_tiled_matches_torch(L, hd):
+    """ssrhip_attn_prefill: causal attention of whole prompts from the paged cache (K/V tiles in LDS, both products on the matrix
+    core) vs F.scaled_dot_product_attention(is_causal=True) per (sequence, head): ragged lengths around the 32-key tile, the
+    128-query block and the 128-position page boundaries, a shuffled page table, q taken from a packed qkv buffer."""
+    g = torch.Generator().manual_seed(100 + hd)
+    H, n_layer, max_pages, layer = 3, 2, 4, 1
+    lens = [1, 33, 130, 300, 128, 129, 257, 64]
+    n_seq = len(lens)
+    D = H * hd
+    pool, table = _make_cache(n_seq, max_pages, n_layer, H, hd, g)
+    perm = torch.randperm(n_seq * max_pages, generator=g).to(torch.int32).view(n_seq, max_pages)
+    table = perm
+    R = sum(lens)
+    qkv = torch.randn(R, 3 * D, generator=g)
+    starts = [0]
+    for ln in lens:
+        starts.append(starts[-1] + ln)
+    ref = torch.zeros(R, D)
+    for s_, ln in enumerate(lens):
+        for h in range(H):
+            k = _gather(pool, table, s_, layer, 0, h, ln)
+            v = _gather(pool, table, s_, layer, 1, h, ln)
+            q = qkv[starts[s_]:starts[s_ + 1], h * hd:(h + 1) * hd]
+            o = F.scaled_dot_product_attention(q.view(1, 1, ln, hd), k.view(1, 1, ln, hd), v.view(1, 1, ln, hd), is_causal=True)
+            ref[starts[s_]:starts[s_ + 1], h * hd:(h + 1) * hd] = o.view(ln, hd)
+    dpool, dtable, dq = dev(pool), dev(table), dev(qkv)
+    dstart = dev(torch.tensor(starts, dtype=torch.int32))
+    out = torch.full((R, D), float("nan"), device="cuda")
+    a = _lib.AttnArgs()
+    a.q, a.q_stride = dq.data_ptr(), 3 * D
+    a.kv = _lib.KV(dpool.data_ptr(), dtable.data_ptr(), max_pages, n_layer, H, hd)
+    a.layer, a.scale = layer, 1.0 / math.sqrt(hd)
+    _lib.check(L.ssrhip_attn_prefill(C.byref(a), dstart.data_ptr(), n_seq, max(lens), out.data_ptr(), _lib.stream_ptr()))
+    sync()
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-5, atol=2e-5)
+
+
 def test_qkv_append_writes_cache(L):
     g = torch.Generator().manual_seed(9)
     B, D, H, hd, n_layer, max_pages, layer = 2, 256, 2, 128, 2, 3, 1
