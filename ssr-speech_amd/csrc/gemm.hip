@@ -16,7 +16,11 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16, LDSW = BK + 4;
+#ifndef SSR_GEMM_BK
+#define SSR_GEMM_BK 16
+#endif
+constexpr int BK = SSR_GEMM_BK, LDSW = BK + 4;
+constexpr int TPR = BK / 4, RPP = 256 / TPR;      // loader: threads per tile row, rows per pass of the 256 threads
 
 __device__ __forceinline__ float act_fn(float v, int act) {
   if (act == SSRHIP_ACT_RELU) return fmaxf(v, 0.f);
@@ -34,7 +38,7 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 template <int MW, int NW, int MT, int NT>
 __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
   constexpr int BM = MW * MT * 32, BN = NW * NT * 32;
-  constexpr int LA = BM / 64, LW = (BN + 63) / 64;       // float4 loads per thread per k-tile
+  constexpr int LA = BM / RPP, LW = (BN + RPP - 1) / RPP;       // float4 loads per thread per k-tile
   __shared__ __attribute__((aligned(16))) float As[BM * LDSW];
   __shared__ __attribute__((aligned(16))) float Ws[BN * LDSW];
   ssrhip_gemm_args a = a0;
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / NW, wn = wave % NW;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-  const int lr = t >> 2, lc = (t & 3) * 4;            // loader: row, first k column
+  const int lr = t / TPR, lc = (t % TPR) * 4;            // loader: row, first k column
   const int M = a.M, N = a.N, K = a.K;
 
   f32x16 acc[MT][NT];
@@ -64,14 +68,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
     const bool kin = (k0 + lc) < K;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-      const int m = m0 + lr + 64 * i;
+      const int m = m0 + lr + RPP * i;
       ra[i] = (kin && m < M) ? ld4(a.A + (size_t)m * a.lda + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (a.act_in == SSRHIP_ACT_ELU) { ra[i].x = elu1(ra[i].x); ra[i].y = elu1(ra[i].y); ra[i].z = elu1(ra[i].z); ra[i].w = elu1(ra[i].w); }
     }
 #pragma unroll
     for (int i = 0; i < LW; ++i) {
-      const int n = n0 + lr + 64 * i;
-      rw[i] = (kin && n < N && (lr + 64 * i) < BN) ? ld4(a.W + (size_t)n * K + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int n = n0 + lr + RPP * i;
+      rw[i] = (kin && n < N && (lr + RPP * i) < BN) ? ld4(a.W + (size_t)n * K + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   gload(0);
@@ -79,10 +83,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();                                   // previous tile fully consumed
 #pragma unroll
-    for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(&As[(lr + 64 * i) * LDSW + lc]) = ra[i];
+    for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(&As[(lr + RPP * i) * LDSW + lc]) = ra[i];
 #pragma unroll
     for (int i = 0; i < LW; ++i)
-      if (lr + 64 * i < BN) *reinterpret_cast<float4*>(&Ws[(lr + 64 * i) * LDSW + lc]) = rw[i];
+      if (lr + RPP * i < BN) *reinterpret_cast<float4*>(&Ws[(lr + RPP * i) * LDSW + lc]) = rw[i];
     __syncthreads();
     if (k0 + BK < K) gload(k0 + BK);                   // prefetch next tile under the MFMAs
 #pragma unroll

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import time
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
@@ -451,6 +452,8 @@ class DecodeEngine:
         ms = (max(kv0) + PAGE - 1) // PAGE
         ws = dict(x=torch.empty(R, D, **f32), xn=torch.empty(R, D, **f32), qkv=torch.empty(R, 3 * D, **f32),
                   o=torch.empty(R, D, **f32), h=torch.empty(R, F, **f32))
+        if os.environ.get("SSRHIP_PREFILL_ATTN_ROWWISE", "0") not in ("", "0"):      # A/B knob: the round-1 per-row attention needs its partials
+            ws.update(part_o=torch.empty(R * H * ms * self.hd, **f32), part_ml=torch.empty(R * H * ms * 2, **f32))
         # rows of sequence b are contiguous and in position order: the tiled prefill attention needs only where each starts
         starts = np.concatenate([[0], np.cumsum(kv0)]).astype(np.int32)
         seq_start = torch.from_numpy(starts).to(dev)
