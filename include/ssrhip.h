@@ -265,7 +265,8 @@ int ssrhip_rvq_encode(const float* emb, const float* codebooks, const float* e2,
                       int32_t D, int32_t n_q, int32_t bins, int64_t emb_bstride, ssrhip_stream_t stream);
 int ssrhip_rvq_decode(const int32_t* codes, const float* codebooks, float* out, int32_t B, int32_t T, int32_t D,
                       int32_t n_q, int32_t bins, int64_t out_bstride, ssrhip_stream_t stream);
-/* Fused SEANetResnetBlock (modules/seanet.py:16-60; true_skip, dilation 1, kernel sizes 3 and 1) for C == 64 channels:
+/* Fused SEANetResnetBlock (modules/seanet.py:16-60; true_skip, dilation 1, kernel sizes 3 and 1) for C in {64, 128, 256, 512}
+ * channels (64: one persistent kernel with W3 resident in LDS; wider: two chained GEMMs with the C/2 intermediate kept in LDS):
  *   y[b][t][:] = x[b][t][:] + b1 + W1 . ELU(b3 + W3 . ELU(x[b][t-1 : t+2][:]))
  * x points at the row BEFORE t = 0 of item 0 of a time-major buffer [B][1 + T + 1][C] (halo rows hold the zero / reflect
  * padding); w3 is [C/2][3][C] (output channel, tap, input channel), w1 is [C][C/2]; y points at row t = 0. */

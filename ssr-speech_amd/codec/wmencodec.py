@@ -258,13 +258,14 @@ class WMEncodecModel:
 
     def _res(self, cs, x: TM, nxt) -> TM:
         c3, c1 = cs
-        if self.fuse_resblock and c3.Cin == 64 and c3.k == 3 and c3.s == 1 and c1.k == 1 and c1.s == 1 and x.padL == 1 and x.padR == 1:
-            # the full-rate 64-channel block as one kernel (csrc/resblock.hip): one read + one write of the activation
+        if self.fuse_resblock and c3.Cin in (64, 128, 256, 512) and c3.Cout * 2 == c3.Cin and c3.k == 3 and c3.s == 1 and c1.k == 1 and c1.s == 1 \
+                and x.padL == 1 and x.padR == 1:
+            # the whole block as one kernel (csrc/resblock.hip): one read + one write of the activation, the C/2 intermediate stays on chip
             out = self._alloc_for(x.B, x.T, c1.Cout, nxt)
             a = _lib.ResblockArgs()
             a.x, a.y = x.base, out.interior
             a.w3, a.b3, a.w1, a.b1 = c3.W.data_ptr(), c3.b.data_ptr(), c1.W.data_ptr(), c1.b.data_ptr()
-            a.B, a.T, a.C = x.B, x.T, 64
+            a.B, a.T, a.C = x.B, x.T, c3.Cin
             a.x_bstride, a.y_bstride = x.bstride, out.bstride
             _lib.check(self.lib.ssrhip_resblock(C.byref(a), self._s()), "ssrhip_resblock")
             self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))

@@ -134,11 +134,170 @@ __global__ __launch_bounds__(NWAVE * 64) void resblock64_kernel(const ssrhip_res
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same block for C = 128 / 256 / 512 channels (the 8 kHz / 2 kHz / 400 Hz stages of SEANet) as TWO CHAINED GEMMs in one
+// kernel. W3 (98 KB .. 1.5 MB) no longer fits next to the activation tiles, so the weights stream through LDS in 16-wide k-tiles
+// like in gemm.hip — what is kept on chip is the C/2-channel INTERMEDIATE: stage 1 leaves ELU(b3 + W3 . ELU(x-window)) for a
+// block of BM time steps in LDS (64 KB whatever C is: BM = 256 / 128 / 64 rows), stage 2 reads it as its A operand straight
+// from there. As two GEMM launches the intermediate made a round trip through HBM and the 1x1 convolution ran on a thin
+// K = C/2 GEMM that was bound by its three activation streams (C = 128 at 32 x 30 s: 5.6 + 4.6 ms for the two launches).
+//   4 waves; both stages give every wave a 64-row slab: stage 1  (BM x C/2):  64 x 64  per wave = 4 accumulators,
+//                                                       stage 2  (BM x C)  :  64 x 128 per wave = 8 accumulators.
+//   v_mfma_f32_32x32x2_f32, operands via conflict-free ds_read_b128, next k-tile prefetched into registers under the MFMAs.
+template <int CC>
+__global__ __launch_bounds__(256) void resblock_chain_kernel(const ssrhip_resblock_args a) {
+  constexpr int HH = CC / 2, MW = 512 / CC, NW = 4 / MW, BM = MW * 64;
+  constexpr int BKc = 16, LDT = BKc + 4, LDH = HH + 4;
+  constexpr int LA = BM / 64, LW3 = HH / 64, LW1 = CC / 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Hs = smem;                          // [BM][LDH]  intermediate (A operand of stage 2)
+  float* As = Hs + BM * LDH;                 // [BM][LDT]  stage-1 A tile
+  float* Ws = As + BM * LDT;                 // [CC][LDT]  W3 tile (HH rows) / W1 tile (CC rows)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / NW, wn = wave % NW;
+  const int lr = t >> 2, lc = (t & 3) * 4;
+  const int T = a.T, m0 = blockIdx.x * BM;
+  const float* xin = a.x + (size_t)blockIdx.y * a.x_bstride;      // row 0 = the halo row in front of t = 0
+  float* yout = a.y + (size_t)blockIdx.y * a.y_bstride;
+  constexpr int K3c = 3 * CC;
+
+  // ---------------- stage 1: Hm[BM][HH] = ELU(x-window)[BM][3C] . W3^T
+  f32x16 acc1[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+  float4 ra[LA], rw[LW1];
+  auto gload1 = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int m = min(m0 + lr + 64 * i, T - 1);                  // rows past T: clamped (their outputs are not stored)
+      float4 v = ld4(xin + (size_t)m * CC + k0 + lc);              // window of time m = padded rows m, m+1, m+2 = 3C contiguous floats
+      ra[i] = make_float4(elu_fast(v.x), elu_fast(v.y), elu_fast(v.z), elu_fast(v.w));
+    }
+#pragma unroll
+    for (int i = 0; i < LW3; ++i) rw[i] = ld4(a.w3 + (size_t)(lr + 64 * i) * K3c + k0 + lc);
+  };
+  gload1(0);
+  for (int k0 = 0; k0 < K3c; k0 += BKc) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(&As[(lr + 64 * i) * LDT + lc]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < LW3; ++i) *reinterpret_cast<float4*>(&Ws[(lr + 64 * i) * LDT + lc]) = rw[i];
+    __syncthreads();
+    if (k0 + BKc < K3c) gload1(k0 + BKc);
+#pragma unroll
+    for (int kk = 0; kk < BKc; kk += 8) {
+      float4 a4[2], b4[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a4[i] = *reinterpret_cast<const float4*>(&As[(wm * 64 + i * 32 + li) * LDT + kk + lh * 4]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b4[j] = *reinterpret_cast<const float4*>(&Ws[(wn * 64 + j * 32 + li) * LDT + kk + lh * 4]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc1[i][j], 0, 0, 0);
+          acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc1[i][j], 0, 0, 0);
+          acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc1[i][j], 0, 0, 0);
+          acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc1[i][j], 0, 0, 0);
+        }
+    }
+  }
+  // intermediate -> LDS with bias + ELU (accumulator element r: row (r&3) + 8(r>>2) + 4lh, column li of its 32x32 block)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int hc = wn * 64 + j * 32 + li;
+    const float b3 = a.b3[hc];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Hs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDH + hc] = elu_fast(acc1[i][j][r] + b3);
+  }
+  // ---------------- stage 2: Y[BM][C] = Hm[BM][HH] . W1^T  (+ b1 + x)
+  f32x16 acc2[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+  auto gload2 = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < LW1; ++i) rw[i] = ld4(a.w1 + (size_t)(lr + 64 * i) * HH + k0 + lc);
+  };
+  gload2(0);
+  for (int k0 = 0; k0 < HH; k0 += BKc) {
+    __syncthreads();                                               // first pass: Hs complete and the W3 tile consumed
+#pragma unroll
+    for (int i = 0; i < LW1; ++i) *reinterpret_cast<float4*>(&Ws[(lr + 64 * i) * LDT + lc]) = rw[i];
+    __syncthreads();
+    if (k0 + BKc < HH) gload2(k0 + BKc);
+#pragma unroll
+    for (int kk = 0; kk < BKc; kk += 8) {
+      float4 a4[2], b4[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a4[i] = *reinterpret_cast<const float4*>(&Hs[(wm * 64 + i * 32 + li) * LDH + k0 + kk + lh * 4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(&Ws[(wn * 128 + j * 32 + li) * LDT + kk + lh * 4]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc2[i][j], 0, 0, 0);
+          acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc2[i][j], 0, 0, 0);
+          acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc2[i][j], 0, 0, 0);
+          acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc2[i][j], 0, 0, 0);
+        }
+    }
+  }
+  // ---------------- epilogue: + b1 + x (raw, the centre tap's row), 128-byte runs per accumulator row
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = wn * 128 + j * 32 + li;
+    const float b1 = a.b1[n];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < T) yout[(size_t)m * CC + n] = xin[(size_t)(m + 1) * CC + n] + (acc2[i][j][r] + b1);
+      }
+  }
+}
+
+template <int CC>
+int launch_resblock_chain(const ssrhip_resblock_args* a, hipStream_t s) {
+  constexpr int HH = CC / 2, MW = 512 / CC, BM = MW * 64;
+  const size_t smem = ((size_t)BM * (HH + 4) + (size_t)BM * 20 + (size_t)CC * 20) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_chain_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_set = true;
+  }
+  SSR_REQUIRE((a->T + BM - 1) / BM <= 2147483647 / 1 && a->B <= 65535, "ssrhip_resblock: grid too large");
+  hipLaunchKernelGGL(resblock_chain_kernel<CC>, dim3((a->T + BM - 1) / BM, a->B), dim3(256), smem, s, *a);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int ssrhip_resblock(const ssrhip_resblock_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->x && a->y && a->w3 && a->b3 && a->w1 && a->b1, "ssrhip_resblock: null argument");
-  SSR_REQUIRE(a->C == 64 && a->B > 0 && a->B <= 65535 && a->T > 0, "ssrhip_resblock: only the 64-channel block is fused (C=%d)", a->C);
+  SSR_REQUIRE(a->B > 0 && a->B <= 65535 && a->T > 0, "ssrhip_resblock: bad B / T");
+  if (a->C == 128 || a->C == 256 || a->C == 512) {
+    int rc = a->C == 128 ? launch_resblock_chain<128>(a, (hipStream_t)stream) : (a->C == 256 ? launch_resblock_chain<256>(a, (hipStream_t)stream) : launch_resblock_chain<512>(a, (hipStream_t)stream));
+    if (rc) return rc;
+    SSR_LAUNCH_CHECK();
+    return 0;
+  }
+  SSR_REQUIRE(a->C == 64, "ssrhip_resblock: fused for C in {64, 128, 256, 512} (C=%d)", a->C);
   int gx = (256 + a->B - 1) / a->B;                       // ~1 eight-wave workgroup per CU in total; every wave then walks many tiles
   const int need = (a->T + 32 * NWAVE - 1) / (32 * NWAVE);
   if (gx > need) gx = need;
