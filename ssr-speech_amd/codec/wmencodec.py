@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -159,6 +160,12 @@ class WMEncodecModel:
         self.lib = _lib.lib()
         self.fuse_resblock = True            # tests switch it off to compare with the two-GEMM path
         self.force_few_out = False           # tests: take the few-output-channel kernel also for short inputs
+        # channel counts whose residual block runs as one kernel (env knob for A/B runs: e.g. SSRHIP_RESBLOCK_FUSE=64,128,256,512).
+        # Measured at 32 clips x 30 s (encode / decode ms): {64}: 86.9 / 88.8; {64,128}: 86.4 / 87.7 and 1.9 GB less memory;
+        # adding 256 or 512 (short time axes, wide weights): 88.3 / 89.1-90.5 — the chained kernel's LDS footprint leaves one
+        # workgroup per CU there and loses to two ordinary GEMM launches. So 64 and 128 are fused, 256 / 512 stay two GEMMs.
+        env = os.environ.get("SSRHIP_RESBLOCK_FUSE")
+        self.fuse_channels = tuple(int(v) for v in env.split(",") if v) if env is not None else (64, 128)
         sd = {k: v.detach().to(torch.float32).cpu() for k, v in state_dict.items()}
         dev = self.device
         self.encoder = _SeaNet(sd, "encoder.", cfg, False, dev)
@@ -258,7 +265,7 @@ class WMEncodecModel:
 
     def _res(self, cs, x: TM, nxt) -> TM:
         c3, c1 = cs
-        if self.fuse_resblock and c3.Cin in (64, 128, 256, 512) and c3.Cout * 2 == c3.Cin and c3.k == 3 and c3.s == 1 and c1.k == 1 and c1.s == 1 \
+        if self.fuse_resblock and c3.Cin in self.fuse_channels and c3.Cout * 2 == c3.Cin and c3.k == 3 and c3.s == 1 and c1.k == 1 and c1.s == 1 \
                 and x.padL == 1 and x.padR == 1:
             # the whole block as one kernel (csrc/resblock.hip): one read + one write of the activation, the C/2 intermediate stays on chip
             out = self._alloc_for(x.B, x.T, c1.Cout, nxt)

@@ -16,6 +16,7 @@
 //   * stage 2  D2[c][t] = sum_h W1[c][h] ELU(D1 + b3)[h][t], then the tile goes back through LDS so that the residual add
 //     and the store to HBM are coalesced 256-byte rows.
 // Waves never synchronise with each other (wave-scope fences only). HBM traffic: one read + one write of the activation.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -145,9 +146,11 @@ __global__ __launch_bounds__(NWAVE * 64) void resblock64_kernel(const ssrhip_res
 //   4 waves; both stages give every wave a 64-row slab: stage 1  (BM x C/2):  64 x 64  per wave = 4 accumulators,
 //                                                       stage 2  (BM x C)  :  64 x 128 per wave = 8 accumulators.
 //   v_mfma_f32_32x32x2_f32, operands via conflict-free ds_read_b128, next k-tile prefetched into registers under the MFMAs.
-template <int CC>
+template <int CC, int BM>
 __global__ __launch_bounds__(256) void resblock_chain_kernel(const ssrhip_resblock_args a) {
-  constexpr int HH = CC / 2, MW = 512 / CC, NW = 4 / MW, BM = MW * 64;
+  constexpr int HH = CC / 2, MW = BM / 64, NW = 4 / MW;
+  constexpr int NT1 = HH / (NW * 32), NT2 = CC / (NW * 32);        // 32-column accumulator blocks per wave in stage 1 / 2
+  static_assert(MW * NW == 4 && NT1 >= 1 && NT2 >= 1 && NT1 * NW * 32 == HH && NT2 * NW * 32 == CC, "bad tile");
   constexpr int BKc = 16, LDT = BKc + 4, LDH = HH + 4;
   constexpr int LA = BM / 64, LW3 = HH / 64, LW1 = CC / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -164,11 +167,11 @@ __global__ __launch_bounds__(256) void resblock_chain_kernel(const ssrhip_resblo
   constexpr int K3c = 3 * CC;
 
   // ---------------- stage 1: Hm[BM][HH] = ELU(x-window)[BM][3C] . W3^T
-  f32x16 acc1[2][2];
+  f32x16 acc1[2][NT1];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT1; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
   float4 ra[LA], rw[LW1];
@@ -193,15 +196,15 @@ __global__ __launch_bounds__(256) void resblock_chain_kernel(const ssrhip_resblo
     if (k0 + BKc < K3c) gload1(k0 + BKc);
 #pragma unroll
     for (int kk = 0; kk < BKc; kk += 8) {
-      float4 a4[2], b4[2];
+      float4 a4[2], b4[NT1];
 #pragma unroll
       for (int i = 0; i < 2; ++i) a4[i] = *reinterpret_cast<const float4*>(&As[(wm * 64 + i * 32 + li) * LDT + kk + lh * 4]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b4[j] = *reinterpret_cast<const float4*>(&Ws[(wn * 64 + j * 32 + li) * LDT + kk + lh * 4]);
+      for (int j = 0; j < NT1; ++j) b4[j] = *reinterpret_cast<const float4*>(&Ws[((wn * NT1 + j) * 32 + li) * LDT + kk + lh * 4]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NT1; ++j) {
           acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc1[i][j], 0, 0, 0);
           acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc1[i][j], 0, 0, 0);
           acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc1[i][j], 0, 0, 0);
@@ -211,8 +214,8 @@ __global__ __launch_bounds__(256) void resblock_chain_kernel(const ssrhip_resblo
   }
   // intermediate -> LDS with bias + ELU (accumulator element r: row (r&3) + 8(r>>2) + 4lh, column li of its 32x32 block)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int hc = wn * 64 + j * 32 + li;
+  for (int j = 0; j < NT1; ++j) {
+    const int hc = (wn * NT1 + j) * 32 + li;
     const float b3 = a.b3[hc];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -221,11 +224,11 @@ __global__ __launch_bounds__(256) void resblock_chain_kernel(const ssrhip_resblo
         Hs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDH + hc] = elu_fast(acc1[i][j][r] + b3);
   }
   // ---------------- stage 2: Y[BM][C] = Hm[BM][HH] . W1^T  (+ b1 + x)
-  f32x16 acc2[2][4];
+  f32x16 acc2[2][NT2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NT2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
   auto gload2 = [&](int k0) {
@@ -241,15 +244,15 @@ __global__ __launch_bounds__(256) void resblock_chain_kernel(const ssrhip_resblo
     if (k0 + BKc < HH) gload2(k0 + BKc);
 #pragma unroll
     for (int kk = 0; kk < BKc; kk += 8) {
-      float4 a4[2], b4[4];
+      float4 a4[2], b4[NT2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) a4[i] = *reinterpret_cast<const float4*>(&Hs[(wm * 64 + i * 32 + li) * LDH + k0 + kk + lh * 4]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b4[j] = *reinterpret_cast<const float4*>(&Ws[(wn * 128 + j * 32 + li) * LDT + kk + lh * 4]);
+      for (int j = 0; j < NT2; ++j) b4[j] = *reinterpret_cast<const float4*>(&Ws[((wn * NT2 + j) * 32 + li) * LDT + kk + lh * 4]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NT2; ++j) {
           acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc2[i][j], 0, 0, 0);
           acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc2[i][j], 0, 0, 0);
           acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc2[i][j], 0, 0, 0);
@@ -259,8 +262,8 @@ __global__ __launch_bounds__(256) void resblock_chain_kernel(const ssrhip_resblo
   }
   // ---------------- epilogue: + b1 + x (raw, the centre tap's row), 128-byte runs per accumulator row
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = wn * 128 + j * 32 + li;
+  for (int j = 0; j < NT2; ++j) {
+    const int n = (wn * NT2 + j) * 32 + li;
     const float b1 = a.b1[n];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -272,17 +275,16 @@ __global__ __launch_bounds__(256) void resblock_chain_kernel(const ssrhip_resblo
   }
 }
 
-template <int CC>
+template <int CC, int BM>
 int launch_resblock_chain(const ssrhip_resblock_args* a, hipStream_t s) {
-  constexpr int HH = CC / 2, MW = 512 / CC, BM = MW * 64;
+  constexpr int HH = CC / 2;
   const size_t smem = ((size_t)BM * (HH + 4) + (size_t)BM * 20 + (size_t)CC * 20) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_chain_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_chain_kernel<CC, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr_set = true;
   }
-  SSR_REQUIRE((a->T + BM - 1) / BM <= 2147483647 / 1 && a->B <= 65535, "ssrhip_resblock: grid too large");
-  hipLaunchKernelGGL(resblock_chain_kernel<CC>, dim3((a->T + BM - 1) / BM, a->B), dim3(256), smem, s, *a);
+  hipLaunchKernelGGL((resblock_chain_kernel<CC, BM>), dim3((a->T + BM - 1) / BM, a->B), dim3(256), smem, s, *a);
   return 0;
 }
 
@@ -292,7 +294,12 @@ extern "C" int ssrhip_resblock(const ssrhip_resblock_args* a, ssrhip_stream_t st
   SSR_REQUIRE(a && a->x && a->y && a->w3 && a->b3 && a->w1 && a->b1, "ssrhip_resblock: null argument");
   SSR_REQUIRE(a->B > 0 && a->B <= 65535 && a->T > 0, "ssrhip_resblock: bad B / T");
   if (a->C == 128 || a->C == 256 || a->C == 512) {
-    int rc = a->C == 128 ? launch_resblock_chain<128>(a, (hipStream_t)stream) : (a->C == 256 ? launch_resblock_chain<256>(a, (hipStream_t)stream) : launch_resblock_chain<512>(a, (hipStream_t)stream));
+    static const int big = getenv("SSRHIP_RESCHAIN_BIG") ? atoi(getenv("SSRHIP_RESCHAIN_BIG")) : 0;   // tuning knob: the larger row block
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (a->C == 128) rc = big ? launch_resblock_chain<128, 256>(a, s) : launch_resblock_chain<128, 128>(a, s);
+    else if (a->C == 256) rc = big ? launch_resblock_chain<256, 128>(a, s) : launch_resblock_chain<256, 64>(a, s);
+    else rc = launch_resblock_chain<512, 64>(a, s);
     if (rc) return rc;
     SSR_LAUNCH_CHECK();
     return 0;

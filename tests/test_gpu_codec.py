@@ -211,6 +211,7 @@ def test_every_seanet_layer_matches_the_reference(golden_dir, name):
     cfg.pad_mode = str(g["pad_mode"])
     sd = W.codec_state_dict(cfg, seed=int(g["weight_seed"]))
     m = WMEncodecModel(cfg, sd, "cuda")
+    m.fuse_channels = (64, 128, 256, 512)      # every fused residual-block kernel is checked, also the ones the default leaves to two GEMMs
 
     def as_tm(arr, nxt):                       # reference activation [1, C, T] -> time-major buffer with the halo `nxt` wants
         t = torch.from_numpy(arr)
