@@ -126,7 +126,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     at.part_o = b.part_o; at.part_ml = b.part_ml;
     // 5..16 rows with enough (row, head) pairs to give every CU one: the fused walk over the pages (no partials, no merge
     // launch); its output goes to b.h (free until FFN1 of this layer) because q is still being read by other workgroups
-    const bool fused_attn = B > 4 && B * d.n_head >= 192 && !getenv_flag("SSRHIP_ATTN_SPLIT");
+    const bool fused_attn = B > 4 && B * d.n_head >= 192 && b.kv.max_pages <= 256 && !getenv_flag("SSRHIP_ATTN_SPLIT");   // 256 pages: the kernel's page-id registers
     if (fused_attn) {
       at.out_tiled = 1;
       STEP_CALL(CAT_ATTN, ssrhip_attn_rows(&at, b.h, s));

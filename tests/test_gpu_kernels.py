@@ -276,6 +276,40 @@ def test_attention_decode_and_combine(L, hd):
         torch.testing.assert_close(dy.cpu(), F.linear(ref[r0:r0 + 2], Wt), rtol=2e-5, atol=2e-5)
 
 
+def test_attention_rows_beyond_64_pages(L):
+    """ssrhip_attn_rows keeps a row's page ids in 4 VGPRs (64 pages each, picked with v_readlane): contexts that cross the 64-,
+    128- and 192-page register boundaries (8,192 / 16,384 / 24,576 positions), a shuffled table, both register-pair parities of
+    the two-page pipeline (odd and even page counts)."""
+    g = torch.Generator().manual_seed(77)
+    H, hd, n_layer, layer = 2, 64, 1, 0
+    lens = [8191, 8193, 16385 + 128, 24577, 300, 1]
+    R = len(lens)
+    max_pages = (max(lens) + _lib.PAGE - 1) // _lib.PAGE
+    n_pages = R * max_pages
+    pool = torch.randn(n_pages, n_layer, 2, H, _lib.PAGE, hd, generator=g)
+    table = torch.randperm(n_pages, generator=g).to(torch.int32).view(R, max_pages)
+    q = torch.randn(R, H * hd, generator=g)
+    ref = torch.zeros(R, H * hd)
+    for r, ln in enumerate(lens):
+        for h in range(H):
+            k = _gather(pool, table, r, layer, 0, h, ln)
+            v = _gather(pool, table, r, layer, 1, h, ln)
+            ref[r, h * hd:(h + 1) * hd] = F.scaled_dot_product_attention(q[r, h * hd:(h + 1) * hd].view(1, 1, 1, hd), k.view(1, 1, ln, hd), v.view(1, 1, ln, hd)).view(-1)
+    dpool, dtable, dq = dev(pool), dev(table), dev(q)
+    dlen = dev(torch.tensor(lens, dtype=torch.int32))
+    out = torch.full((R, H * hd), float("nan"), device="cuda")
+    a = _lib.AttnArgs()
+    a.q, a.q_stride = dq.data_ptr(), 0
+    a.kv = _lib.KV(dpool.data_ptr(), dtable.data_ptr(), max_pages, n_layer, H, hd)
+    a.layer, a.row_seq, a.row_len, a.R, a.max_splits = layer, 0, dlen.data_ptr(), R, max_pages
+    a.scale = 1.0 / math.sqrt(hd)
+    _lib.check(L.ssrhip_attn_rows(C.byref(a), out.data_ptr(), _lib.stream_ptr()))
+    sync()
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-5, atol=2e-5)
+    a.kv = _lib.KV(dpool.data_ptr(), dtable.data_ptr(), 257, n_layer, H, hd)
+    assert L.ssrhip_attn_rows(C.byref(a), out.data_ptr(), _lib.stream_ptr()) != 0          # more than 256 pages per row: refused, not mis-read
+
+
 @pytest.mark.parametrize("hd", [64, 128])
 def test_attention_prefill_tiled_matches_torch(L, hd):
     """ssrhip_attn_prefill: causal attention of whole prompts from the paged cache (K/V tiles in LDS, both products on the matrix
