@@ -257,6 +257,10 @@ typedef struct ssrhip_lstm_args {
    * h = c = 0; a later window continues from the state the previous call left in hbuf / cbuf. Lets a caller run two stacked
    * layers as a software pipeline over chunks of steps on two streams (layer 2 chunk i beside layer 1 chunk i+1). */
   int32_t t_begin, t_end;
+  /* matrix-core path only (B > 4, or C not in {256,512,1024,2048}): w_hh is given as 16 x 16 blocks in lane order,
+   * packed[C/4 tiles][C/16 k-steps][4 k-slots][16 rows][4 floats] with row r of tile j = W_hh[(r % 4) * C + 4j + r / 4] (gate r % 4 of
+   * hidden unit 4j + r / 4), so that one wave-level load is one contiguous KiB instead of 64 pieces of 16 rows */
+  int32_t w_packed;
 } ssrhip_lstm_args;
 int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stream);
 /* residual vector quantisation (quantization/core_vq.py:164-179, 382-400): emb [B][T][D] time-major;

@@ -114,6 +114,14 @@ class _Lstm:
             bias = sd[pfx + f"lstm.bias_ih_l{l}"] + sd[pfx + f"lstm.bias_hh_l{l}"]
             self.layers.append((wih.contiguous().to(dev), whh.contiguous().to(dev), bias.contiguous().to(dev)))
         self.C = self.layers[0][1].shape[1]
+        # the recurrent matrix once more, in the order the matrix-core step kernel's lanes read it (include/ssrhip.h w_packed)
+        Cc = self.C
+        self.packed = []
+        for _, whh, _ in self.layers:
+            if Cc % 16 == 0:
+                self.packed.append(whh.view(4, Cc // 4, 4, Cc // 16, 4, 4).permute(1, 3, 4, 2, 0, 5).contiguous())
+            else:
+                self.packed.append(None)
 
 
 class _SeaNet:
@@ -160,6 +168,7 @@ class WMEncodecModel:
         self.lib = _lib.lib()
         self.fuse_resblock = True            # tests switch it off to compare with the two-GEMM path
         self.force_few_out = False           # tests: take the few-output-channel kernel also for short inputs
+        self.lstm_packed = os.environ.get("SSRHIP_LSTM_PACKED", "1") != "0"      # A/B knob for the packed recurrent matrix
         # channel counts whose residual block runs as one kernel (env knob for A/B runs: e.g. SSRHIP_RESBLOCK_FUSE=64,128,256,512).
         # Measured at 32 clips x 30 s (encode / decode ms): {64}: 86.9 / 88.8; {64,128}: 86.4 / 87.7 and 1.9 GB less memory;
         # adding 256 or 512 (short time axes, wide weights): 88.3 / 89.1-90.5 — the chained kernel's LDS footprint leaves one
@@ -305,7 +314,10 @@ class WMEncodecModel:
 
         def steps(l, t0, t1):
             a = _lib.LstmArgs()
-            a.gin, a.w_hh, a.out = gins[l].data_ptr(), L.layers[l][1].data_ptr(), outs[l].interior
+            small_b = B <= 4 and Cc in (256, 512, 1024, 2048)            # ssrhip_lstm_layer's path choice
+            use_packed = (not small_b) and L.packed[l] is not None and self.lstm_packed
+            a.gin, a.w_hh, a.out = gins[l].data_ptr(), (L.packed[l] if use_packed else L.layers[l][1]).data_ptr(), outs[l].interior
+            a.w_packed = int(use_packed)
             a.skip = x.interior if l == nl - 1 else 0                   # y = lstm(x) + x (lstm.py:21-23)
             a.hbuf, a.cbuf, a.gates = hbufs[l].data_ptr(), cbufs[l].data_ptr(), 0
             a.B, a.T, a.C = B, T, Cc

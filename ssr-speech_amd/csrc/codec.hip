@@ -217,7 +217,11 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const ssrhip_lstm_a
   const int c = lane & 15, ks = lane >> 4;
   const int C = a.C, j0 = blockIdx.x * 4, bt0 = blockIdx.y * NT;
   const int last = steps - 1;
-  const unsigned wvoff = ((unsigned)(c & 3) * C + min(j0 + (c >> 2), C - 1)) * (unsigned)C + ks * 4;
+  // W_hh operand: torch's [4C][C] (lane -> row (gate c&3, unit j0 + c>>2): 64 sixteen-byte pieces of 16 rows per wave-level load) or,
+  // a.w_packed, the same 16 x 16 blocks stored in the order the lanes read them (one contiguous KiB per load; codec/wmencodec.py packs it)
+  const unsigned wvoff = a.w_packed ? (unsigned)(ks * 16 + c) * 4 : ((unsigned)(c & 3) * C + min(j0 + (c >> 2), C - 1)) * (unsigned)C + ks * 4;
+  const float* wbase = a.w_packed ? a.w_hh + (size_t)blockIdx.x * steps * 256 : a.w_hh;
+  const int wstep = a.w_packed ? 256 : 16;
   const unsigned xvoff = (unsigned)(ks * 16 + c) * 4;
   const int tbase = wave * SPW;
 
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const ssrhip_lstm_a
   }
   float4 w[SPW];
 #pragma unroll
-  for (int i = 0; i < SPW; ++i) w[i] = ld4(a.w_hh + min(tbase + i, last) * 16 + wvoff);
+  for (int i = 0; i < SPW; ++i) w[i] = ld4(wbase + min(tbase + i, last) * wstep + wvoff);
 #pragma unroll
   for (int q = 0; q < NT; ++q)
 #pragma unroll
@@ -528,6 +532,7 @@ extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stre
     // small-batch kernel: C in {256, 512, 1024, 2048}; anything else (e.g. the narrow test configs) takes the matrix-core
     // path, which handles any C % 16 == 0 and any B
     if (small_b) {
+      SSR_REQUIRE(!a->w_packed, "ssrhip_lstm_layer: the small-batch path reads W_hh in torch's [4C][C] layout");
       for (int t = t_lo; t < t_hi; ++t) {
         const float* hp = a->hbuf + (size_t)(t & 1) * hc;
         float* hn = a->hbuf + (size_t)((t + 1) & 1) * hc;
@@ -541,6 +546,7 @@ extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stre
     } else {
       // hbuf holds [2][ceil(B/16)][C/4][16][4] (tiled per 16-item batch tile) on this path
       const int steps = a->C / 16;
+      SSR_REQUIRE(!a->w_packed || a->C % 16 == 0, "ssrhip_lstm_layer: packed W_hh needs C %% 16 == 0");
       SSR_REQUIRE(a->C <= 1024, "ssrhip_lstm_layer: the matrix-core path (B > 4, or C not in {256,512,1024,2048}) needs C <= 1024");
       const int nw = (steps + 15) / 16;                        // 256 columns of W_hh per wave -> <= 4 waves
       for (int t = t_lo; t < t_hi; ++t) {
