@@ -252,7 +252,12 @@ __device__ __forceinline__ const float* tile_wptr(const float* wbase, int row_lo
   return wbase + (size_t)min(rr, N - 1) * K + ks * 4;
 }
 
-template <int PRO, int SPWX, int DEP = 16>
+// PAIR (host-selected when every workgroup owns exactly ONE 8-row unit: out-proj, FFN2 — and the weights are in streaming order):
+// an 8-row tile in the 16-row MFMA duplicates its rows, so a wave-level load would carry only 512 useful bytes. Instead lanes
+// c >= 8 load the NEXT k-step's block of the same 8 rows (adjacent in memory: one contiguous KiB per load, half as many loads), the
+// k-steps are consumed in pairs — MFMAs against x[2i] are right in tile rows 0..7, MFMAs against x[2i+1] in rows 8..15 — and the
+// two half-results are added across lanes l <-> l+32 at the end. Same matrix-core work, half the load instructions.
+template <int PRO, int SPWX, int DEP = 16, bool PAIR = false>
 __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
   static_assert(SPWX >= DEP && SPWX % DEP == 0, "SPWX must be a multiple of the pipeline depth");
   __shared__ float red[2][8][16];
@@ -280,9 +285,14 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
 #pragma unroll
   for (int t = 0; t < SPWX; ++t) xr[t] = ld4(xbase + min(tbase + t, last) * xstep + xvoff);
   __builtin_amdgcn_sched_barrier(0);
-  const float* wp = tile_wptr(wbase, row_lo, nun, 0, c, ks, N, K, a.w_tiled);
+  const float* wp = tile_wptr(wbase, row_lo, nun, 0, c, ks, N, K, a.w_tiled) + (PAIR ? (c >> 3) * 128 : 0);
+  if (PAIR) {
 #pragma unroll
-  for (int i = 0; i < DEP; ++i) w[i] = ld_nt(wp + min(tbase + i, last) * wstep);
+    for (int i = 0; i < SPWX / 2; ++i) w[i] = ld_nt(wp + min(tbase + 2 * i, last - 1) * wstep);   // host: steps even, SPWX / 2 <= DEP
+  } else {
+#pragma unroll
+    for (int i = 0; i < DEP; ++i) w[i] = ld_nt(wp + min(tbase + i, last) * wstep);
+  }
   __builtin_amdgcn_sched_barrier(0);
   // what this wave's epilogue (tile `wave`) will need, requested now (behind the first weight loads, used after the last MFMA)
   const bool epi_mine = wave < ntile;
@@ -337,6 +347,32 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
     }
   }
 
+  if (PAIR) {
+    f4v aA = {0.f, 0.f, 0.f, 0.f}, aB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < SPWX / 2; ++i) {
+      const float4 wv = w[i], xa = xr[2 * i], xb = xr[2 * i + 1];
+      aA = mfma4(wv.x, xa.x, aA);
+      aB = mfma4(wv.x, xb.x, aB);
+      aA = mfma4(wv.y, xa.y, aA);
+      aB = mfma4(wv.y, xb.y, aB);
+      aA = mfma4(wv.z, xa.z, aA);
+      aB = mfma4(wv.z, xb.z, aB);
+      aA = mfma4(wv.w, xa.w, aA);
+      aB = mfma4(wv.w, xb.w, aB);
+    }
+    f4v acc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = aA[e] + xor32_f(aB[e]);          // rows 0..7 (lanes < 32) = own rows + rows 8..15 of lane + 32
+    part[0][wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+      f4v sum = part[0][0][lane];
+      for (int v = 1; v < p.nw; ++v) sum += part[0][v][lane];
+      tile_epilogue_finish(a, epi0, sum);
+    }
+    return;
+  }
   // all tiles but the last: the refills past this tile's k-range fetch the head of the next tile
   for (int tile = 0; tile < ntile - 1; ++tile) {
     const float* wn = tile_wptr(wbase, row_lo, nun, tile + 1, c, ks, N, K, a.w_tiled);
@@ -380,6 +416,7 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
 
 // K > 2048 without a LayerNorm prologue (FFN2, K = 8192): x no longer fits the registers of 8 waves, so it is streamed like W: per k-step one KiB of W (HBM) and one
 // KiB of x (L2; the tiled layout makes it one contiguous KiB per wave instruction), 16 of each in flight per wave.
+template <bool PAIR>
 __global__ __launch_bounds__(512) void gemv_rows_stream_kernel(const GemvR p) {
   constexpr int DEP = 16;
   __shared__ f4v part[MAXT][8][64];
@@ -403,7 +440,68 @@ __global__ __launch_bounds__(512) void gemv_rows_stream_kernel(const GemvR p) {
   const int xstep = a.x_tiled ? 256 : 16;
 
   float4 w[DEP], xr[DEP];
-  const float* wp = tile_wptr(wbase, row_lo, nun, 0, c, ks, N, K, a.w_tiled);
+  const float* wp = tile_wptr(wbase, row_lo, nun, 0, c, ks, N, K, a.w_tiled) + (PAIR ? (c >> 3) * 128 : 0);
+  if (PAIR) {
+    // one 8-row unit per workgroup (see gemv_rows_xreg_kernel): per group of 16 k-steps 8 weight loads (k-step pairs) + 16 x loads
+    float4 wq[DEP / 2];
+#pragma unroll
+    for (int i = 0; i < DEP; ++i) xr[i] = ld4(xp + min(tbase + i, last) * xstep);
+#pragma unroll
+    for (int i = 0; i < DEP / 2; ++i) wq[i] = ld_nt(wp + min(tbase + 2 * i, last - 1) * wstep);
+    __builtin_amdgcn_sched_barrier(0);
+    const TileEpi epi0 = tile_epilogue_fetch(a, p.hd, grp, row_lo, wave == 0 ? 8 : 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    f4v aA = {0.f, 0.f, 0.f, 0.f}, aB = {0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < ngrp - 1; ++g) {                                   // all groups but the last: refill for group g + 1
+      const int kb = tbase + g * DEP, kbn = kb + DEP;
+#pragma unroll
+      for (int i = 0; i < DEP / 2; ++i) {
+        const float4 wv = wq[i];
+        float4 xa = xr[2 * i], xb = xr[2 * i + 1];
+        if (kb + 2 * i > last) { xa = make_float4(0.f, 0.f, 0.f, 0.f); xb = xa; }   // steps is even: a pair is in or out as a whole
+        aA = mfma4(wv.x, xa.x, aA);
+        aB = mfma4(wv.x, xb.x, aB);
+        aA = mfma4(wv.y, xa.y, aA);
+        aB = mfma4(wv.y, xb.y, aB);
+        aA = mfma4(wv.z, xa.z, aA);
+        aB = mfma4(wv.z, xb.z, aB);
+        aA = mfma4(wv.w, xa.w, aA);
+        aB = mfma4(wv.w, xb.w, aB);
+        xr[2 * i] = ld4(xp + min(kbn + 2 * i, last) * xstep);
+        xr[2 * i + 1] = ld4(xp + min(kbn + 2 * i + 1, last) * xstep);
+        wq[i] = ld_nt(wp + min(kbn + 2 * i, last - 1) * wstep);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    {
+      const int kb = tbase + (ngrp - 1) * DEP;
+#pragma unroll
+      for (int i = 0; i < DEP / 2; ++i) {
+        const float4 wv = wq[i];
+        float4 xa = xr[2 * i], xb = xr[2 * i + 1];
+        if (kb + 2 * i > last) { xa = make_float4(0.f, 0.f, 0.f, 0.f); xb = xa; }
+        aA = mfma4(wv.x, xa.x, aA);
+        aB = mfma4(wv.x, xb.x, aB);
+        aA = mfma4(wv.y, xa.y, aA);
+        aB = mfma4(wv.y, xb.y, aB);
+        aA = mfma4(wv.z, xa.z, aA);
+        aB = mfma4(wv.z, xb.z, aB);
+        aA = mfma4(wv.w, xa.w, aA);
+        aB = mfma4(wv.w, xb.w, aB);
+      }
+    }
+    f4v acc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = aA[e] + xor32_f(aB[e]);
+    part[0][wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+      f4v sum = part[0][0][lane];
+      for (int v = 1; v < p.nw; ++v) sum += part[0][v][lane];
+      tile_epilogue_finish(a, epi0, sum);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < DEP; ++i) {
     const int kk = min(tbase + i, last);
@@ -477,7 +575,7 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s) {
               "ssrhip_gemv (B>4): the split-KV combine prologue is not fused; run ssrhip_attn_combine first");
   SSR_REQUIRE(a->x, "ssrhip_gemv: x is null");
   SSR_REQUIRE(!a->y_tiled || (a->N % 4 == 0 && a->epi != SSRHIP_EPI_QKV_APPEND), "ssrhip_gemv: tiled y needs N %% 4 == 0 and is not available for the q output");
-  static int g_ver = -1, g_cus = 0, g_wpc = 0, g_dep8 = 0;
+  static int g_ver = -1, g_cus = 0, g_wpc = 0, g_dep8 = 0, g_nopair = 0;
   if (g_ver < 0) {
     const char* e = getenv("SSRHIP_GEMVM_V");          // 1: the per-tile kernel (round 1), 2: rows-per-workgroup kernels (default)
     g_ver = (e && atoi(e) == 1) ? 1 : 2;
@@ -485,6 +583,7 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s) {
     g_cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) ? cu : 256;
     const char* w = getenv("SSRHIP_GEMVM_WPC");        // tuning knob: 512-thread workgroups per CU (default 1)
     g_wpc = (w && atoi(w) >= 1 && atoi(w) <= 4) ? atoi(w) : 1;
+    g_nopair = getenv("SSRHIP_GEMVM_NOPAIR") != nullptr;   // A/B knob: 8-row tiles with duplicated rows instead of k-step pairs
     g_dep8 = getenv("SSRHIP_GEMVM_DEP8") != nullptr;   // experiment: 8 instead of 16 weight loads in flight per wave (LayerNorm launches)
   }
   const int hd = a->kv.head_dim > 0 ? a->kv.head_dim : 1;
@@ -520,7 +619,11 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s) {
     if (r.wgs < need) r.wgs = need;
     SSR_REQUIRE(r.wgs <= 65535 * 32, "ssrhip_gemv (B>4): N too large");
     dim3 grid(r.wgs, a->groups), block(r.nw * 64);
-    if (!xreg) hipLaunchKernelGGL(gemv_rows_stream_kernel, grid, block, 0, s, r);
+    // every workgroup owns exactly one 8-row unit (out-proj, FFN2) and the weights are in streaming order: k-step pairs per load
+    const bool pair = a->w_tiled && r.units <= r.wgs && r.steps % 2 == 0 && !g_nopair;
+    if (!xreg && pair) hipLaunchKernelGGL(gemv_rows_stream_kernel<true>, grid, block, 0, s, r);
+    else if (!xreg) hipLaunchKernelGGL(gemv_rows_stream_kernel<false>, grid, block, 0, s, r);
+    else if (pair && a->pro == SSRHIP_PRO_NONE && spwx == 16) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_NONE, 16, 16, true>), grid, block, 0, s, r);
     else if (g_dep8 && a->pro == SSRHIP_PRO_LAYERNORM && spwx == 16) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_LAYERNORM, 16, 8>), grid, block, 0, s, r);
     else if (a->pro == SSRHIP_PRO_LAYERNORM && spwx == 16) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_LAYERNORM, 16>), grid, block, 0, s, r);
     else if (a->pro == SSRHIP_PRO_LAYERNORM) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_LAYERNORM, 32>), grid, block, 0, s, r);
