@@ -10,6 +10,7 @@
 //   * residual vector quantisation: nearest codebook row per frame (block per frame, scores in the
 //     reference's arithmetic form, first-max tie rule) and the gather-sum dequantiser,
 #include <string.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -300,6 +301,91 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const ssrhip_lstm_a
   }
 }
 
+// The same step for LARGE batches (>= 4 batch tiles, i.e. more than 48 items). With 4 hidden units per workgroup every one of the
+// C/4 = 256 workgroup columns re-reads the whole h_{t-1} (1 MB at 256 items) and every pair of batch tiles re-reads all of W_hh:
+// 393 MB of L2 traffic per step at 256 items, 64 us per step against a matrix-core floor of 13.7 us (rocprofv3, 256 clips x 30 s).
+// Here a workgroup owns RT = 4 row tiles (16 hidden units: 64 gate rows) — its W_hh slice, 256 KB, lives in the registers of its 4
+// waves (each wave a quarter of K) for the whole launch — and walks NQ batch tiles one after the other: h traffic drops 4x (64
+// workgroup columns), W traffic 2x (nbt/NQ batch groups), and the matrix core sees 256 back-to-back MFMAs per batch tile per wave.
+// The K-slices of a batch tile are added through LDS (double-buffered: one barrier per batch tile); wave r then finishes row tile
+// r of that batch tile (gates, cell update, h / out stores) while the others already multiply the next one. Needs the packed
+// W_hh (w_packed) and C % 16 == 0.
+template <int RT>
+__global__ __launch_bounds__(256) void lstm_step_wide_kernel(const ssrhip_lstm_args a, int t, const float* hprev, float* hnext, int nw, int steps,
+                                                              int nbt, int NQ) {
+  constexpr int SPW = 16;
+  __shared__ f4v_ tile[2][RT][4][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, ks = lane >> 4;
+  const int C = a.C, j0 = blockIdx.x * 4 * RT, bt0 = blockIdx.y * NQ;
+  const int last = steps - 1;
+  const int tbase = wave * SPW;
+  const unsigned lvoff = (unsigned)(ks * 16 + c) * 4;          // this lane's float4 inside a 1-KiB block (weights and h alike)
+
+  float4 w[RT][SPW];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const float* wb = a.w_hh + (size_t)min(blockIdx.x * RT + r, C / 4 - 1) * steps * 256;
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) w[r][i] = ld4(wb + min(tbase + i, last) * 256 + lvoff);
+  }
+  const int nq = min(NQ, nbt - bt0);
+  float4 xr[SPW];
+  auto load_x = [&](int q) {
+    const float* xbase = hprev + (size_t)min(bt0 + q, nbt - 1) * 16 * C;
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) xr[i] = ld4(xbase + min(tbase + i, last) * 256 + lvoff);
+  };
+  load_x(0);
+  for (int q = 0; q < nq; ++q) {
+    // what the finishing wave (wave r finishes row tile r) needs for this batch tile: requested before the MFMA chain
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pc = 0.f;
+    const bool fin = wave < RT;
+    const int bt = bt0 + q;
+    const int bb = min(bt * 16 + c, a.B - 1), jj = min(j0 + 4 * wave + ks, C - 1);
+    if (fin) {
+      const float* gin = a.gin + (size_t)bb * a.gin_bstride + (size_t)t * 4 * C;
+      pg[0] = gin[jj]; pg[1] = gin[C + jj]; pg[2] = gin[2 * C + jj]; pg[3] = gin[3 * C + jj];
+      pc = (t == 0) ? 0.f : a.cbuf[(size_t)bb * C + jj];
+    }
+    f4v_ acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = f4v_{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+      float4 xv = xr[i];
+      if (tbase + i > last) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r][i].x, xv.x, acc[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r][i].y, xv.y, acc[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r][i].z, xv.z, acc[r], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r][i].w, xv.w, acc[r], 0, 0, 0);
+    }
+    if (q + 1 < nq) load_x(q + 1);                            // next batch tile's h slice: in flight during the merge / gate phase
+#pragma unroll
+    for (int r = 0; r < RT; ++r) tile[q & 1][r][wave][lane] = acc[r];
+    __syncthreads();
+    if (fin) {
+      f4v_ sum = tile[q & 1][wave][0][lane];
+      for (int w2 = 1; w2 < nw; ++w2) sum += tile[q & 1][wave][w2][lane];
+      const int b = bt * 16 + c, j = j0 + 4 * wave + ks;
+      if (b < a.B && j < C) {
+        const float gi = sum[0] + pg[0], gf = sum[1] + pg[1], gg = sum[2] + pg[2], go = sum[3] + pg[3];
+        const float cn = sigmoidf_(gf) * pc + sigmoidf_(gi) * tanhf(gg);
+        const float hn = sigmoidf_(go) * tanhf(cn);
+        a.cbuf[(size_t)b * C + j] = cn;
+        hnext[(size_t)bt * 16 * C + SSRHIP_TILED(c, j)] = hn;
+        float o = hn;
+        if (a.skip) o += a.skip[(size_t)b * a.skip_bstride + (size_t)t * C + j];
+        a.out[(size_t)b * a.out_bstride + (size_t)t * C + j] = o;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void zero_kernel(float* p, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0.f;
 }
@@ -549,10 +635,15 @@ extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stre
       SSR_REQUIRE(!a->w_packed || a->C % 16 == 0, "ssrhip_lstm_layer: packed W_hh needs C %% 16 == 0");
       SSR_REQUIRE(a->C <= 1024, "ssrhip_lstm_layer: the matrix-core path (B > 4, or C not in {256,512,1024,2048}) needs C <= 1024");
       const int nw = (steps + 15) / 16;                        // 256 columns of W_hh per wave -> <= 4 waves
+      // large batches: 16 hidden units per workgroup, W_hh slice in registers, batch tiles walked in sequence (lstm_step_wide_kernel)
+      static const bool no_wide = getenv("SSRHIP_LSTM_NOWIDE") != nullptr;
+      const bool wide = a->w_packed && nbt >= 4 && a->C % 16 == 0 && a->C >= 64 && !no_wide;
+      const int wide_nq = nbt >= 8 ? 4 : 2;                    // >= 2 batch groups: with C = 1024 that is >= 128 workgroups
       for (int t = t_lo; t < t_hi; ++t) {
         const float* hp = a->hbuf + (size_t)(t & 1) * hc;
         float* hn = a->hbuf + (size_t)((t + 1) & 1) * hc;
-        if (nbt >= 2 && nw >= 2) hipLaunchKernelGGL((lstm_step_mfma_kernel<2>), dim3((a->C + 3) / 4, (nbt + 1) / 2), dim3(nw * 64), 0, s, *a, t, hp, hn, nw, steps, nbt);
+        if (wide) hipLaunchKernelGGL((lstm_step_wide_kernel<4>), dim3(a->C / 16, (nbt + wide_nq - 1) / wide_nq), dim3(256), 0, s, *a, t, hp, hn, nw, steps, nbt, wide_nq);
+        else if (nbt >= 2 && nw >= 2) hipLaunchKernelGGL((lstm_step_mfma_kernel<2>), dim3((a->C + 3) / 4, (nbt + 1) / 2), dim3(nw * 64), 0, s, *a, t, hp, hn, nw, steps, nbt);
         else hipLaunchKernelGGL((lstm_step_mfma_kernel<1>), dim3((a->C + 3) / 4, nbt), dim3(nw * 64), 0, s, *a, t, hp, hn, nw, steps, nbt);
       }
     }

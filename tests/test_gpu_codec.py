@@ -110,6 +110,25 @@ def test_lstm_mfma_step_full_width_two_batch_tiles():
     torch.testing.assert_close(d20[16:19], d2, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("B", [70, 130])
+def test_lstm_wide_step_kernel_large_batch(B):
+    """More than 48 clips switch the recurrence to `lstm_step_wide_kernel` (16 hidden units per workgroup, W_hh slice in registers,
+    batch tiles walked in sequence; B=70: 5 tiles in groups of 2 with a ragged last group and a ragged last tile, B=130: 9 tiles in
+    groups of 4). Items from the first, a middle and the last tile must equal the same clips run through the small-batch path
+    (which is pinned against the reference fixtures)."""
+    cfg = W.codec_config_full()
+    sd = W.codec_state_dict(cfg, seed=15)
+    m = WMEncodecModel(cfg, sd, "cuda")
+    g = torch.Generator().manual_seed(6)
+    wav = (torch.randn(B, 1, cfg.hop * 9 + 33, generator=g) * 0.2).cuda()
+    cB, _, eB = m.encode(wav)
+    dB = m.decode(cB)
+    for lo in (0, 47, B - 2):
+        c2, _, e2 = m.encode(wav[lo:lo + 2])
+        torch.testing.assert_close(eB[lo:lo + 2], e2, rtol=0, atol=2e-5)
+        torch.testing.assert_close(dB[lo:lo + 2], m.decode(cB[lo:lo + 2]), rtol=0, atol=2e-5)
+
+
 def test_rvq_encode_mfma_equals_scalar_kernel(monkeypatch):
     """The matrix-core RVQ search (16 frames per workgroup) against the per-frame scalar kernel: same codes except where
     the two best scores of a frame are closer than 1e-4 (different fp32 summation order). Full width: 128 dims, 2048 bins."""
