@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const ssrhip_lstm_a
   }
 }
 
-// The same step for LARGE batches (>= 4 batch tiles, i.e. more than 48 items). With 4 hidden units per workgroup every one of the
+// The same step for LARGE batches (>= 8 batch tiles, i.e. more than 112 items). With 4 hidden units per workgroup every one of the
 // C/4 = 256 workgroup columns re-reads the whole h_{t-1} (1 MB at 256 items) and every pair of batch tiles re-reads all of W_hh:
 // 393 MB of L2 traffic per step at 256 items, 64 us per step against a matrix-core floor of 13.7 us (rocprofv3, 256 clips x 30 s).
 // Here a workgroup owns RT = 4 row tiles (16 hidden units: 64 gate rows) — its W_hh slice, 256 KB, lives in the registers of its 4
@@ -322,21 +322,24 @@ __global__ __launch_bounds__(256) void lstm_step_wide_kernel(const ssrhip_lstm_a
   const int tbase = wave * SPW;
   const unsigned lvoff = (unsigned)(ks * 16 + c) * 4;          // this lane's float4 inside a 1-KiB block (weights and h alike)
 
-  float4 w[RT][SPW];
-#pragma unroll
-  for (int r = 0; r < RT; ++r) {
-    const float* wb = a.w_hh + (size_t)min(blockIdx.x * RT + r, C / 4 - 1) * steps * 256;
-#pragma unroll
-    for (int i = 0; i < SPW; ++i) w[r][i] = ld4(wb + min(tbase + i, last) * 256 + lvoff);
-  }
   const int nq = min(NQ, nbt - bt0);
+  float4 w[RT][SPW];
   float4 xr[SPW];
   auto load_x = [&](int q) {
     const float* xbase = hprev + (size_t)min(bt0 + q, nbt - 1) * 16 * C;
 #pragma unroll
     for (int i = 0; i < SPW; ++i) xr[i] = ld4(xbase + min(tbase + i, last) * 256 + lvoff);
   };
+  // the first batch tile's h slice, then W in the order the MFMA loop consumes it (k-step major): loads return in order, so the
+  // chain starts after the first RT weight loads and the rest of the 256 KB slice streams in underneath it
   load_x(0);
+  const float* wb[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) wb[r] = a.w_hh + (size_t)min(blockIdx.x * RT + r, C / 4 - 1) * steps * 256 + lvoff;
+#pragma unroll
+  for (int i = 0; i < SPW; ++i)
+#pragma unroll
+    for (int r = 0; r < RT; ++r) w[r][i] = ld4(wb[r] + min(tbase + i, last) * 256);
   for (int q = 0; q < nq; ++q) {
     // what the finishing wave (wave r finishes row tile r) needs for this batch tile: requested before the MFMA chain
     float pg[4] = {0.f, 0.f, 0.f, 0.f}, pc = 0.f;
@@ -637,8 +640,10 @@ extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stre
       const int nw = (steps + 15) / 16;                        // 256 columns of W_hh per wave -> <= 4 waves
       // large batches: 16 hidden units per workgroup, W_hh slice in registers, batch tiles walked in sequence (lstm_step_wide_kernel)
       static const bool no_wide = getenv("SSRHIP_LSTM_NOWIDE") != nullptr;
-      const bool wide = a->w_packed && nbt >= 4 && a->C % 16 == 0 && a->C >= 64 && !no_wide;
-      const int wide_nq = nbt >= 8 ? 4 : 2;                    // >= 2 batch groups: with C = 1024 that is >= 128 workgroups
+      // measured (encode / decode ms): 256 x 30 s: 602 / 611 -> 595 / 604 (step 63.9 -> 56.1 us with the two layers' launches sharing
+      // the GPU, 36.8 -> 27.8 us alone); 64 x 30 s (4 tiles -> 128 workgroups): 156.5 / 159.0 -> 158.3 / 161.8, so it starts at 8 tiles
+      const bool wide = a->w_packed && nbt >= 8 && a->C % 16 == 0 && a->C >= 64 && !no_wide;
+      const int wide_nq = 4;
       for (int t = t_lo; t < t_hi; ++t) {
         const float* hp = a->hbuf + (size_t)(t & 1) * hc;
         float* hn = a->hbuf + (size_t)((t + 1) & 1) * hc;

@@ -110,11 +110,10 @@ def test_lstm_mfma_step_full_width_two_batch_tiles():
     torch.testing.assert_close(d20[16:19], d2, rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("B", [70, 130])
+@pytest.mark.parametrize("B", [114, 130])
 def test_lstm_wide_step_kernel_large_batch(B):
-    """More than 48 clips switch the recurrence to `lstm_step_wide_kernel` (16 hidden units per workgroup, W_hh slice in registers,
-    batch tiles walked in sequence; B=70: 5 tiles in groups of 2 with a ragged last group and a ragged last tile, B=130: 9 tiles in
-    groups of 4). Items from the first, a middle and the last tile must equal the same clips run through the small-batch path
+    """More than 112 clips switch the recurrence to `lstm_step_wide_kernel` (16 hidden units per workgroup, W_hh slice in registers,
+    batch tiles walked in sequence, groups of 4: B=114: 8 tiles with a ragged last tile, B=130: 9 tiles = a ragged last group). Items from the first, a middle and the last tile must equal the same clips run through the small-batch path
     (which is pinned against the reference fixtures)."""
     cfg = W.codec_config_full()
     sd = W.codec_state_dict(cfg, seed=15)
