@@ -16,6 +16,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef SSR_GEMM_SINGLE_BUF
+#define SSR_GEMM_SINGLE_BUF 1      // 0: double-buffered LDS tiles, one barrier per k-tile — measured equal (4096^3: 100.5 vs 99.0 TFLOP/s;
+#endif                             // codec 32 x 30 s: 86.6 vs 86.7 ms), so the smaller LDS footprint stays the default
 #ifndef SSR_GEMM_BK
 #define SSR_GEMM_BK 16
 #endif
@@ -39,8 +42,13 @@ template <int MW, int NW, int MT, int NT>
 __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
   constexpr int BM = MW * MT * 32, BN = NW * NT * 32;
   constexpr int LA = BM / RPP, LW = (BN + RPP - 1) / RPP;       // float4 loads per thread per k-tile
-  __shared__ __attribute__((aligned(16))) float As[BM * LDSW];
-  __shared__ __attribute__((aligned(16))) float Ws[BN * LDSW];
+  constexpr int NBUF = SSR_GEMM_SINGLE_BUF ? 1 : 2;
+  const int li_ = threadIdx.x & 31, lh_ = (threadIdx.x & 63) >> 5;
+  // NBUF == 2: double-buffered LDS tiles, ONE barrier per k-tile (the next tile is written into the other buffer after this tile's
+  // MFMAs); NBUF == 1 (default, see SSR_GEMM_SINGLE_BUF): one buffer, two barriers per k-tile. Several workgroups share a CU, so the
+  // barrier stalls are already hidden: both forms keep the matrix core busy ~65 % of the time (profiles/r02_mfma_util_*).
+  __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDSW];
+  __shared__ __attribute__((aligned(16))) float Ws[NBUF][BN * LDSW];
   ssrhip_gemm_args a = a0;
   {   // batched problems: grid.z
     const size_t z = blockIdx.z;
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
     if (a.R) a.R += z * (size_t)a.strideR;
     if (a.rclass) a.rclass += z * (size_t)a.rclass_stride;
   }
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, wave = t >> 6;
   const int wm = wave / NW, wn = wave % NW;
   const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
   const int lr = t / TPR, lc = (t % TPR) * 4;            // loader: row, first k column
@@ -78,24 +86,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
       rw[i] = (kin && n < N && (lr + RPP * i) < BN) ? ld4(a.W + (size_t)n * K + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  gload(0);
-  const int li = lane & 31, lh = lane >> 5;
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();                                   // previous tile fully consumed
+  auto lds_store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(&As[(lr + RPP * i) * LDSW + lc]) = ra[i];
+    for (int i = 0; i < LA; ++i) *reinterpret_cast<float4*>(&As[buf][(lr + RPP * i) * LDSW + lc]) = ra[i];
 #pragma unroll
     for (int i = 0; i < LW; ++i)
-      if (lr + RPP * i < BN) *reinterpret_cast<float4*>(&Ws[(lr + RPP * i) * LDSW + lc]) = rw[i];
-    __syncthreads();
-    if (k0 + BK < K) gload(k0 + BK);                   // prefetch next tile under the MFMAs
+      if (lr + RPP * i < BN) *reinterpret_cast<float4*>(&Ws[buf][(lr + RPP * i) * LDSW + lc]) = rw[i];
+  };
+  auto mma_tile = [&](int buf) {
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 8) {
       float4 b4[NT], a4[MT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b4[j] = *reinterpret_cast<const float4*>(&Ws[((wn * NT + j) * 32 + li) * LDSW + kk + lh * 4]);
+      for (int j = 0; j < NT; ++j) b4[j] = *reinterpret_cast<const float4*>(&Ws[buf][((wn * NT + j) * 32 + li_) * LDSW + kk + lh_ * 4]);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a4[i] = *reinterpret_cast<const float4*>(&As[((wm * MT + i) * 32 + li) * LDSW + kk + lh * 4]);
+      for (int i = 0; i < MT; ++i) a4[i] = *reinterpret_cast<const float4*>(&As[buf][((wm * MT + i) * 32 + li_) * LDSW + kk + lh_ * 4]);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -113,8 +118,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(const ssrhip_gemm_args a0) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
     }
+  };
+  gload(0);
+  if (NBUF == 2) {
+    lds_store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += BK, buf ^= 1) {
+      const bool more = k0 + BK < K;
+      if (more) gload(k0 + BK);                        // in flight during this tile's MFMAs
+      mma_tile(buf);
+      if (more) lds_store(buf ^ 1);                    // the other buffer: its last readers passed the previous barrier
+      __syncthreads();
+    }
+  } else {
+    for (int k0 = 0; k0 < K; k0 += BK) {
+      __syncthreads();                                 // previous tile fully consumed
+      lds_store(0);
+      __syncthreads();
+      if (k0 + BK < K) gload(k0 + BK);                 // prefetch next tile under the MFMAs
+      mma_tile(0);
+    }
   }
   // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int li = li_, lh = lh_;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + (wn * NT + j) * 32 + li;
