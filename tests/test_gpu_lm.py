@@ -392,3 +392,31 @@ def test_prefill_kv_cache_equals_reference_present(golden_dir, name):
         worst = max(worst, float((got - want).abs().max()))
         torch.testing.assert_close(got, want, rtol=0, atol=2e-5)
     print(f"{name}: prefill K/V max |diff| vs reference present = {worst:.2e}")
+
+
+@pytest.mark.parametrize("greedy", [True, False])
+def test_sixteen_rows_sixteen_heads_full_generation_equals_batch1(greedy):
+    """The whole 16-row decode path end to end on a model wide enough to take it: d_model 1024 with 16 heads => 16 rows x 16 heads
+    = 256 (row, head) pairs = the fused `attn_rows` kernel, the rows-per-workgroup matrix-core GEMVs with streaming-order weights
+    (incl. the k-step-pair kernels for out-proj / FFN2 with K = 4096 streamed) and the page allocator under growth — 8 utterances of
+    different lengths x CFG, run to completion (~100 steps each, several KV pages); every utterance must equal its batch-1 run
+    (VALU GEMV + split attention) seeded seed + i."""
+    args = W.lm_args_tiny(d_model=1024, nhead=16, layers=2, vocab=64)
+    m = _model(args, 52)
+    g = torch.Generator().manual_seed(12)
+    utts = []
+    for (L, T) in [(12, 130), (9, 20), (14, 140), (10, 60), (13, 125), (8, 30), (11, 100), (12, 127)]:
+        utts.append(dict(x=torch.randint(0, 30, (1, L), generator=g), y=torch.randint(0, 64, (1, T, 4), generator=g),
+                         mask_interval=torch.LongTensor([[[T, T]]])))
+    utts[3]["mask_interval"] = torch.LongTensor([[[20, 31]]])
+    kw = dict(top_k=1, top_p=1.0) if greedy else dict(top_k=12, top_p=0.9)
+    kw.update(temperature=1.0, stop_repetition=2, silence_tokens=[3, 7, 11], cfg_coef=1.5, cfg_stride=2, aug_text=True)
+    batch = m.inference_batch(utts, seed=300, **kw)
+    eng = next(iter(m._engines.values()))
+    assert eng.B == 16 and eng.B * args.nhead >= 192
+    for i, u in enumerate(utts):
+        torch.manual_seed(300 + i)
+        L = u["x"].shape[1]
+        one = m.inference(u["x"].cuda(), torch.LongTensor([L]), u["x"].cuda(), torch.LongTensor([L]), u["y"].cuda(), u["y"].cuda(),
+                          u["mask_interval"].cuda(), kvcache=1, **kw)
+        assert torch.equal(batch[i][0], one[0]) and torch.equal(batch[i][1], one[1]) and batch[i][2] == one[2], i
