@@ -173,6 +173,15 @@ class WMEncodecModel:
         # Measured at 32 clips x 30 s (encode / decode ms): {64}: 86.9 / 88.8; {64,128}: 86.4 / 87.7 and 1.9 GB less memory;
         # adding 256 or 512 (short time axes, wide weights): 88.3 / 89.1-90.5 — the chained kernel's LDS footprint leaves one
         # workgroup per CU there and loses to two ordinary GEMM launches. So 64 and 128 are fused, 256 / 512 stay two GEMMs.
+        # Batch lanes: the items of a batch are independent, so a batch can be cut into `lanes` groups that run one after the other
+        # in host order on their own HIP streams: peak memory falls with the group size (256 clips x 30 s: 81 GB in one lane, 50 GB in
+        # two, 34 GB in four) at 2-4 % of the throughput. It was built hoping that one group's LSTM (a latency-bound launch per time
+        # step) would hide under the other group's convolutions; measured, the step launches queue behind the convolutions'
+        # workgroups instead (32 clips: 85 -> 94 ms with two lanes, 122 ms with high-priority LSTM streams), so the default is ONE
+        # lane and this is a memory knob (SSRHIP_CODEC_LANES, at least `lane_min_items` items per lane).
+        self.lanes = int(os.environ.get("SSRHIP_CODEC_LANES", "1"))
+        self.lane_min_items = int(os.environ.get("SSRHIP_CODEC_LANE_MIN", "8"))
+        self._lane_streams, self._side_streams, self._keep = [], {}, {}
         env = os.environ.get("SSRHIP_RESBLOCK_FUSE")
         self.fuse_channels = tuple(int(v) for v in env.split(",") if v) if env is not None else (64, 128)
         sd = {k: v.detach().to(torch.float32).cpu() for k, v in state_dict.items()}
@@ -329,7 +338,6 @@ class WMEncodecModel:
             main = torch.cuda.current_stream(dev)
             side = self._side_stream()
             in_gemm(0, 0, T)
-            ev_done = []
             for t0 in range(0, T, self.LSTM_CHUNK):
                 t1 = min(t0 + self.LSTM_CHUNK, T)
                 steps(0, t0, t1)
@@ -339,7 +347,6 @@ class WMEncodecModel:
                     side.wait_event(ev)
                     in_gemm(1, t0, t1)
                     steps(1, t0, t1)
-                ev_done.append(ev)
             fin = torch.cuda.Event()
             fin.record(side)
             main.wait_event(fin)
@@ -349,13 +356,57 @@ class WMEncodecModel:
                 steps(l, 0, T)
         out = outs[-1]
         self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
-        self._keep = (gins, hbufs, cbufs, outs)
+        self._keep[torch.cuda.current_stream(dev).cuda_stream] = (gins, hbufs, cbufs, outs)
         return out
 
     def _side_stream(self):
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(self.device)
-        return self._side
+        """The second stream of the LSTM layer pipeline: one per stream the codec is called on (every batch lane has its own)."""
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        if key not in self._side_streams:
+            self._side_streams[key] = torch.cuda.Stream(self.device)
+        return self._side_streams[key]
+
+    def _lane_cuts(self, B: int):
+        n = min(self.lanes, B // max(self.lane_min_items, 1))
+        if n <= 1:
+            return None
+        edges = [B * i // n for i in range(n + 1)]
+        return list(zip(edges[:-1], edges[1:]))
+
+    def _in_lanes(self, B: int, body):
+        """Run `body(lo, hi) -> tuple of tensors` for the batch lanes [lo, hi), each lane on its own stream, and join them on the
+        calling stream. With one lane `body(0, B)` runs on the calling stream itself. Returns the list of per-lane results."""
+        cuts = self._lane_cuts(B)
+        if cuts is None:
+            return [body(0, B)]
+        dev = self.device
+        main = torch.cuda.current_stream(dev)
+        while len(self._lane_streams) < len(cuts):
+            self._lane_streams.append(torch.cuda.Stream(dev))
+        start = torch.cuda.Event()
+        start.record(main)
+        results, done = [], []
+        for (lo, hi), st in zip(cuts, self._lane_streams):
+            with torch.cuda.stream(st):
+                st.wait_event(start)
+                r = body(lo, hi)
+                for t in r:
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(main)                          # allocated in the lane's pool, consumed on the caller's stream
+                ev = torch.cuda.Event()
+                ev.record(st)
+            results.append(r)
+            done.append(ev)
+        for ev in done:
+            main.wait_event(ev)
+        return results
+
+    @staticmethod
+    def _join(parts, i):
+        vals = [p[i] for p in parts]
+        if vals[0] is None:
+            return None
+        return vals[0] if len(vals) == 1 else torch.cat(vals, dim=0)
 
     def _run(self, nodes, x: TM, after=None) -> TM:
         """Run consecutive nodes; `after` = the node that will consume the result (decides its halo)."""
@@ -386,20 +437,30 @@ class WMEncodecModel:
     def encode(self, x: torch.Tensor):
         """-> (codes int64 [B,K,T'], scale=None (renormalize False), emb f32 [B,D,T'])."""
         assert x.dim() == 3
-        inp = self._input_tm(x, self.encoder.nodes[0])
-        emb = self._run(self.encoder.nodes, inp)
-        B, T, D = emb.B, emb.T, emb.C
-        codes = torch.empty(B, self.cfg.n_q, T, dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.ssrhip_rvq_encode(emb.interior, self.codebooks.data_ptr(), self.e2.data_ptr(), codes.data_ptr(), B, T, D,
-                                              self.cfg.n_q, self.cfg.bins, emb.bstride, self._s()), "ssrhip_rvq_encode")
-        return codes.to(torch.int64), None, emb.interior_view().transpose(1, 2).contiguous()
 
-    def _dequant(self, codes: torch.Tensor, nxt) -> TM:
+        def body(lo, hi):
+            inp = self._input_tm(x[lo:hi], self.encoder.nodes[0])
+            emb = self._run(self.encoder.nodes, inp)
+            B, T, D = emb.B, emb.T, emb.C
+            codes = torch.empty(B, self.cfg.n_q, T, dtype=torch.int32, device=self.device)
+            _lib.check(self.lib.ssrhip_rvq_encode(emb.interior, self.codebooks.data_ptr(), self.e2.data_ptr(), codes.data_ptr(), B, T, D,
+                                                  self.cfg.n_q, self.cfg.bins, emb.bstride, self._s()), "ssrhip_rvq_encode")
+            return codes.to(torch.int64), emb.interior_view().transpose(1, 2).contiguous()
+
+        parts = self._in_lanes(x.shape[0], body)
+        return self._join(parts, 0), None, self._join(parts, 1)
+
+    def _codes32(self, codes: torch.Tensor) -> torch.Tensor:
+        """Code ids on the device as int32, range-checked once for the whole batch (before it is cut into lanes)."""
         assert codes.dim() == 3
-        B, K, T = codes.shape
         c32 = codes.to(self.device, torch.int32).contiguous()
-        if T > 0 and (int(c32.max()) >= self.cfg.bins or int(c32.min()) < 0):
+        if c32.numel() > 0 and (int(c32.max()) >= self.cfg.bins or int(c32.min()) < 0):
             raise IndexError("index out of range in self")            # what F.embedding raises in the reference (core_vq.py:175)
+        return c32
+
+    def _dequant(self, c32: torch.Tensor, nxt) -> TM:
+        B, K, T = c32.shape
+        c32 = c32.contiguous()
         out = self._alloc_for(B, T, self.cfg.dimension, nxt)
         _lib.check(self.lib.ssrhip_rvq_decode(c32.data_ptr(), self.codebooks.data_ptr(), out.interior, B, T, self.cfg.dimension, K,
                                               self.cfg.bins, out.bstride, self._s()), "ssrhip_rvq_decode")
@@ -416,14 +477,18 @@ class WMEncodecModel:
 
     @torch.no_grad()
     def decode_latent(self, codes: torch.Tensor) -> torch.Tensor:
-        return self._dequant(codes, None).interior_view().transpose(1, 2).contiguous()
+        return self._dequant(self._codes32(codes), None).interior_view().transpose(1, 2).contiguous()
 
     @torch.no_grad()
     def decode(self, codes: torch.Tensor, scale=None) -> torch.Tensor:
         assert scale is None, "renormalize=False codec: scale must be None (wmencodec.py:199-203)"
-        z = self._dequant(codes, self.decoder.nodes[0])
-        y = self._run(self.decoder.nodes, z)
-        return self._channel_major(y)
+        c32 = self._codes32(codes)
+
+        def body(lo, hi):
+            z = self._dequant(c32[lo:hi], self.decoder.nodes[0])
+            return (self._channel_major(self._run(self.decoder.nodes, z)),)
+
+        return self._join(self._in_lanes(c32.shape[0], body), 0)
 
     def _concat_proj(self, j: int, skip: TM, labels32: torch.Tensor, rep: int, x: TM, nxt) -> TM:
         """wm_proj_j(ELU(cat(skip, wm_embed(labels upsampled)))) + x   (seanet.py:577-591) without building the concatenation:
@@ -444,34 +509,45 @@ class WMEncodecModel:
         assert scale is None and self.has_wm
         r = list(self.cfg.ratios)
         assert len(r) == 4, "the watermark decoder's slicing (seanet.py:560-591) is written for 4 ratios"
-        lab = labels.to(self.device, torch.int32).contiguous()
+        lab_all = labels.to(self.device, torch.int32).contiguous()
+        c32 = self._codes32(codes)
         dec, senc = self.wmdecoder, self.skip_encoder
         cuts = [(0, 4), (4, 7), (7, 10), (10, None)]
         dn = [dec.slice_nodes(lo, hi) for lo, hi in cuts]
-        # skip features at 4 scales; every skip is consumed by a k=1 conv => no halo
-        z = self._run(senc.slice_nodes(0, 2), self._input_tm(wavform, senc.nodes[0]), after=senc.slice_nodes(2, 5)[0])
-        sk = []
-        for lo, hi in [(2, 5), (5, 8), (8, 11), (11, None)]:
-            nxt_nodes = senc.slice_nodes(hi, None) if hi is not None else []
-            z = self._run(senc.slice_nodes(lo, hi), z, after=(nxt_nodes[0] if nxt_nodes else None))
-            sk.append(z)
         reps = [r[0] * r[1] * r[2], r[0] * r[1], r[0], 1]
-        x = self._dequant(codes, None)
-        for j in range(4):
-            skip, rep = sk[3 - j], reps[3 - j]
-            out = self._concat_proj(j, skip, lab, rep, x, dn[j][0])
-            x = self._run(dn[j], out, after=None)
-        wav = self._channel_major(x)
-        if not with_mark:
-            return wav, None
-        m = self._run(self.wm_encoder.nodes, self._input_tm(wav, self.wm_encoder.nodes[0]), after=None)
-        mk = self._conv(self.wm_predictor, m, None)
-        return wav, mk.interior_view().contiguous()
+
+        def body(b0, b1):
+            lab = lab_all[b0:b1].contiguous()
+            # skip features at 4 scales; every skip is consumed by a k=1 conv => no halo
+            z = self._run(senc.slice_nodes(0, 2), self._input_tm(wavform[b0:b1], senc.nodes[0]), after=senc.slice_nodes(2, 5)[0])
+            sk = []
+            for lo, hi in [(2, 5), (5, 8), (8, 11), (11, None)]:
+                nxt_nodes = senc.slice_nodes(hi, None) if hi is not None else []
+                z = self._run(senc.slice_nodes(lo, hi), z, after=(nxt_nodes[0] if nxt_nodes else None))
+                sk.append(z)
+            x = self._dequant(c32[b0:b1], None)
+            for j in range(4):
+                skip, rep = sk[3 - j], reps[3 - j]
+                out = self._concat_proj(j, skip, lab, rep, x, dn[j][0])
+                x = self._run(dn[j], out, after=None)
+            wav = self._channel_major(x)
+            if not with_mark:
+                return wav, None
+            m = self._run(self.wm_encoder.nodes, self._input_tm(wav, self.wm_encoder.nodes[0]), after=None)
+            mk = self._conv(self.wm_predictor, m, None)
+            return wav, mk.interior_view().contiguous()
+
+        parts = self._in_lanes(c32.shape[0], body)
+        return self._join(parts, 0), self._join(parts, 1)
 
     @torch.no_grad()
     def detect_watermark(self, x: torch.Tensor) -> torch.Tensor:
         """wmencodec.py:377-382, including its argmax over the LAST dim of [B,2,T'] (time)."""
         assert x.dim() == 3
-        m = self._run(self.wm_encoder.nodes, self._input_tm(x, self.wm_encoder.nodes[0]), after=None)
-        mk = self._conv(self.wm_predictor, m, None).interior_view().transpose(1, 2)      # [B,2,T']
-        return torch.argmax(mk.squeeze(-1), dim=-1)
+
+        def body(lo, hi):
+            m = self._run(self.wm_encoder.nodes, self._input_tm(x[lo:hi], self.wm_encoder.nodes[0]), after=None)
+            mk = self._conv(self.wm_predictor, m, None).interior_view().transpose(1, 2)      # [B,2,T']
+            return (torch.argmax(mk.squeeze(-1), dim=-1),)
+
+        return self._join(self._in_lanes(x.shape[0], body), 0)

@@ -101,6 +101,7 @@ def test_lstm_mfma_step_full_width_two_batch_tiles():
     m = WMEncodecModel(cfg, sd, "cuda")
     g = torch.Generator().manual_seed(1)
     wav = (torch.randn(20, 1, cfg.hop * 12 + 17, generator=g) * 0.2).cuda()
+    m.lanes = 1                                                     # the whole batch in one launch chain: two batch tiles
     c20, _, e20 = m.encode(wav)
     for lo in (0, 15, 18):
         c2, _, e2 = m.encode(wav[lo:lo + 2])
@@ -120,12 +121,53 @@ def test_lstm_wide_step_kernel_large_batch(B):
     m = WMEncodecModel(cfg, sd, "cuda")
     g = torch.Generator().manual_seed(6)
     wav = (torch.randn(B, 1, cfg.hop * 9 + 33, generator=g) * 0.2).cuda()
+    m.lanes = 1                                                     # one lane, or the halves would fall below the wide kernel's 8 tiles
     cB, _, eB = m.encode(wav)
     dB = m.decode(cB)
     for lo in (0, 47, B - 2):
         c2, _, e2 = m.encode(wav[lo:lo + 2])
         torch.testing.assert_close(eB[lo:lo + 2], e2, rtol=0, atol=2e-5)
         torch.testing.assert_close(dB[lo:lo + 2], m.decode(cB[lo:lo + 2]), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("lanes,B", [(2, 20), (3, 27), (2, 17)])
+def test_batch_lanes_equal_one_lane(lanes, B):
+    """A batch is cut into lanes that run on their own streams (one lane's LSTM overlaps the other's convolutions). Every public
+    entry point must return what the single-lane run returns: same kernels per item, only the launch grouping differs."""
+    cfg = W.codec_config_full()
+    sd = W.codec_state_dict(cfg, seed=21)
+    m = WMEncodecModel(cfg, sd, "cuda")
+    g = torch.Generator().manual_seed(9)
+    n = cfg.hop * 70 + 11                                           # 71 frames: the two-stream LSTM layer pipeline is on (chunks of 64)
+    wav = (torch.randn(B, 1, n, generator=g) * 0.2).cuda()
+    labels = torch.randint(0, 2, (B, 71), generator=g).cuda()
+
+    def run(use_codes=None):
+        codes, _, emb = m.encode(wav)
+        dec_in = codes if use_codes is None else use_codes          # a flipped near-tie code must not leak into the decoder checks
+        dec = m.decode(dec_in)
+        track = torch.nn.functional.pad(wav, (0, 71 * cfg.hop - n))
+        wm, mark = m.wmdecode(dec_in, labels, track)
+        det = m.detect_watermark(wm)
+        torch.cuda.synchronize()
+        return codes, emb, dec, wm, mark, det
+
+    m.lanes, m.lane_min_items = 1, 8
+    one = run()
+    m.lanes = lanes
+    assert len(m._lane_cuts(B)) == lanes
+    for rep in range(2):                                            # twice: the second run reuses the lanes' cached memory blocks
+        many = run(one[0])
+        for a, b in zip(one, many):
+            assert a.shape == b.shape and a.dtype == b.dtype
+            if a.dtype.is_floating_point:
+                torch.testing.assert_close(a, b, rtol=0, atol=2e-5)
+            else:
+                assert (a != b).float().mean() < 0.002              # near-tie RVQ picks may flip with a different LSTM batch tile
+    with pytest.raises(IndexError):
+        bad = one[0].clone()
+        bad[B - 1, 0, 0] = cfg.bins
+        m.decode(bad)
 
 
 def test_rvq_encode_mfma_equals_scalar_kernel(monkeypatch):
@@ -179,6 +221,7 @@ def test_large_batch_kernels_match_the_oracle_directly(B, pad_mode):
     cfg = dataclasses.replace(W.codec_config_full(), pad_mode=pad_mode)
     sd = W.codec_state_dict(cfg, seed=13)
     m = WMEncodecModel(cfg, sd, "cuda")
+    m.lanes = 1                                                     # B=20 in ONE lane: two batch tiles, the second ragged
     g = torch.Generator().manual_seed(5)
     wav = torch.randn(B, 1, cfg.hop * 11 + 129, generator=g) * 0.2
     codes, _, emb = m.encode(wav.cuda())
@@ -247,7 +290,7 @@ def test_every_seanet_layer_matches_the_reference(golden_dir, name):
                 if pfx == "enc_":
                     x = m._input_tm(torch.from_numpy(g["wav"]).cuda(), node)
                 else:
-                    x = m._dequant(torch.from_numpy(g["codes"]).cuda(), node)
+                    x = m._dequant(m._codes32(torch.from_numpy(g["codes"])), node)
             else:
                 x = as_tm(g[f"{pfx}{nodes[idx - 1][3]}"], node)          # the reference's output of the previous node
             y = m._run([node], x, after=nxt)
