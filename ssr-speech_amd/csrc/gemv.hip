@@ -731,6 +731,260 @@ void launch_b(const GemvK& p, dim3 grid, size_t smem, hipStream_t s) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Segment kernel (round 2, second half): the same fused GEMV organised the way `tools/overlap_bench xmodes/sweep` found
+// fastest for a DEPENDENT chain of launches on this GPU:
+//   * 512-thread workgroups, 2 per CU, each owning a CONTIGUOUS block of rows (balanced split of N over the grid);
+//   * the work unit is a (row, 1024-float segment of K): 4 x global_load_dwordx4 per lane; a wave keeps two units = 8 loads
+//     in flight (the row-per-wave kernel above keeps 16 in 12 waves per CU: 192 KB per CU in flight where ~60 KB cover the
+//     HBM latency-bandwidth product; the surplus only lengthens the ramp: 15.7 MB took 6.5 us with 16 in flight, 4.8 with 4);
+//   * a wave always works on the same segment (8 waves, S = K/1024 in {1,2,4,8}), so its x slice is B x 4 float4 registers
+//     (was B x 8) and every workgroup fetches each x element once per pair of waves instead of once per wave;
+//   * per unit a wave all-reduce, lanes 0..B-1 park the partial in LDS; after ONE barrier threads (row, b) add the S segments
+//     in k order and apply bias / activation / residual / KV append (operands fetched at kernel entry);
+//   * LayerNorm prologue without staging x: a wave normalises its own segment in registers — per-segment two-pass statistics,
+//     exchanged through LDS (one barrier), merged exactly (Chan) — gamma / beta folded into W / bias by the host;
+//   * split-KV combine prologue: one float4 column per thread and row (512 threads x 4 = K = 2048), 6 pages prefetched;
+//   * 16 waves per CU (two workgroups): 128 VGPRs per lane (HIP's second launch-bound is waves per SIMD).
+constexpr int SEG = 1024;            // floats per unit
+constexpr int SEG_TH = 512, SEG_NW = 8;
+template <int B> struct SegCS { static constexpr int v = (B <= 2) ? 6 : 2; };   // pages prefetched by the combine prologue (register budget: 128; even)
+
+template <int B, int PRO>
+__global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int SEG_CS = SegCS<B>::v;
+  const ssrhip_gemv_args& a = p.a;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int g = blockIdx.y, G = p.groups_x;
+  const int K = a.K, N = a.N, S = p.nslice;                        // S segments per row (power of two <= 8)
+  const int r0 = (int)(((long)N * blockIdx.x) / G), r1 = (int)(((long)N * (blockIdx.x + 1)) / G);
+  const int nrows = r1 - r0, nu = nrows * S;                       // host guarantees N >= G: nrows >= 1
+  const int seg = wave & (S - 1), sh = p.slice_len;                // sh = log2(S)
+  float* part = smem;                                              // [p.nch rows max][S][B]
+  float* aux = smem + p.nch * S * B;                               // prologue scratch
+  const float* Wg = a.W + ((size_t)g * N + r0) * K + seg * SEG + lane * 4;
+
+  // ---- 1. activations (L2) — issued first, they return first
+  float4 xr[B][4];
+  float4 co[(PRO == SSRHIP_PRO_ATTN_COMBINE) ? B : 1][SEG_CS];
+  float4 cml[SEG_CS / 2];
+  int ns[(PRO == SSRHIP_PRO_ATTN_COMBINE) ? B : 1];
+  if constexpr (PRO != SSRHIP_PRO_ATTN_COMBINE) {
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[b][i] = ld4(a.x + (size_t)b * a.x_stride + (size_t)g * K + seg * SEG + (i * 64 + lane) * 4);
+  } else {                                                         // K == 2048: thread t owns float4 column t*4 of every row
+    const int hd = p.hd, H = K / hd, MS = a.max_splits;
+#pragma unroll
+    for (int b = 0; b < B; ++b) ns[b] = (a.row_len[b] + SSRHIP_PAGE - 1) / SSRHIP_PAGE;
+    const int tt = t % (B * H);                                    // every thread loads an (m,l) block; only t < B*H uses it
+    const float* ml = a.part_ml + (size_t)tt * MS * 2;
+#pragma unroll
+    for (int i = 0; i < SEG_CS / 2; ++i) cml[i] = ld4(ml + 4 * min(i, (MS * 2 - 4) / 4));
+    const int e = t * 4, h = e / hd, d = e % hd;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const float* po = a.part_o + (((size_t)b * H + h) * MS) * hd + d;
+#pragma unroll
+      for (int s2 = 0; s2 < SEG_CS; ++s2) co[b][s2] = ld4(po + (size_t)min(s2, ns[b] - 1) * hd);
+    }
+  }
+  // ---- 2. the wave's first unit, unconditional (clamped to the workgroup's last unit). FOUR loads in flight per lane, 16 waves per
+  // CU: 64 KB per CU cover the HBM latency-bandwidth product; `tools/overlap_bench orders`: 8 in flight cost +1.5 us per launch.
+  float4 wa[4];
+  int ua = wave;
+  {
+    const int ca = min(ua, nu - 1) >> sh;                           // local row (the segment is the wave's own)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wa[i] = ld_nt(Wg + (size_t)ca * K + i * 256);
+  }
+  // ---- epilogue operands of the (row, b) this thread finalises
+  RowEpi efin = {0.f, 0.f};
+  const int bfin = t % B, rfin = min(t / B, nrows - 1), nfin = r0 + rfin;
+  efin.bias = a.bias ? a.bias[(size_t)g * N + nfin] : 0.f;
+  efin.resid = (a.epi == SSRHIP_EPI_RESIDUAL) ? a.y[(size_t)bfin * a.y_stride + (size_t)g * N + nfin] : 0.f;
+  float* kvb[2] = {nullptr, nullptr};
+  if (a.epi == SSRHIP_EPI_QKV_APPEND) {                            // scalar-path address chain (kv_pos -> page table -> pool)
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int pos = a.kv_pos[b];
+      float* kb = kv_addr(a.kv, b, a.layer, 0, 0, pos);
+      float* vb = kv_addr(a.kv, b, a.layer, 1, 0, pos);
+      if (bfin == b) { kvb[0] = kb; kvb[1] = vb; }
+    }
+  }
+  // ---- 3. prologue math, under the latency of the first units
+  if constexpr (PRO == SSRHIP_PRO_LAYERNORM) {
+    float m[B], q[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      float s0 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s0 += (xr[b][i].x + xr[b][i].y) + (xr[b][i].z + xr[b][i].w);
+      m[b] = wave_sum(s0) * (1.0f / SEG);
+      float q0 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dx = xr[b][i].x - m[b], dy = xr[b][i].y - m[b], dz = xr[b][i].z - m[b], dw = xr[b][i].w - m[b];
+        q0 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+      q[b] = wave_sum(q0);
+      if (wave < S && lane == 0) { aux[(wave * B + b) * 2] = m[b]; aux[(wave * B + b) * 2 + 1] = q[b]; }   // wave w < S holds segment w
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      float mean = 0.f, M2 = 0.f, dev = 0.f;
+      for (int s2 = 0; s2 < S; ++s2) mean += aux[(s2 * B + b) * 2];
+      mean /= (float)S;
+      for (int s2 = 0; s2 < S; ++s2) { const float dm = aux[(s2 * B + b) * 2] - mean; M2 += aux[(s2 * B + b) * 2 + 1]; dev = fmaf(dm, dm, dev); }
+      const float var = (M2 + (float)SEG * dev) / (float)K;
+      const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        xr[b][i] = make_float4((xr[b][i].x - mean) * rstd, (xr[b][i].y - mean) * rstd, (xr[b][i].z - mean) * rstd, (xr[b][i].w - mean) * rstd);
+    }
+  }
+  if constexpr (PRO == SSRHIP_PRO_ATTN_COMBINE) {
+    const int hd = p.hd, H = K / hd, MS = a.max_splits;
+    float* xs = aux;                                               // [B][K]
+    float* wtab = aux + B * K;                                     // [B*H][MS]
+    if (t < B * H) {                                               // softmax-merge weights of (row, head) = t
+      const int n = ns[t / H];
+      const float* ml = a.part_ml + (size_t)t * MS * 2;
+      float M = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < SEG_CS / 2; ++i) { if (2 * i < n) M = fmaxf(M, cml[i].x); if (2 * i + 1 < n) M = fmaxf(M, cml[i].z); }
+      for (int s2 = SEG_CS; s2 < n; ++s2) M = fmaxf(M, ml[2 * s2]);
+      float den = 0.f;
+#pragma unroll
+      for (int i = 0; i < SEG_CS / 2; ++i) {
+        if (2 * i < n) den = fmaf(expf(cml[i].x - M), cml[i].y, den);
+        if (2 * i + 1 < n) den = fmaf(expf(cml[i].z - M), cml[i].w, den);
+      }
+      for (int s2 = SEG_CS; s2 < n; ++s2) den = fmaf(expf(ml[2 * s2] - M), ml[2 * s2 + 1], den);
+      const float inv = 1.0f / den;
+#pragma unroll
+      for (int i = 0; i < SEG_CS / 2; ++i) {
+        if (2 * i < n) wtab[t * MS + 2 * i] = expf(cml[i].x - M) * inv;
+        if (2 * i + 1 < n) wtab[t * MS + 2 * i + 1] = expf(cml[i].z - M) * inv;
+      }
+      for (int s2 = SEG_CS; s2 < n; ++s2) wtab[t * MS + s2] = expf(ml[2 * s2] - M) * inv;
+    }
+    __syncthreads();
+    const int e = t * 4, h = e / hd, d = e % hd;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const float* w = wtab + (b * H + h) * MS;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int s2 = 0; s2 < SEG_CS; ++s2) {
+        const float ws = (s2 < ns[b]) ? w[s2] : 0.f;
+        acc.x = fmaf(ws, co[b][s2].x, acc.x);
+        acc.y = fmaf(ws, co[b][s2].y, acc.y);
+        acc.z = fmaf(ws, co[b][s2].z, acc.z);
+        acc.w = fmaf(ws, co[b][s2].w, acc.w);
+      }
+      const float* po = a.part_o + (((size_t)b * H + h) * MS) * hd + d;
+      for (int s2 = SEG_CS; s2 < ns[b]; ++s2) {                    // contexts beyond the prefetched pages: the rest, loaded late
+        const float ws = w[s2];
+        const float4 o = ld4(po + (size_t)s2 * hd);
+        acc.x = fmaf(ws, o.x, acc.x);
+        acc.y = fmaf(ws, o.y, acc.y);
+        acc.z = fmaf(ws, o.z, acc.z);
+        acc.w = fmaf(ws, o.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(xs + b * K + e) = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[b][i] = *reinterpret_cast<const float4*>(xs + b * K + seg * SEG + (i * 64 + lane) * 4);
+  }
+  // ---- 4. stream the units: every 16-byte piece is re-requested for the next unit as soon as it has been used
+  auto reduce_park = [&](float (&acc)[B][2], int u) {
+    float mine = 0.f;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const float sum = wave_sum(acc[b][0] + acc[b][1]);
+      if (lane == b) mine = sum;
+    }
+    if (lane < B) part[u * B + lane] = mine;                       // u = local_row * S + seg
+  };
+  if (ua < nu) {
+    while (ua + SEG_NW < nu) {                                      // not the wave's last unit: re-request in place, UNCONDITIONALLY
+      const int un = ua + SEG_NW;                                   // (a conditional re-request makes hipcc drain the queue every unit)
+      const float* wn = Wg + (size_t)(un >> sh) * K;
+      float acc[B][2];
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[b][0] = acc[b][1] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[b][i & 1] = dot4(wa[i], xr[b][i], acc[b][i & 1]);
+        __builtin_amdgcn_sched_barrier(0);                          // use, THEN overwrite in place: no second register set, no copies
+        wa[i] = ld_nt(wn + i * 256);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      reduce_park(acc, ua);
+      ua = un;
+    }
+    float acc[B][2];                                                // the last unit: nothing left to request
+#pragma unroll
+    for (int b = 0; b < B; ++b) acc[b][0] = acc[b][1] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[b][i & 1] = dot4(wa[i], xr[b][i], acc[b][i & 1]);
+    reduce_park(acc, ua);
+  }
+  __syncthreads();
+  if (t < nrows * B) {
+    float v = 0.f;
+    for (int s2 = 0; s2 < S; ++s2) v += part[(rfin * S + s2) * B + bfin];
+    finalize(p, g, nfin, bfin, v, efin, kvb);
+  }
+}
+
+int g_seg_mode = -1;   // SSRHIP_GEMV_SEG: 1 (default) = take the segment kernel where its conditions hold, 0 = never
+
+// true if the segment kernel was launched
+template <int B>
+bool try_seg(const ssrhip_gemv_args* a, int num_cu, hipStream_t s) {
+  if (a->K % SEG != 0) return false;
+  const int S = a->K / SEG;
+  if (S != 1 && S != 2 && S != 4 && S != 8) return false;
+  if (a->pro == SSRHIP_PRO_LAYERNORM && a->ln_w != nullptr) return false;
+  const int H = a->kv.head_dim > 0 ? a->K / a->kv.head_dim : 0;
+  if (a->pro == SSRHIP_PRO_ATTN_COMBINE && (a->K != 2048 || a->max_splits < 2 || a->groups != 1 || B * H > SEG_TH || a->kv.head_dim % 4 != 0)) return false;
+  int G = (2 * num_cu) / a->groups;                                // two resident workgroups per CU over all groups
+  if (G > a->N) G = a->N;                                          // fewer rows than workgroups: one row each
+  if (G < 1) G = 1;
+  const int rows_max = (a->N + G - 1) / G;
+  if (rows_max * B > SEG_TH) return false;
+  GemvK p;
+  p.a = *a;
+  p.nslice = S;
+  p.slice_len = (S == 1) ? 0 : (S == 2) ? 1 : (S == 4) ? 2 : 3;   // log2(S)
+  p.nch = rows_max;
+  p.groups_x = G;
+  p.hd = (a->kv.head_dim > 0) ? a->kv.head_dim : 1;
+  size_t smem = (size_t)rows_max * S * B * sizeof(float);
+  if (a->pro == SSRHIP_PRO_LAYERNORM) smem += (size_t)S * B * 2 * sizeof(float);
+  if (a->pro == SSRHIP_PRO_ATTN_COMBINE) smem += ((size_t)B * a->K + (size_t)B * H * a->max_splits) * sizeof(float);
+  smem = (smem + 15) / 16 * 16;
+  dim3 grid(G, a->groups);
+  switch (a->pro) {
+    case SSRHIP_PRO_LAYERNORM: hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_LAYERNORM>), grid, dim3(SEG_TH), smem, s, p); break;
+    case SSRHIP_PRO_ATTN_COMBINE: hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_ATTN_COMBINE>), grid, dim3(SEG_TH), smem, s, p); break;
+    default: hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_NONE>), grid, dim3(SEG_TH), smem, s, p); break;
+  }
+  return true;
+}
+
 int g_num_cu = 0;
 int g_blocks_per_cu = 3;   // A/B in the real (dependent-launch) decode step: 1 -> 1.536, 2 -> 1.109, 3 -> 1.065 ms/step. (Independent
                           // back-to-back launches, tools/gemv_bench.hip, prefer 2: 12.5 us vs 12.6 for 67 MB; the chain wants the faster ramp.)
@@ -754,12 +1008,38 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
     else g_num_cu = 256;
     if (const char* e = getenv("SSRHIP_GEMV_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 3) g_blocks_per_cu = v; }   // tuning knob
   }
+  if (a->pro != SSRHIP_PRO_NONE) {
+    SSR_REQUIRE(a->groups == 1 || a->pro == SSRHIP_PRO_LAYERNORM, "ssrhip_gemv: combine prologue needs groups==1");
+    if (a->pro == SSRHIP_PRO_LAYERNORM) SSR_REQUIRE(a->x && ((a->ln_w && a->ln_b) || (!a->ln_w && !a->ln_b)), "ssrhip_gemv: LayerNorm prologue needs x and either both or none of ln_w/ln_b");
+    if (a->pro == SSRHIP_PRO_ATTN_COMBINE) {
+      SSR_REQUIRE(a->part_o && a->part_ml && a->row_len && a->kv.head_dim > 0 && a->K % a->kv.head_dim == 0 && a->kv.head_dim % 4 == 0,
+                  "ssrhip_gemv: combine prologue needs part_o, part_ml, row_len, kv.head_dim");
+    }
+  } else {
+    SSR_REQUIRE(a->x, "ssrhip_gemv: x is null");
+  }
+  if (a->epi == SSRHIP_EPI_QKV_APPEND) {
+    SSR_REQUIRE(a->N == 3 * a->K && a->groups == 1 && a->kv.pool && a->kv.table && a->kv_pos && a->kv.head_dim > 0,
+                "ssrhip_gemv: QKV epilogue needs N==3K and a kv cache");
+  }
+  if (g_seg_mode < 0) { const char* e = getenv("SSRHIP_GEMV_SEG"); g_seg_mode = (e && e[0] == '0') ? 0 : 1; }
+  if (g_seg_mode) {
+    bool done = false;
+    switch (a->B) {
+      case 1: done = try_seg<1>(a, g_num_cu, (hipStream_t)stream); break;
+      case 2: done = try_seg<2>(a, g_num_cu, (hipStream_t)stream); break;
+      default: done = try_seg<4>(a, g_num_cu, (hipStream_t)stream); break;
+    }
+    if (done) { SSR_LAUNCH_CHECK(); return 0; }
+  }
   GemvK p;
   p.a = *a;
   p.nslice = a->K <= 2048 ? 1 : (a->K <= 4096 ? 2 : 4);
   p.slice_len = ((a->K + p.nslice - 1) / p.nslice + 3) / 4 * 4;
   p.nch = (p.slice_len + 255) / 256;
   SSR_REQUIRE(p.nch <= MAXCH, "ssrhip_gemv: slice too long");
+  SSR_REQUIRE(!(a->pro == SSRHIP_PRO_LAYERNORM && a->ln_w == nullptr && p.nslice != 1),
+              "ssrhip_gemv: the row-per-wave kernels take a folded LayerNorm (ln_w == NULL) only for K <= 2048 (the segment kernel covers K = 4096 / 8192)");
   const int n_rg = 4 / p.nslice;
   // resident grid: <= 3 workgroups per CU in total (over all groups); rows dealt round-robin to wave-groups
   int max_blocks_x = (g_blocks_per_cu * g_num_cu) / a->groups;

@@ -205,6 +205,119 @@ def test_gemv_mfma_grouped_heads_and_qkv_append(L):
     assert torch.equal(newpool[mask], pool[mask])
 
 
+
+# ------------------------------------------------------------------------------------------ 2-row segment kernel at the step's shapes
+@pytest.mark.parametrize("seg", ["1", "0"])
+@pytest.mark.parametrize("B", [1, 2, 4])
+@pytest.mark.parametrize("N,K,groups,pro,act,epi", [(6144, 2048, 1, 1, 0, 0), (8192, 2048, 1, 1, 1, 0), (2048, 8192, 1, 0, 0, 1), (4096, 2048, 1, 1, 2, 0),
+                                                     (2056, 1024, 4, 0, 0, 0), (2048, 2048, 1, 0, 0, 1), (1000, 4096, 1, 1, 0, 1), (515, 2048, 2, 0, 1, 0)])
+def test_gemv_step_shapes_both_kernels(L, monkeypatch, seg, B, N, K, groups, pro, act, epi):
+    """The six GEMV shapes of the 830M decode step (plus a ragged N and a K = 4096 one) through `ssrhip_gemv` with the segment kernel
+    (SSRHIP_GEMV_SEG=1, default) and with the row-per-wave kernels (=0), LayerNorm folded as the engine does (ln_w = NULL)."""
+    import subprocess, sys, os
+    if seg == "0" and pro == 1 and K > 2048:
+        pytest.skip("the row-per-wave kernels take a folded LayerNorm only up to K = 2048 (they refuse it; the segment kernel covers it)")
+    # the switch is read once per process: run the comparison in a child process
+    code = f"""
+import ctypes as C, math, sys, torch, torch.nn.functional as F
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import ssr_speech_amd
+from ssr_speech_amd import _lib
+L = _lib.lib()
+B, N, K, G, pro, act, epi = {B}, {N}, {K}, {groups}, {pro}, {act}, {epi}
+g = torch.Generator().manual_seed(B * 7 + N + K)
+Wt = torch.randn(G, N, K, generator=g) / math.sqrt(K)
+bias = torch.randn(G, N, generator=g)
+x = torch.randn(B, G, K, generator=g) * 1.5 + 0.3
+y0 = torch.randn(B, G, N, generator=g)
+xin = F.layer_norm(x, (K,), None, None, 1e-5) if pro == 1 else x
+ref = torch.stack([F.linear(xin[:, k].double(), Wt[k].double(), bias[k].double()) for k in range(G)], 1)
+ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+ref = (y0.double() + ref) if epi == 1 else ref
+dW, db, dx, dy = Wt.cuda(), bias.cuda(), x.cuda().contiguous(), y0.clone().cuda().contiguous()
+a = _lib.GemvArgs()
+a.W, a.bias, a.x, a.y = dW.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr()
+a.B, a.N, a.K, a.groups, a.x_stride, a.y_stride = B, N, K, G, G * K, G * N
+a.pro, a.act, a.epi, a.ln_eps = pro, act, epi, 1e-5
+_lib.check(L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()))
+torch.cuda.synchronize()
+err = float((dy.cpu().double() - ref).abs().max())
+print("ERR", err)
+"""
+    env = dict(os.environ, SSRHIP_GEMV_SEG=seg)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    err = float(out.stdout.strip().split("ERR")[-1])
+    assert err < 3e-5, err
+
+
+@pytest.mark.parametrize("B", [1, 2, 4])
+def test_gemv_seg_combine_and_qkv_append_at_2048(L, B):
+    """Segment kernel, the two launches with special plumbing at d_model = 2048 / 16 heads: (a) LayerNorm (folded) + QKV with the K/V
+    rows appended into the paged cache, (b) split-KV merge prologue (contexts of 1..8 pages: beyond the 6 prefetched ones) + residual."""
+    g = torch.Generator().manual_seed(40 + B)
+    D, H, hd, n_layer, max_pages, layer = 2048, 16, 128, 2, 8, 1
+    pool, table = _make_cache(B, max_pages, n_layer, H, hd, g)
+    # ---- (a)
+    Wt = torch.randn(3 * D, D, generator=g) / math.sqrt(D)
+    bias = torch.randn(3 * D, generator=g)
+    x = torch.randn(B, D, generator=g) * 1.3 + 0.2
+    pos = torch.tensor([130, 7, 1023, 512][:B], dtype=torch.int32)
+    ref = F.linear(F.layer_norm(x, (D,), None, None, 1e-5).double(), Wt.double(), bias.double()).float()
+    dpool, dtable, dW, db, dx, dpos = dev(pool), dev(table), dev(Wt), dev(bias), dev(x), dev(pos)
+    dq = torch.zeros(B, D, device="cuda")
+    a = _lib.GemvArgs()
+    a.W, a.bias, a.x, a.y = dW.data_ptr(), db.data_ptr(), dx.data_ptr(), dq.data_ptr()
+    a.B, a.N, a.K, a.groups, a.x_stride, a.y_stride = B, 3 * D, D, 1, D, D
+    a.pro, a.act, a.epi, a.ln_eps = _lib.PRO_LAYERNORM, 0, _lib.EPI_QKV_APPEND, 1e-5
+    a.kv = _lib.KV(dpool.data_ptr(), dtable.data_ptr(), max_pages, n_layer, H, hd)
+    a.layer, a.kv_pos = layer, dpos.data_ptr()
+    _lib.check(L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()))
+    sync()
+    torch.testing.assert_close(dq.cpu(), ref[:, :D], rtol=3e-5, atol=3e-5)
+    newpool = dpool.cpu()
+    mask = torch.ones_like(pool, dtype=torch.bool)
+    for b in range(B):
+        p = int(pos[b])
+        page = int(table[b, p // _lib.PAGE])
+        for which in (0, 1):
+            got = newpool[page, layer, which, :, p % _lib.PAGE, :].reshape(-1)
+            torch.testing.assert_close(got, ref[b, (1 + which) * D:(2 + which) * D], rtol=3e-5, atol=3e-5)
+        mask[page, layer, :, :, p % _lib.PAGE, :] = False
+    assert torch.equal(newpool[mask], pool[mask])
+    # ---- (b)
+    for lens in ([1000, 129, 1, 640][:B], [5, 1024, 900, 257][:B]):
+        q = torch.randn(B, D, generator=g)
+        att = torch.zeros(B, D)
+        for r, ln in enumerate(lens):
+            for h in range(H):
+                k = _gather(pool, table, r, layer, 0, h, ln)
+                v = _gather(pool, table, r, layer, 1, h, ln)
+                att[r, h * hd:(h + 1) * hd] = F.scaled_dot_product_attention(q[r, h * hd:(h + 1) * hd].view(1, 1, 1, hd), k.view(1, 1, ln, hd), v.view(1, 1, ln, hd)).view(-1)
+        dlen = dev(torch.tensor(lens, dtype=torch.int32))
+        part_o = torch.zeros(B * H * max_pages * hd, device="cuda")
+        part_ml = torch.zeros(B * H * max_pages * 2, device="cuda")
+        at = _lib.AttnArgs()
+        dq2 = dev(q)
+        at.q, at.q_stride = dq2.data_ptr(), 0
+        keep = dev(pool)
+        at.kv = _lib.KV(keep.data_ptr(), dtable.data_ptr(), max_pages, n_layer, H, hd)
+        at.layer, at.row_seq, at.row_len, at.R, at.max_splits = layer, 0, dlen.data_ptr(), B, max_pages
+        at.scale, at.part_o, at.part_ml = 1.0 / math.sqrt(hd), part_o.data_ptr(), part_ml.data_ptr()
+        _lib.check(L.ssrhip_attn_decode(C.byref(at), _lib.stream_ptr()))
+        Wo = torch.randn(D, D, generator=g) / math.sqrt(D)
+        bo = torch.randn(D, generator=g)
+        y0 = torch.randn(B, D, generator=g)
+        dWo, dbo, dy = dev(Wo), dev(bo), dev(y0.clone())
+        ga = _lib.GemvArgs()
+        ga.W, ga.bias, ga.y, ga.B, ga.N, ga.K, ga.groups, ga.x_stride, ga.y_stride = dWo.data_ptr(), dbo.data_ptr(), dy.data_ptr(), B, D, D, 1, D, D
+        ga.pro, ga.act, ga.epi = _lib.PRO_ATTN_COMBINE, 0, _lib.EPI_RESIDUAL
+        ga.part_o, ga.part_ml, ga.max_splits, ga.row_len, ga.kv = part_o.data_ptr(), part_ml.data_ptr(), max_pages, dlen.data_ptr(), at.kv
+        _lib.check(L.ssrhip_gemv(C.byref(ga), _lib.stream_ptr()))
+        sync()
+        want = y0 + F.linear(att.double(), Wo.double(), bo.double()).float()
+        torch.testing.assert_close(dy.cpu(), want, rtol=3e-5, atol=3e-5)
+
 # ------------------------------------------------------------------------------------------ attention
 def _make_cache(n_seq, max_pages, n_layer, H, hd, g):
     n_pages = n_seq * max_pages
