@@ -425,7 +425,7 @@ def main():
                          # for wide reads applied: 50.5 MB read + 0.1 MB written per GEMV launch vs 49.85 MB algorithmic
                          "traffic": TRAFFIC_BYTES_PER_GEMV_LAUNCH.get(2 * U) if (arena.D == 2048 and arena.L == 16) else None,
                          "traffic_source": TRAFFIC_SOURCE.get(2 * U, "not measured for this row count") + " (rocprofv3 --pmc passes of this command, gfx950 x2 FETCH_SIZE correction)",
-                         "kernel": ("gemv_fast_kernel<2,*> (fused LN/combine + GEMV + bias/act/residual), all 66 launches of a step" if 2 * U <= 4 else
+                         "kernel": ("gemv_seg_kernel<2,*> (fused LN/combine + GEMV + bias/act/residual), all 66 launches of a step" if 2 * U <= 4 else
                                     "gemv_rows_xreg_kernel / gemv_rows_stream_kernel (matrix-core GEMV, streaming-order weights), all 66 launches of a step"),
                          "bytes_per_launch": int(bytes_per_launch), "launches_per_step": n_gemv, "us_per_launch": round(gemv_us, 3),
                          "us_per_launch_eager_event_pair": round(gemv_us_eager, 3),

@@ -32,17 +32,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args
   constexpr int NI = 32 / KPI;        // load instructions for the wave's 32 keys
   __shared__ __attribute__((aligned(16))) float sm[4][HD + 4];   // row stride keeps float4 stores 16-B aligned
   const int split = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
-  const int len = a.row_len[r];
-  const int base = split * SSRHIP_PAGE;
-  if (base >= len) return;            // uniform per block
-  const int seq = a.row_seq ? a.row_seq[r] : r;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPK;         // which key row inside one wave-instruction
   const int c4 = (lane % LPK) * 4;    // this lane's 4 columns
   const int H = a.kv.n_head;
-
-  const float4 q = ld4(a.q + (size_t)r * (a.q_stride ? a.q_stride : H * HD) + h * HD + c4);
+  // the row's length, its page id and q are requested TOGETHER, before the early exit (split < max_pages: the table entry exists and
+  // holds a valid page — the engine's spare page — also beyond the row's length): one scalar-memory round trip instead of two in a row
+  const int seq = a.row_seq ? a.row_seq[r] : r;
+  const int len = a.row_len[r];
   const int page = a.kv.table[(size_t)seq * a.kv.max_pages + split];
+  const float4 q = ld4(a.q + (size_t)r * (a.q_stride ? a.q_stride : H * HD) + h * HD + c4);
+  const int base = split * SSRHIP_PAGE;
+  if (base >= len) return;            // uniform per block
   const float* kp = a.kv.pool + ((((size_t)page * a.kv.n_layer + a.layer) * 2 + 0) * H + h) * SSRHIP_PAGE * HD;
   const float* vp = kp + (size_t)H * SSRHIP_PAGE * HD;
 

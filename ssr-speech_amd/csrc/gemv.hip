@@ -788,7 +788,8 @@ __global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
     for (int b = 0; b < B; ++b) {
       const float* po = a.part_o + (((size_t)b * H + h) * MS) * hd + d;
 #pragma unroll
-      for (int s2 = 0; s2 < SEG_CS; ++s2) co[b][s2] = ld4(po + (size_t)min(s2, ns[b] - 1) * hd);
+      for (int s2 = 0; s2 < SEG_CS; ++s2) co[b][s2] = ld4(po + (size_t)min(s2, MS - 1) * hd);   // address independent of row_len (no scalar-load
+                                                                                                  // round trip ahead of these); pages beyond the row are dropped below
     }
   }
   // ---- 2. the wave's first unit, unconditional (clamped to the workgroup's last unit). FOUR loads in flight per lane, 16 waves per
@@ -881,11 +882,12 @@ __global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int s2 = 0; s2 < SEG_CS; ++s2) {
-        const float ws = (s2 < ns[b]) ? w[s2] : 0.f;
-        acc.x = fmaf(ws, co[b][s2].x, acc.x);
-        acc.y = fmaf(ws, co[b][s2].y, acc.y);
-        acc.z = fmaf(ws, co[b][s2].z, acc.z);
-        acc.w = fmaf(ws, co[b][s2].w, acc.w);
+        const bool in = s2 < ns[b];                                   // a page beyond the row: whatever the buffer holds there must not count (0 * NaN)
+        const float ws = in ? w[s2] : 0.f;
+        acc.x = fmaf(ws, in ? co[b][s2].x : 0.f, acc.x);
+        acc.y = fmaf(ws, in ? co[b][s2].y : 0.f, acc.y);
+        acc.z = fmaf(ws, in ? co[b][s2].z : 0.f, acc.z);
+        acc.w = fmaf(ws, in ? co[b][s2].w : 0.f, acc.w);
       }
       const float* po = a.part_o + (((size_t)b * H + h) * MS) * hd + d;
       for (int s2 = SEG_CS; s2 < ns[b]; ++s2) {                    // contexts beyond the prefetched pages: the rest, loaded late
