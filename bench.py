@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # Not re-measured live (counters need rocprofv3): the constants are this round's profiles, named in `traffic_source`.
 #   2 rows : (67.95 x16 + 59.22 x32 + 17.60 x16 + 34.31 + 33.97) / 66 = 50.5 MB read + 0.1 MB written
 #   16 rows: (59.30 x33 + 71.66 x16 + 18.17 x16 + 36.04) / 66 = 52.0 MB read + 0.3 MB written (x re-read through L2 by the streamed-x kernel)
-TRAFFIC_BYTES_PER_GEMV_LAUNCH = {2: 50.6e6, 16: 52.3e6}
+TRAFFIC_BYTES_PER_GEMV_LAUNCH = {2: 50.5e6, 16: 52.3e6}
 TRAFFIC_SOURCE = {2: "profiles/r02_pmc_fetch_size.md + profiles/r02_pmc_write_size.md", 16: "profiles/r02_pmc_fetch_size_16rows.md + profiles/r02_pmc_write_size_16rows.md"}
 
 

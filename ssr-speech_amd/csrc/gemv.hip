@@ -963,6 +963,9 @@ bool try_seg(const ssrhip_gemv_args* a, int num_cu, hipStream_t s) {
   const int H = a->kv.head_dim > 0 ? a->K / a->kv.head_dim : 0;
   if (a->pro == SSRHIP_PRO_ATTN_COMBINE && (a->K != 2048 || a->max_splits < 2 || a->groups != 1 || B * H > SEG_TH || a->kv.head_dim % 4 != 0)) return false;
   int G = (2 * num_cu) / a->groups;                                // two resident workgroups per CU over all groups
+  // the combine prologue makes EVERY workgroup read all the attention partials (~100 KB at 6 pages): with two workgroups per CU that is
+  // 3x the CU's share of the weights through its 64 B/clk L2 port; one workgroup per CU halves it
+  if (a->pro == SSRHIP_PRO_ATTN_COMBINE && !getenv("SSRHIP_GEMV_SEG_COMBINE_2")) G = num_cu;
   if (G > a->N) G = a->N;                                          // fewer rows than workgroups: one row each
   if (G < 1) G = 1;
   const int rows_max = (a->N + G - 1) / G;
