@@ -8,7 +8,7 @@ files left alone (:53-57, :103-108).
 
 What differs, deliberately:
 * the codec is this package's HIP `WMEncodecModel` (through `AudioTokenizer`), not `WMCompressionSolver.model_from_checkpoint`;
-* WAV reading is the in-tree RIFF reader (torchaudio is not required unless a clip needs resampling);
+* WAV reading is the in-tree RIFF reader, resampling `data/resample.py` (torchaudio's windowed-sinc `Resample` as a HIP polyphase filter);
 * under `torch.distributed.run` (RANK / WORLD_SIZE in the environment) the `[start:end]` slice is split further into
   contiguous per-rank shards — no collective, every rank writes its own files (the reference shards by hand with
   `--start/--end`); `--n_workers` is accepted and ignored (clips are read on the main thread: the encode is ~2000x real time);

@@ -135,12 +135,8 @@ def convert_audio(wav: torch.Tensor, sr: int, target_sr: int, target_channels: i
     elif wav.shape[0] == 1:
         wav = wav.expand(target_channels, -1)
     if sr != target_sr:
-        try:
-            import torchaudio
-        except ImportError as e:
-            raise RuntimeError(f"resampling {sr} -> {target_sr} Hz needs torchaudio (reference data/tokenizer.py:96); "
-                               f"provide {target_sr} Hz audio") from e
-        wav = torchaudio.transforms.Resample(sr, target_sr)(wav)
+        from .resample import resample                       # torchaudio.transforms.Resample(sr, target_sr) of the reference (:96)
+        wav = resample(wav, sr, target_sr)
     return wav
 
 

