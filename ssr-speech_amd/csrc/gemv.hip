@@ -16,6 +16,10 @@
 //   * no LDS on the weight path (each weight element is used once: staging would be pure overhead);
 //     LDS only shares the prologue result between the 4 waves and adds the K-slices of one row;
 //   * wave reductions are DPP/permlane (no ds_bpermute).
+// The paragraph above describes the row-per-wave kernels (`gemv_kernel`, `gemv_fast_kernel`). Since the second half of round 2 the
+// shapes of the 830M step (K = 1024 * {1,2,4,8}, LayerNorm folded) run on `gemv_seg_kernel` further down — same fusion, a different
+// split of the work (contiguous rows per 512-thread workgroup, (row, 1024-float segment) units, 4 loads in flight per lane); the
+// row-per-wave kernels serve every other shape and `SSRHIP_GEMV_SEG=0`.
 // Replaces F.linear (+LayerNorm / ReLU / GELU / residual) of the reference: see include/ssrhip.h.
 #include <stdlib.h>
 #include "common.h"
@@ -29,6 +33,8 @@ struct GemvK {
   int nch;        // float4 chunks per lane per slice (<= 8)
   int groups_x;   // wave-groups along N (= gridDim.x * 4/nslice)
   int hd;         // head_dim (QKV epilogue / combine prologue)
+  int seg_shift;  // segment kernel: log2(K / 1024)
+  int rows_max;   // segment kernel: most rows a workgroup owns (sizes the LDS partials)
 };
 
 constexpr int PRO_LN_REGS = 3;   // internal: LayerNorm with gamma/beta folded into W/bias, whole row per wave (no LDS)
@@ -760,9 +766,9 @@ __global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
   const int K = a.K, N = a.N, S = p.nslice;                        // S segments per row (power of two <= 8)
   const int r0 = (int)(((long)N * blockIdx.x) / G), r1 = (int)(((long)N * (blockIdx.x + 1)) / G);
   const int nrows = r1 - r0, nu = nrows * S;                       // host guarantees N >= G: nrows >= 1
-  const int seg = wave & (S - 1), sh = p.slice_len;                // sh = log2(S)
-  float* part = smem;                                              // [p.nch rows max][S][B]
-  float* aux = smem + p.nch * S * B;                               // prologue scratch
+  const int seg = wave & (S - 1), sh = p.seg_shift;                // sh = log2(S)
+  float* part = smem;                                              // [rows_max][S][B]
+  float* aux = smem + p.rows_max * S * B;                          // prologue scratch
   const float* Wg = a.W + ((size_t)g * N + r0) * K + seg * SEG + lane * 4;
 
   // ---- 1. activations (L2) — issued first, they return first
@@ -973,8 +979,10 @@ bool try_seg(const ssrhip_gemv_args* a, int num_cu, hipStream_t s) {
   GemvK p;
   p.a = *a;
   p.nslice = S;
-  p.slice_len = (S == 1) ? 0 : (S == 2) ? 1 : (S == 4) ? 2 : 3;   // log2(S)
-  p.nch = rows_max;
+  p.slice_len = SEG;
+  p.nch = 4;
+  p.seg_shift = (S == 1) ? 0 : (S == 2) ? 1 : (S == 4) ? 2 : 3;
+  p.rows_max = rows_max;
   p.groups_x = G;
   p.hd = (a->kv.head_dim > 0) ? a->kv.head_dim : 1;
   size_t smem = (size_t)rows_max * S * B * sizeof(float);
@@ -1039,6 +1047,8 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   }
   GemvK p;
   p.a = *a;
+  p.seg_shift = 0;
+  p.rows_max = 0;
   p.nslice = a->K <= 2048 ? 1 : (a->K <= 4096 ? 2 : 4);
   p.slice_len = ((a->K + p.nslice - 1) / p.nslice + 3) / 4 * 4;
   p.nch = (p.slice_len + 255) / 256;
