@@ -135,7 +135,14 @@ __device__ __forceinline__ void combine_issue(const GemvK& p, CombineRegs<B>& r,
     const float* ml = p.a.part_ml + (size_t)t * MS * 2;
     const int n = ns[t / H];
 #pragma unroll
-    for (int i = 0; i < CS / 2; ++i) r.ml[i] = (2 * i < n) ? ld4(ml + 4 * i) : make_float4(-INFINITY, 0.f, -INFINITY, 0.f);
+    for (int i = 0; i < CS / 2; ++i) {
+      if (2 * i + 1 < MS) {
+        r.ml[i] = (2 * i < n) ? ld4(ml + 4 * i) : make_float4(-INFINITY, 0.f, -INFINITY, 0.f);
+      } else {                                                       // odd max_splits: the last pair has no partner (never read past the block)
+        const float2 v = (2 * i < n) ? *reinterpret_cast<const float2*>(ml + 4 * i) : make_float2(-INFINITY, 0.f);
+        r.ml[i] = make_float4(v.x, v.y, -INFINITY, 0.f);
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -717,7 +724,7 @@ bool try_fast(const GemvK& p, dim3 grid, size_t smem, hipStream_t s) {
     return false;
   }
   if (a.pro == SSRHIP_PRO_ATTN_COMBINE) {
-    if (a.K != 2048 || p.nch != 8 || a.max_splits < 2 || B * (a.K / p.hd) > 256) return false;
+    if (a.K != 2048 || p.nch != 8 || a.max_splits < 2 || (a.max_splits & 1) || B * (a.K / p.hd) > 256) return false;   // its (m, l) loads take two pages at a time
     launch_fast<B, SSRHIP_PRO_ATTN_COMBINE, 8>(p, grid, smem, s, rows0);
     return true;
   }
@@ -754,7 +761,7 @@ void launch_b(const GemvK& p, dim3 grid, size_t smem, hipStream_t s) {
 //   * 16 waves per CU (two workgroups): 128 VGPRs per lane (HIP's second launch-bound is waves per SIMD).
 constexpr int SEG = 1024;            // floats per unit
 constexpr int SEG_TH = 512, SEG_NW = 8;
-template <int B> struct SegCS { static constexpr int v = (B <= 2) ? 6 : 2; };   // pages prefetched by the combine prologue (register budget: 128; even)
+template <int B> struct SegCS { static constexpr int v = (B <= 2) ? 6 : 2; };   // pages prefetched by the combine prologue (register budget: 128)
 
 template <int B, int PRO>
 __global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
@@ -774,7 +781,7 @@ __global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
   // ---- 1. activations (L2) — issued first, they return first
   float4 xr[B][4];
   float4 co[(PRO == SSRHIP_PRO_ATTN_COMBINE) ? B : 1][SEG_CS];
-  float4 cml[SEG_CS / 2];
+  float2 cml[SEG_CS];                                              // (m, l) of the first SEG_CS pages of this thread's (row, head)
   int ns[(PRO == SSRHIP_PRO_ATTN_COMBINE) ? B : 1];
   if constexpr (PRO != SSRHIP_PRO_ATTN_COMBINE) {
 #pragma unroll
@@ -788,7 +795,7 @@ __global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
     const int tt = t % (B * H);                                    // every thread loads an (m,l) block; only t < B*H uses it
     const float* ml = a.part_ml + (size_t)tt * MS * 2;
 #pragma unroll
-    for (int i = 0; i < SEG_CS / 2; ++i) cml[i] = ld4(ml + 4 * min(i, (MS * 2 - 4) / 4));
+    for (int i = 0; i < SEG_CS; ++i) cml[i] = *reinterpret_cast<const float2*>(ml + 2 * min(i, MS - 1));   // pair by pair: any max_splits >= 1, odd ones too
     const int e = t * 4, h = e / hd, d = e % hd;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
@@ -863,21 +870,18 @@ __global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
       const float* ml = a.part_ml + (size_t)t * MS * 2;
       float M = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < SEG_CS / 2; ++i) { if (2 * i < n) M = fmaxf(M, cml[i].x); if (2 * i + 1 < n) M = fmaxf(M, cml[i].z); }
+      for (int i = 0; i < SEG_CS; ++i)
+        if (i < n) M = fmaxf(M, cml[i].x);
       for (int s2 = SEG_CS; s2 < n; ++s2) M = fmaxf(M, ml[2 * s2]);
       float den = 0.f;
 #pragma unroll
-      for (int i = 0; i < SEG_CS / 2; ++i) {
-        if (2 * i < n) den = fmaf(expf(cml[i].x - M), cml[i].y, den);
-        if (2 * i + 1 < n) den = fmaf(expf(cml[i].z - M), cml[i].w, den);
-      }
+      for (int i = 0; i < SEG_CS; ++i)
+        if (i < n) den = fmaf(expf(cml[i].x - M), cml[i].y, den);
       for (int s2 = SEG_CS; s2 < n; ++s2) den = fmaf(expf(ml[2 * s2] - M), ml[2 * s2 + 1], den);
       const float inv = 1.0f / den;
 #pragma unroll
-      for (int i = 0; i < SEG_CS / 2; ++i) {
-        if (2 * i < n) wtab[t * MS + 2 * i] = expf(cml[i].x - M) * inv;
-        if (2 * i + 1 < n) wtab[t * MS + 2 * i + 1] = expf(cml[i].z - M) * inv;
-      }
+      for (int i = 0; i < SEG_CS; ++i)
+        if (i < n) wtab[t * MS + i] = expf(cml[i].x - M) * inv;
       for (int s2 = SEG_CS; s2 < n; ++s2) wtab[t * MS + s2] = expf(ml[2 * s2] - M) * inv;
     }
     __syncthreads();
@@ -967,7 +971,7 @@ bool try_seg(const ssrhip_gemv_args* a, int num_cu, hipStream_t s) {
   if (S != 1 && S != 2 && S != 4 && S != 8) return false;
   if (a->pro == SSRHIP_PRO_LAYERNORM && a->ln_w != nullptr) return false;
   const int H = a->kv.head_dim > 0 ? a->K / a->kv.head_dim : 0;
-  if (a->pro == SSRHIP_PRO_ATTN_COMBINE && (a->K != 2048 || a->max_splits < 2 || a->groups != 1 || B * H > SEG_TH || a->kv.head_dim % 4 != 0)) return false;
+  if (a->pro == SSRHIP_PRO_ATTN_COMBINE && (a->K != 2048 || a->max_splits < 1 || a->groups != 1 || B * H > SEG_TH || a->kv.head_dim % 4 != 0)) return false;
   int G = (2 * num_cu) / a->groups;                                // two resident workgroups per CU over all groups
   // the combine prologue makes EVERY workgroup read all the attention partials (~100 KB at 6 pages): with two workgroups per CU that is
   // 3x the CU's share of the weights through its 64 B/clk L2 port; one workgroup per CU halves it

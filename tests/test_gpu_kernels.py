@@ -251,18 +251,20 @@ print("ERR", err)
     assert err < 3e-5, err
 
 
+@pytest.mark.parametrize("max_pages", [8, 7, 5, 1])
 @pytest.mark.parametrize("B", [1, 2, 4])
-def test_gemv_seg_combine_and_qkv_append_at_2048(L, B):
+def test_gemv_seg_combine_and_qkv_append_at_2048(L, B, max_pages):
     """Segment kernel, the two launches with special plumbing at d_model = 2048 / 16 heads: (a) LayerNorm (folded) + QKV with the K/V
     rows appended into the paged cache, (b) split-KV merge prologue (contexts of 1..8 pages: beyond the 6 prefetched ones) + residual."""
     g = torch.Generator().manual_seed(40 + B)
-    D, H, hd, n_layer, max_pages, layer = 2048, 16, 128, 2, 8, 1
+    D, H, hd, n_layer, layer = 2048, 16, 128, 2, 1                 # max_pages: even, odd (the (m, l) pairs are read one by one), a single page
+    cap = max_pages * _lib.PAGE
     pool, table = _make_cache(B, max_pages, n_layer, H, hd, g)
     # ---- (a)
     Wt = torch.randn(3 * D, D, generator=g) / math.sqrt(D)
     bias = torch.randn(3 * D, generator=g)
     x = torch.randn(B, D, generator=g) * 1.3 + 0.2
-    pos = torch.tensor([130, 7, 1023, 512][:B], dtype=torch.int32)
+    pos = torch.tensor([min(p, cap - 1) for p in [130, 7, 1023, 512][:B]], dtype=torch.int32)
     ref = F.linear(F.layer_norm(x, (D,), None, None, 1e-5).double(), Wt.double(), bias.double()).float()
     dpool, dtable, dW, db, dx, dpos = dev(pool), dev(table), dev(Wt), dev(bias), dev(x), dev(pos)
     dq = torch.zeros(B, D, device="cuda")
@@ -286,7 +288,8 @@ def test_gemv_seg_combine_and_qkv_append_at_2048(L, B):
         mask[page, layer, :, :, p % _lib.PAGE, :] = False
     assert torch.equal(newpool[mask], pool[mask])
     # ---- (b)
-    for lens in ([1000, 129, 1, 640][:B], [5, 1024, 900, 257][:B]):
+    for lens in ([1000, 129, 1, 640][:B], [5, 1024, 900, 257][:B], [cap, cap - 1, cap, 1][:B]):
+        lens = [min(v, cap) for v in lens]
         q = torch.randn(B, D, generator=g)
         att = torch.zeros(B, D)
         for r, ln in enumerate(lens):
