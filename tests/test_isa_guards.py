@@ -1,0 +1,88 @@
+"""CPU (hipcc cross-compiles gfx950 without a GPU): code-generation properties the decode GEMV's speed depends on, read off the ISA.
+They were found by reading `hipcc -S` output while tuning and are easy to lose with an innocent edit:
+
+  * every `gemv_seg_kernel` variant fits 128 VGPRs (16 waves per CU) with NO scratch (a spill puts memory traffic in the prologue);
+  * its streaming loop re-requests each 16-byte piece in place: four non-temporal `global_load_dwordx4` per iteration, each behind an
+    `s_waitcnt vmcnt(3)` — never a `vmcnt(0)` drain inside the loop (what a conditional re-request produced);
+  * the row-per-wave kernels and the matrix-core kernels of the 830M shapes stay spill-free too.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ssr-speech_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def _asm(tmp_path_factory, name):
+    out = tmp_path_factory.mktemp("isa") / (name + ".s")
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", f"-I{ROOT}/include", f"-I{CSRC}", "-ffp-contract=off", "-S", "--cuda-device-only",
+           os.path.join(CSRC, name + ".hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    return open(out).read()
+
+
+def _kernel_meta(asm):
+    """symbol -> (vgpr_count, private_segment_fixed_size) from the .amdhsa metadata block."""
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", asm, re.S):
+        body = m.group(2)
+        v = re.search(r"\.vgpr_count:\s+(\d+)", body)
+        p = re.search(r"\.private_segment_fixed_size:\s+(\d+)", asm[m.start() - 400:m.end()])
+        if v and p:
+            meta[m.group(1)] = (int(v.group(1)), int(p.group(1)))
+    return meta
+
+
+def _body(asm, symbol):
+    start = asm.index("\n" + symbol + ":")
+    return asm[start:asm.index("s_endpgm", start)]
+
+
+@pytest.fixture(scope="module")
+def gemv_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "gemv")
+
+
+def test_segment_kernel_fits_128_vgprs_without_scratch(gemv_asm):
+    meta = {k: v for k, v in _kernel_meta(gemv_asm).items() if "gemv_seg_kernel" in k}
+    assert len(meta) == 9, sorted(meta)                              # B in {1,2,4} x prologue in {none, LayerNorm, split-KV merge}
+    for sym, (vgpr, scratch) in meta.items():
+        assert vgpr <= 128, (sym, vgpr)
+        assert scratch == 0, (sym, scratch)
+
+
+def test_segment_kernel_loop_rerequests_in_place(gemv_asm):
+    for sym in (s for s in _kernel_meta(gemv_asm) if "gemv_seg_kernel" in s and "ILi2E" in s):
+        body = _body(gemv_asm, sym)
+        loops = [m.start() for m in re.finditer(r"=>This Inner Loop Header", body)]
+        assert loops, sym
+        found = False
+        for lo in loops:
+            # the loop's text runs to its backward branch: the first s_cbranch after the header that targets a label defined before it
+            seg = body[lo:lo + 12000]
+            nt = [m.start() for m in re.finditer(r"global_load_dwordx4 [^\n]* nt", seg)]
+            if len(nt) >= 4:
+                inner = seg[:nt[3]]
+                if inner.count("s_waitcnt vmcnt(3)") >= 4 and "s_waitcnt vmcnt(0)" not in inner:
+                    found = True
+        assert found, f"{sym}: no loop with four in-place non-temporal re-requests behind vmcnt(3) waits"
+
+
+def test_row_per_wave_and_matrix_core_kernels_of_the_830m_shapes_do_not_spill(gemv_asm, tmp_path_factory):
+    fast = {k: v for k, v in _kernel_meta(gemv_asm).items() if "gemv_fast_kernel" in k and "ILi2E" in k}
+    assert fast
+    for sym, (vgpr, scratch) in fast.items():
+        limit = 256 if "ILi2ELi2E" in sym else 170                   # 3 waves per SIMD; the split-KV merge variant is launched at 2 per SIMD
+        assert scratch == 0 and vgpr <= limit, (sym, vgpr, scratch)
+    mfma = _kernel_meta(_asm(tmp_path_factory, "gemv_mfma"))
+    used = [k for k in mfma if ("gemv_rows_xreg_kernel" in k and "Li16ELi16E" in k) or "gemv_rows_stream_kernel" in k]
+    assert len(used) >= 4, sorted(mfma)
+    for sym in used:
+        assert mfma[sym][1] == 0 and mfma[sym][0] <= 256, (sym, mfma[sym])
