@@ -226,12 +226,16 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const ssrhip_lstm_a
   const unsigned xvoff = (unsigned)(ks * 16 + c) * 4;
   const int tbase = wave * SPW;
 
+  // operands are requested in the order the MFMA chain consumes them (k-step by k-step: W_hh block, then that k-step's h blocks of every
+  // batch tile): loads return in order, so the chain starts after the first three KiB instead of after all 48 (the h tiles used to be
+  // requested first, all W_hh blocks last: the whole 1.7 us matrix-core chain sat behind the complete load phase)
   float4 xr[NT][SPW];
+  float4 w[SPW];
 #pragma unroll
-  for (int q = 0; q < NT; ++q) {
-    const float* xbase = hprev + (size_t)min(bt0 + q, nbt - 1) * 16 * C;
+  for (int i = 0; i < SPW; ++i) {
+    w[i] = ld4(wbase + min(tbase + i, last) * wstep + wvoff);
 #pragma unroll
-    for (int i = 0; i < SPW; ++i) xr[q][i] = ld4(xbase + min(tbase + i, last) * 256 + xvoff);
+    for (int q = 0; q < NT; ++q) xr[q][i] = ld4(hprev + (size_t)min(bt0 + q, nbt - 1) * 16 * C + min(tbase + i, last) * 256 + xvoff);
   }
   // the finishing waves (wave q finishes batch tile q) request their gate inputs and cell state NOW: they do not depend on
   // the recurrent product, so their L2/HBM latency hides under the MFMA chain instead of following it
@@ -243,9 +247,6 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const ssrhip_lstm_a
     pg[0] = gin[jj]; pg[1] = gin[C + jj]; pg[2] = gin[2 * C + jj]; pg[3] = gin[3 * C + jj];
     pc = (t == 0) ? 0.f : a.cbuf[(size_t)bb * C + jj];
   }
-  float4 w[SPW];
-#pragma unroll
-  for (int i = 0; i < SPW; ++i) w[i] = ld4(wbase + min(tbase + i, last) * wstep + wvoff);
 #pragma unroll
   for (int q = 0; q < NT; ++q)
 #pragma unroll
