@@ -243,6 +243,14 @@ int ssrhip_conv_few_out(const float* x, const float* w, const float* bias, float
 /* reflect padding of a time-major buffer (conv.py:71-88): rows [0,padL) and [padL+T, padL+T+padR) mirror the interior */
 int ssrhip_pad_reflect(float* buf, int32_t B, int32_t T, int32_t padL, int32_t padR, int32_t C, int64_t bstride,
                        ssrhip_stream_t stream);
+/* halo rows of a RAGGED batch in a time-major buffer [B][padL + T + padR][C] whose producer wrote T rows for every item although
+ * item b holds only lens[b] <= T valid ones (device array): the padR rows right behind item b's last valid row (rows padL + lens[b] ..,
+ * partly inside the dense interior) and, for reflect, its padL leading rows get the padding an item of that length ALONE would have —
+ * zeros (reflect == 0) or the mirror image about its own ends (conv.py:71-88, incl. the zero extension of inputs shorter than the
+ * pad). Every layer of the batch then computes, for t < its own length, exactly what a batch-1 call computes (the SEANet
+ * convolutions are not causal, so dense zero padding of a short item would change its tail; wmencodec.py:341-375 per item). */
+int ssrhip_pad_ragged(float* buf, const int32_t* lens, int32_t B, int32_t T, int32_t padL, int32_t padR, int32_t C, int64_t bstride,
+                      int32_t reflect, ssrhip_stream_t stream);
 /* one LSTM layer over T steps (torch.nn.LSTM semantics, gates i,f,g,o; modules/lstm.py:10-25):
  * gin[b][t][4C] = x_t W_ih^T + b_ih + b_hh (precomputed by ssrhip_gemm); h,c start at 0.
  * out[b][t][C] = h_t (+ skip[b][t][C] when skip != NULL).  cbuf: [B][C]; hbuf: [2][ceil(B/16)*16][C] floats (row-major

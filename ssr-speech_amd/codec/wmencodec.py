@@ -13,7 +13,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -30,8 +30,9 @@ def _extra_padding(length: int, k: int, s: int, pt: int) -> int:
 class TM:
     """Time-major activation buffer with halo rows."""
 
-    def __init__(self, B: int, T: int, Cc: int, padL: int, padR: int, device):
+    def __init__(self, B: int, T: int, Cc: int, padL: int, padR: int, device, lens: "Optional[Ragged]" = None):
         self.B, self.T, self.C, self.padL, self.padR = B, T, Cc, padL, padR
+        self.lens = lens                   # ragged batch: per-item valid rows (None = every item has T rows)
         self.rows = padL + T + padR
         # every producer writes the whole interior; only the halo rows need a defined value before the consumer reads them
         # (zero for constant / structural padding; reflect padding overwrites them). A torch.zeros of the whole buffer was 24
@@ -56,6 +57,25 @@ class TM:
 
     def interior_view(self) -> torch.Tensor:
         return self.data[:, self.padL: self.padL + self.T]
+
+
+class Ragged:
+    """Per-item lengths of a ragged batch at one time resolution: host list + the same numbers as a device int32 array (what
+    `ssrhip_pad_ragged` reads). `scaled` derives the lengths after an up-/down-sampling layer; the device arrays are cached
+    per resolution so that a decode creates four small tensors, not one per layer."""
+
+    def __init__(self, lens: Sequence[int], device, _cache=None):
+        self.host = [int(v) for v in lens]
+        self.dev = torch.tensor(self.host, dtype=torch.int32, device=device)
+        self._cache = _cache if _cache is not None else {}
+        self._cache[tuple(self.host)] = self
+
+    def scaled(self, num: int, den: int = 1) -> "Ragged":
+        if any((v * num) % den for v in self.host):
+            raise ValueError(f"ragged lengths {self.host} are not whole frames at a stride of {den}")
+        new = tuple(v * num // den for v in self.host)
+        hit = self._cache.get(new)
+        return hit if hit is not None else Ragged(new, self.dev.device, self._cache)
 
 
 def _fold_wn(sd, pfx: str, which: str) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -227,6 +247,15 @@ class WMEncodecModel:
         _lib.check(self.lib.ssrhip_gemm(C.byref(a), self._s()), "ssrhip_gemm")
 
     def _fill_pads(self, buf: TM, structural_zero: bool = False):
+        if self.cfg.pad_mode not in ("constant", "reflect"):
+            raise ValueError(self.cfg.pad_mode)
+        if buf.lens is not None:
+            # ragged batch: every item gets ITS OWN halo right behind its last valid row (and in front, for reflect)
+            if buf.padL + buf.padR > 0:
+                refl = int(self.cfg.pad_mode == "reflect" and not structural_zero)
+                _lib.check(self.lib.ssrhip_pad_ragged(buf.base, buf.lens.dev.data_ptr(), buf.B, buf.T, buf.padL, buf.padR, buf.C, buf.bstride,
+                                                      refl, self._s()), "ssrhip_pad_ragged")
+            return
         if self.cfg.pad_mode == "reflect" and not structural_zero and (buf.padL + buf.padR) > 0:
             _lib.check(self.lib.ssrhip_pad_reflect(buf.base, buf.B, buf.T, buf.padL, buf.padR, buf.C, buf.bstride, self._s()), "ssrhip_pad_reflect")
         elif self.cfg.pad_mode not in ("constant", "reflect"):
@@ -247,15 +276,15 @@ class WMEncodecModel:
             return 1, 1, True
         return 0, 0, False
 
-    def _alloc_for(self, B, T, Cc, nxt) -> TM:
+    def _alloc_for(self, B, T, Cc, nxt, lens: Optional[Ragged] = None) -> TM:
         pl, pr, _ = self._need(nxt, T)
-        return TM(B, T, Cc, pl, pr, self.device)
+        return TM(B, T, Cc, pl, pr, self.device, lens)
 
     # ------------------------------------------------------------------ nodes
     def _conv(self, c: _Conv, x: TM, nxt, R: Optional[TM] = None) -> TM:
         B = x.B
         T_out = (x.T + x.padL + x.padR - c.k) // c.s + 1
-        out = self._alloc_for(B, T_out, c.Cout, nxt)
+        out = self._alloc_for(B, T_out, c.Cout, nxt, x.lens.scaled(1, c.s) if x.lens is not None else None)
         if c.Cin == 1:
             assert c.act_in == 0
             _lib.check(self.lib.ssrhip_conv_cin1(x.base, c.Wraw.data_ptr(), c.b.data_ptr(), out.interior, B, T_out, c.k, c.s, c.Cout,
@@ -274,7 +303,7 @@ class WMEncodecModel:
     def _convtr(self, c: _ConvTr, x: TM, nxt) -> TM:
         assert x.padL == 1 and x.padR == 1
         T_out = x.T * c.s
-        out = self._alloc_for(x.B, T_out, c.Cout, nxt)
+        out = self._alloc_for(x.B, T_out, c.Cout, nxt, x.lens.scaled(c.s) if x.lens is not None else None)
         Cp = out.interior - 4 * c.trim_l * c.Cout
         self._gemm(x.base, c.W, c.b, Cp, x.T + 1, c.s * c.Cout, 2 * c.Cin, c.Cin, c.s * c.Cout, act_in=_lib.ACT_ELU, batch=x.B,
                    sA=x.bstride, sC=out.bstride, tm=(c.Cout, c.trim_l, c.trim_l + T_out))
@@ -286,7 +315,7 @@ class WMEncodecModel:
         if self.fuse_resblock and c3.Cin in self.fuse_channels and c3.Cout * 2 == c3.Cin and c3.k == 3 and c3.s == 1 and c1.k == 1 and c1.s == 1 \
                 and x.padL == 1 and x.padR == 1:
             # the whole block as one kernel (csrc/resblock.hip): one read + one write of the activation, the C/2 intermediate stays on chip
-            out = self._alloc_for(x.B, x.T, c1.Cout, nxt)
+            out = self._alloc_for(x.B, x.T, c1.Cout, nxt, x.lens)
             a = _lib.ResblockArgs()
             a.x, a.y = x.base, out.interior
             a.w3, a.b3, a.w1, a.b1 = c3.W.data_ptr(), c3.b.data_ptr(), c1.W.data_ptr(), c1.b.data_ptr()
@@ -313,7 +342,7 @@ class WMEncodecModel:
         gins = [torch.empty(B, T, 4 * Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
         hbufs = [torch.empty(2, rows, Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
         cbufs = [torch.empty(B, Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
-        outs = [self._alloc_for(B, T, Cc, nxt) if l == nl - 1 else TM(B, T, Cc, 0, 0, dev) for l in range(nl)]
+        outs = [self._alloc_for(B, T, Cc, nxt, x.lens) if l == nl - 1 else TM(B, T, Cc, 0, 0, dev) for l in range(nl)]
 
         def in_gemm(l, t0, t1):                                        # gin_l[:, t0:t1] = in_l[:, t0:t1] W_ih^T + b
             src_ptr, src_bs = (x.interior, x.bstride) if l == 0 else (outs[l - 1].interior, outs[l - 1].bstride)
@@ -423,11 +452,11 @@ class WMEncodecModel:
                 x = self._lstm(obj, x, nxt)
         return x
 
-    def _input_tm(self, wav: torch.Tensor, first) -> TM:
+    def _input_tm(self, wav: torch.Tensor, first, lens: Optional[Ragged] = None) -> TM:
         """[B,1,T] -> time-major buffer with the first node's halo."""
         assert wav.dim() == 3 and wav.shape[1] == self.channels == 1, wav.shape
         B, _, T = wav.shape
-        x = self._alloc_for(B, T, 1, first)
+        x = self._alloc_for(B, T, 1, first, lens)
         x.data[:, x.padL: x.padL + T, 0] = wav[:, 0].to(self.device, torch.float32)
         self._fill_pads(x)
         return x
@@ -454,14 +483,17 @@ class WMEncodecModel:
         """Code ids on the device as int32, range-checked once for the whole batch (before it is cut into lanes)."""
         assert codes.dim() == 3
         c32 = codes.to(self.device, torch.int32).contiguous()
-        if c32.numel() > 0 and (int(c32.max()) >= self.cfg.bins or int(c32.min()) < 0):
-            raise IndexError("index out of range in self")            # what F.embedding raises in the reference (core_vq.py:175)
+        if c32.numel() > 0:
+            lo, hi = torch.aminmax(c32)                               # one kernel; the two scalars come back in one wait
+            lo_hi = torch.stack([lo, hi]).tolist()
+            if lo_hi[1] >= self.cfg.bins or lo_hi[0] < 0:
+                raise IndexError("index out of range in self")        # what F.embedding raises in the reference (core_vq.py:175)
         return c32
 
-    def _dequant(self, c32: torch.Tensor, nxt) -> TM:
+    def _dequant(self, c32: torch.Tensor, nxt, lens: Optional[Ragged] = None) -> TM:
         B, K, T = c32.shape
         c32 = c32.contiguous()
-        out = self._alloc_for(B, T, self.cfg.dimension, nxt)
+        out = self._alloc_for(B, T, self.cfg.dimension, nxt, lens)
         _lib.check(self.lib.ssrhip_rvq_decode(c32.data_ptr(), self.codebooks.data_ptr(), out.interior, B, T, self.cfg.dimension, K,
                                               self.cfg.bins, out.bstride, self._s()), "ssrhip_rvq_decode")
         self._fill_pads(out)
@@ -490,55 +522,153 @@ class WMEncodecModel:
 
         return self._join(self._in_lanes(c32.shape[0], body), 0)
 
+    # ------------------------------------------------------------------ ragged batches (items of different lengths in one pass)
+    # cost model of one dense pass over a bucket, in microseconds per frame of its longest item: every frame is one LSTM time step
+    # of each layer (a latency-bound launch whose cost hardly depends on the batch) + the convolutions' share per item
+    # (profiles/r02_codec_b32_kernel_trace_summary.md: ~10 us per step and layer; 85 ms / (32 items x 1500 frames) per item)
+    RAGGED_STEP_US = 20.0
+    RAGGED_ITEM_US = 1.8
+    RAGGED_MAX_FRAMES = 256 * 1500          # items x frames of one dense pass (memory: ~0.3 GB per 1500 frames in the decoder)
+
+    def _ragged_buckets(self, lens: Sequence[int], per_item_us: Optional[float] = None) -> List[List[int]]:
+        """Partition item indices into buckets that are decoded as ONE dense pass each (every item padded to its bucket's
+        longest). Optimal contiguous partition of the items sorted by length under the cost model above (O(n^2)): short items
+        ride along with long ones as long as the padding they add costs less than another pass's per-frame launch chain."""
+        order = sorted(range(len(lens)), key=lambda i: -int(lens[i]))
+        n = len(order)
+        item_us = self.RAGGED_ITEM_US if per_item_us is None else per_item_us
+        best = [0.0] + [float("inf")] * n           # best[j]: cost of the first j items (longest first)
+        cut = [0] * (n + 1)
+        for j in range(1, n + 1):
+            for i in range(j):                      # bucket = sorted items i .. j-1, its longest is item i
+                t_max, cnt = int(lens[order[i]]), j - i
+                if cnt > 1 and cnt * t_max > self.RAGGED_MAX_FRAMES:
+                    continue
+                c = best[i] + t_max * (self.RAGGED_STEP_US + item_us * cnt)
+                if c < best[j]:
+                    best[j], cut[j] = c, i
+        buckets, j = [], n
+        while j > 0:
+            buckets.append(order[cut[j]: j])
+            j = cut[j]
+        return buckets[::-1]
+
+    def _stack_ragged(self, items: Sequence[torch.Tensor], idx: Sequence[int], lead: int, dtype, fill=0) -> Tuple[torch.Tensor, List[int]]:
+        """items[i]: [1, *lead dims, T_i] (or without the leading 1) -> dense [len(idx), *lead, T_max] on the device + the lengths."""
+        ts = [items[i].reshape(*items[i].shape[-(lead + 1):]) for i in idx]
+        lens = [int(t.shape[-1]) for t in ts]
+        out = torch.full((len(idx),) + tuple(ts[0].shape[:-1]) + (max(lens),), fill, dtype=dtype, device=self.device)
+        for j, t in enumerate(ts):
+            out[j, ..., : lens[j]] = t.to(self.device, dtype)
+        return out, lens
+
+    @torch.no_grad()
+    def decode_ragged(self, codes: Sequence[torch.Tensor], scale=None) -> List[torch.Tensor]:
+        """Batched `decode` of items of DIFFERENT lengths: codes[i] is [1, K, T_i] (or [K, T_i]); returns the list of waveforms
+        [1, 1, T_i * hop]. Contract: result i == `decode(codes[i])` of that item alone (same arithmetic per output sample; the
+        LSTM step kernel is chosen by batch size, so the last bits may differ) — the SEANet convolutions are not causal, so every
+        layer gives each item its own halo right behind its own last row (`ssrhip_pad_ragged`) instead of padding to the longest.
+        The reference decodes one utterance at a time (inference_v2.py:331-358, wmencodec.py:341-356)."""
+        assert scale is None, "renormalize=False codec: scale must be None (wmencodec.py:199-203)"
+        out: List[Optional[torch.Tensor]] = [None] * len(codes)
+        hop = int(math.prod(self.cfg.ratios))
+        for idx in self._ragged_buckets([int(c.shape[-1]) for c in codes]):
+            dense, lens = self._stack_ragged(codes, idx, 1, torch.int64)
+            c32 = self._codes32(dense)
+            rg = Ragged(lens, self.device) if min(lens) != max(lens) else None
+            z = self._dequant(c32, self.decoder.nodes[0], rg)
+            wav = self._channel_major(self._run(self.decoder.nodes, z))
+            for j, i in enumerate(idx):
+                out[i] = wav[j: j + 1, :, : lens[j] * hop]
+        return out
+
+    @torch.no_grad()
+    def wmdecode_ragged(self, codes: Sequence[torch.Tensor], labels: Sequence[torch.Tensor], wavforms: Sequence[torch.Tensor], scale=None,
+                        with_mark: bool = True):
+        """Batched `wmdecode` of items of different lengths (see `decode_ragged`): codes[i] [1,K,T_i], labels[i] [1,T_i],
+        wavforms[i] [1,1,T_i*hop]. Returns (list of wav [1,1,T_i*hop], list of mark [1,T_i,2] or None)."""
+        assert scale is None and self.has_wm
+        hop = int(math.prod(self.cfg.ratios))
+        n = len(codes)
+        assert len(labels) == n and len(wavforms) == n
+        wavs: List[Optional[torch.Tensor]] = [None] * n
+        marks: List[Optional[torch.Tensor]] = [None] * n
+        for i in range(n):
+            T = int(codes[i].shape[-1])
+            if int(labels[i].shape[-1]) != T or int(wavforms[i].shape[-1]) != T * hop:
+                raise ValueError(f"item {i}: {T} frames need {T} labels and {T * hop} samples, got {tuple(labels[i].shape)} / {tuple(wavforms[i].shape)}")
+        # 3x the decoder's work per item (skip encoder + decoder [+ detector]): the per-item share of the cost model scales with it
+        for idx in self._ragged_buckets([int(c.shape[-1]) for c in codes], per_item_us=3 * self.RAGGED_ITEM_US):
+            dense, lens = self._stack_ragged(codes, idx, 1, torch.int64)
+            lab, _ = self._stack_ragged(labels, idx, 0, torch.int64)
+            wv, _ = self._stack_ragged(wavforms, idx, 0, torch.float32)
+            rg = Ragged(lens, self.device) if min(lens) != max(lens) else None
+            w, m = self._wmdecode_dense(self._codes32(dense), self._labels32(lab), wv.unsqueeze(1), with_mark, rg)
+            for j, i in enumerate(idx):
+                wavs[i] = w[j: j + 1, :, : lens[j] * hop]
+                if m is not None:
+                    marks[i] = m[j: j + 1, : lens[j]]
+        return wavs, (marks if with_mark else None)
+
     def _concat_proj(self, j: int, skip: TM, labels32: torch.Tensor, rep: int, x: TM, nxt) -> TM:
         """wm_proj_j(ELU(cat(skip, wm_embed(labels upsampled)))) + x   (seanet.py:577-591) without building the concatenation:
         the 1x1 convolution splits into W_a . ELU(skip) + W_b . ELU(embed(label)); the second term has one value per label
         (`self.wm_cls[j]`, computed at load) and enters the GEMM's epilogue as a per-row class bias (include/ssrhip.h rbias)."""
         c, (Wa, cls) = self.wm_proj[j], self.wm_cls[j]
         assert skip.T == x.T and skip.C == Wa.shape[1] and labels32.shape[1] * rep >= skip.T, (skip.T, x.T, skip.C, Wa.shape, labels32.shape, rep)
-        out = self._alloc_for(skip.B, skip.T, c.Cout, nxt)
+        out = self._alloc_for(skip.B, skip.T, c.Cout, nxt, skip.lens)
         self._gemm(skip.interior, Wa, c.b, out.interior, skip.T, c.Cout, skip.C, skip.C, c.Cout, act_in=_lib.ACT_ELU, R=x.interior, ldr=x.C,
                    batch=skip.B, sA=skip.bstride, sC=out.bstride, sR=x.bstride, rowcls=(cls, labels32, rep))
         self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
         return out
+
+    def _labels32(self, labels: torch.Tensor) -> torch.Tensor:
+        """Watermark labels on the device as int32, range-checked like the code ids: they index the class-bias table in the GEMM
+        epilogue, where the reference's F.embedding (seanet.py:562) raises IndexError for an id outside the table."""
+        lab = labels.to(self.device, torch.int32).contiguous()
+        if lab.numel() > 0:
+            lo_hi = torch.stack(torch.aminmax(lab)).tolist()
+            if lo_hi[1] >= self.wm_table.shape[0] or lo_hi[0] < 0:
+                raise IndexError("index out of range in self")
+        return lab
 
     @torch.no_grad()
     def wmdecode(self, codes: torch.Tensor, labels: torch.Tensor, wavform: torch.Tensor, scale=None, with_mark: bool = True):
         """-> (wav [B,1,T], mark [B,T',2]) as wmencodec.py:358-375. `with_mark=False` skips the detector pass whose
         output `AudioTokenizer.wmdecode` discards (data/tokenizer.py:133) and returns mark=None."""
         assert scale is None and self.has_wm
+        lab_all = self._labels32(labels)
+        c32 = self._codes32(codes)
+        parts = self._in_lanes(c32.shape[0], lambda b0, b1: self._wmdecode_dense(c32[b0:b1], lab_all[b0:b1].contiguous(), wavform[b0:b1], with_mark, None))
+        return self._join(parts, 0), self._join(parts, 1)
+
+    def _wmdecode_dense(self, c32: torch.Tensor, lab: torch.Tensor, wavform: torch.Tensor, with_mark: bool, lens: Optional[Ragged]):
+        """One dense pass of the watermark decoder (seanet.py:555-600) over a batch; `lens` = per-item frame counts of a ragged batch."""
         r = list(self.cfg.ratios)
         assert len(r) == 4, "the watermark decoder's slicing (seanet.py:560-591) is written for 4 ratios"
-        lab_all = labels.to(self.device, torch.int32).contiguous()
-        c32 = self._codes32(codes)
         dec, senc = self.wmdecoder, self.skip_encoder
         cuts = [(0, 4), (4, 7), (7, 10), (10, None)]
         dn = [dec.slice_nodes(lo, hi) for lo, hi in cuts]
         reps = [r[0] * r[1] * r[2], r[0] * r[1], r[0], 1]
-
-        def body(b0, b1):
-            lab = lab_all[b0:b1].contiguous()
-            # skip features at 4 scales; every skip is consumed by a k=1 conv => no halo
-            z = self._run(senc.slice_nodes(0, 2), self._input_tm(wavform[b0:b1], senc.nodes[0]), after=senc.slice_nodes(2, 5)[0])
-            sk = []
-            for lo, hi in [(2, 5), (5, 8), (8, 11), (11, None)]:
-                nxt_nodes = senc.slice_nodes(hi, None) if hi is not None else []
-                z = self._run(senc.slice_nodes(lo, hi), z, after=(nxt_nodes[0] if nxt_nodes else None))
-                sk.append(z)
-            x = self._dequant(c32[b0:b1], None)
-            for j in range(4):
-                skip, rep = sk[3 - j], reps[3 - j]
-                out = self._concat_proj(j, skip, lab, rep, x, dn[j][0])
-                x = self._run(dn[j], out, after=None)
-            wav = self._channel_major(x)
-            if not with_mark:
-                return wav, None
-            m = self._run(self.wm_encoder.nodes, self._input_tm(wav, self.wm_encoder.nodes[0]), after=None)
-            mk = self._conv(self.wm_predictor, m, None)
-            return wav, mk.interior_view().contiguous()
-
-        parts = self._in_lanes(c32.shape[0], body)
-        return self._join(parts, 0), self._join(parts, 1)
+        lens_s = lens.scaled(int(math.prod(r))) if lens is not None else None
+        # skip features at 4 scales; every skip is consumed by a k=1 conv => no halo
+        z = self._run(senc.slice_nodes(0, 2), self._input_tm(wavform, senc.nodes[0], lens_s), after=senc.slice_nodes(2, 5)[0])
+        sk = []
+        for lo, hi in [(2, 5), (5, 8), (8, 11), (11, None)]:
+            nxt_nodes = senc.slice_nodes(hi, None) if hi is not None else []
+            z = self._run(senc.slice_nodes(lo, hi), z, after=(nxt_nodes[0] if nxt_nodes else None))
+            sk.append(z)
+        x = self._dequant(c32, None, lens)
+        for j in range(4):
+            skip, rep = sk[3 - j], reps[3 - j]
+            out = self._concat_proj(j, skip, lab, rep, x, dn[j][0])
+            x = self._run(dn[j], out, after=None)
+        wav = self._channel_major(x)
+        if not with_mark:
+            return wav, None
+        m = self._run(self.wm_encoder.nodes, self._input_tm(wav, self.wm_encoder.nodes[0], lens_s), after=None)
+        mk = self._conv(self.wm_predictor, m, None)
+        return wav, mk.interior_view().contiguous()
 
     @torch.no_grad()
     def detect_watermark(self, x: torch.Tensor) -> torch.Tensor:

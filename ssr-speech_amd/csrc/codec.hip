@@ -134,6 +134,31 @@ __global__ __launch_bounds__(256) void pad_reflect_kernel(float* buf, int T, int
   }
 }
 
+// Halo rows of a RAGGED batch: item b holds lens[b] <= T valid rows; the padR rows right behind ITS last valid row (partly inside
+// the interior of the dense buffer, whose producer wrote T rows for every item) and the padL rows in front get the value the
+// convolution's padding has for an item of that length alone: zeros, or the reflection about its own ends (conv.py:71-88, incl.
+// the zero extension of inputs shorter than the pad). Rows further right stay whatever the producer wrote: no valid output reads them.
+__global__ __launch_bounds__(256) void pad_ragged_kernel(float* buf, const int* __restrict__ lens, int T, int padL, int padR, int C,
+                                                         long bstride, int reflect) {
+  float* b = buf + (size_t)blockIdx.y * bstride;
+  const int Ti = min(max(lens[blockIdx.y], 0), T);
+  const int max_pad = padL > padR ? padL : padR;
+  const int Tx = Ti + ((reflect && Ti <= max_pad) ? max_pad - Ti + 1 : 0);
+  const long total = (long)((reflect ? padL : 0) + padR) * C;
+  const int nl = reflect ? padL : 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int p = (int)(i / C), c = (int)(i % C);
+    int dst, src;
+    if (p < nl) { dst = p; src = padL - p; }
+    else {
+      const int r = p - nl;
+      dst = padL + Ti + r;
+      src = (Ti + r < Tx) ? Ti + r : Tx - 2 - (Ti + r - Tx);
+    }
+    b[(size_t)dst * C + c] = (reflect && src >= 0 && src < Ti) ? b[(size_t)(padL + src) * C + c] : 0.f;
+  }
+}
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // One LSTM time step for B <= 4 items. Wave -> hidden unit j (4 gate rows j, C+j, 2C+j, 3C+j of W_hh).
@@ -604,6 +629,18 @@ extern "C" int ssrhip_pad_reflect(float* buf, int32_t B, int32_t T, int32_t padL
   const int extra = T <= max_pad ? max_pad - T + 1 : 0;                       // conv.py:79-83
   dim3 grid(nblocks((long)(padL + padR) * C), B);
   hipLaunchKernelGGL(pad_reflect_kernel, grid, dim3(256), 0, (hipStream_t)stream, buf, T, padL, padR, C, (long)bstride, extra);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ssrhip_pad_ragged(float* buf, const int32_t* lens, int32_t B, int32_t T, int32_t padL, int32_t padR, int32_t C, int64_t bstride,
+                                 int32_t reflect, ssrhip_stream_t stream) {
+  SSR_REQUIRE(buf && lens && B > 0 && T > 0 && C > 0 && padL >= 0 && padR >= 0, "ssrhip_pad_ragged: bad argument");
+  SSR_REQUIRE(B <= 65535, "ssrhip_pad_ragged: batch too large (%d)", B);
+  const long n = (long)((reflect ? padL : 0) + padR) * C;
+  if (n == 0) return 0;
+  dim3 grid(nblocks(n), B);
+  hipLaunchKernelGGL(pad_ragged_kernel, grid, dim3(256), 0, (hipStream_t)stream, buf, lens, T, padL, padR, C, (long)bstride, reflect);
   SSR_LAUNCH_CHECK();
   return 0;
 }

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import re
 import struct
-from typing import Any, List, Optional, Tuple
+from typing import Any, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -45,8 +45,8 @@ def codec_config_from_xp_cfg(cfg) -> CodecConfig:
     # Architecture switches this implementation does not have: refuse them instead of silently producing wrong audio / codes
     # (the reference ships e.g. config/model/encodec/encodec_base_causal.yaml). Absent keys mean the reference's defaults.
     fixed = [("encodec.causal", False), ("seanet.causal", False), ("encodec.renormalize", False), ("seanet.true_skip", True),
-             ("seanet.norm", "weight_norm"), ("seanet.activation", "ELU"), ("seanet.dilation_base", 2), ("seanet.final_activation", None),
-             ("seanet.n_residual_layers", 1), ("seanet.disable_norm_outer_blocks", 0)]
+             ("seanet.norm", "weight_norm"), ("seanet.activation", "ELU"), ("seanet.dilation_base", 2), ("seanet.decoder.final_activation", None),
+             ("seanet.decoder.trim_right_ratio", 1.0), ("seanet.n_residual_layers", 1), ("seanet.disable_norm_outer_blocks", 0)]
     for key, want in fixed:
         got = _cfg_get(cfg, key, want)
         if got != want and not (want is None and got in ("", "null", "None")):
@@ -175,6 +175,16 @@ class AudioTokenizer:
 
     def detect_watermark(self, wav: torch.Tensor):
         return self.codec.detect_watermark(wav.to(self.device))
+
+    # -- several utterances of different lengths in one pass (not in the reference, which decodes one at a time: inference_v2.py:331-358)
+    def decode_batch(self, frames: Sequence[torch.Tensor], scale=None) -> List[torch.Tensor]:
+        """frames[i]: [1, K, T_i] -> list of [1, 1, T_i * 320]; item i equals `decode(frames[i], scale)`."""
+        return self.codec.decode_ragged(list(frames), scale)
+
+    def wmdecode_batch(self, frames: Sequence[torch.Tensor], marks: Sequence[torch.Tensor], wavs: Sequence[torch.Tensor], scale=None) -> List[torch.Tensor]:
+        """item i equals `wmdecode(frames[i], marks[i], wavs[i], scale)`."""
+        out, _ = self.codec.wmdecode_ragged(list(frames), list(marks), list(wavs), scale, with_mark=False)
+        return out
 
 
 def tokenize_audio(tokenizer: AudioTokenizer, audio_path: str, offset=-1, num_frames=-1, multiple=320):

@@ -34,7 +34,7 @@ def _collective_device(hint=None) -> torch.device:
     return torch.device(hint) if hint is not None else torch.device("cpu")
 
 
-def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token: int, device=None) -> List[torch.Tensor]:
+def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token: int, device=None, force_collective: bool = False) -> List[torch.Tensor]:
     """local[i]: int tensor [K, T_i] of this rank's utterances (rank-contiguous shard of `n_total`).
     Returns the list of all `n_total` token tensors on every rank. One all_gather of lengths (n ints per
     rank) and one all_gather of a padded [n_max, K, T_max] int32 block (a few KB..100 KB per rank)."""
@@ -66,15 +66,18 @@ def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token
     return res
 
 
-def generate(model, utterances: Sequence[dict], seed: int = 0, pad_token: int = None, device=None, stats: dict = None, **decode_kw):
+def generate(model, utterances: Sequence[dict], seed: int = 0, pad_token: int = None, device=None, stats: dict = None,
+             force_collective: bool = False, **decode_kw):
     """BASELINE config 4 in one call: shard `utterances` (dicts {x, y, mask_interval}, see `SSR_Speech.inference_batch`)
     over the ranks of the default process group, decode this rank's shard in lock-step (up to 8 utterances x CFG rows per
     engine pass), and all-gather the generated codec tokens so that every rank holds all of them before codec decode.
     Utterance i uses the RNG stream `seed + i` whatever the world size. Returns (tokens, local) where tokens[i] is the int64
     [K, T_i'] result of utterance i (all utterances, every rank) and local = (lo, hi, the 4-tuples of this rank's shard)."""
     import torch.distributed as dist
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    in_group = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if in_group else 1
     rank = dist.get_rank() if world > 1 else 0
+    collective = world > 1 or (force_collective and in_group)
     lo, hi = shard_range(len(utterances), world, rank)
     import time
     t0 = time.perf_counter()
@@ -86,7 +89,7 @@ def generate(model, utterances: Sequence[dict], seed: int = 0, pad_token: int = 
     if stats is not None:           # wall time of this rank's lock-step decode (inference_batch ends on a device->host read)
         stats["decode_s"] = time.perf_counter() - t0
     # A rank that failed must not leave the others waiting in the all-gather: agree on success first (one tiny MIN all-reduce).
-    if world > 1:
+    if collective:
         ok = torch.tensor([0 if failure is not None else 1], dtype=torch.int32, device=_collective_device(device if device is not None else getattr(model, "device", None)))
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
@@ -100,7 +103,46 @@ def generate(model, utterances: Sequence[dict], seed: int = 0, pad_token: int = 
     if device is None:
         device = _collective_device(getattr(model, "device", None))
     t1 = time.perf_counter()
-    everyone = gather_tokens(toks, len(utterances), K, pad_token, device=device)
+    everyone = gather_tokens(toks, len(utterances), K, pad_token, device=device, force_collective=force_collective)
     if stats is not None:
         stats["allgather_s"] = time.perf_counter() - t1
     return everyone, (lo, hi, outs)
+
+
+def synthesize(model, audio_tokenizer, utterances: Sequence[dict], seed: int = 0, use_watermark: bool = False, tts: bool = True,
+               output_dir: str = None, names: Sequence[str] = None, sample_rate: int = 16000, stats: dict = None,
+               force_collective: bool = False, **decode_kw):
+    """The batched-TTS path end to end (BASELINE config 4; north_star: "a single RCCL all-gather ... to collect generated codec
+    tokens before wmencodec decode"): `generate` (shard -> lock-step decode -> all-gather of the tokens), then the codec decode is
+    again sharded by utterance: **rank r turns the utterances [lo, hi) of ITS OWN shard into waveforms** (one ragged pass of the
+    codec per length bucket, `render_many`), using the all-gathered tokens — so every rank could decode any slice, and the
+    waveforms of utterance i do not depend on the world size. No second collective: waveforms stay on the rank that made them
+    (written to `output_dir/{names[i]}.wav` when given).
+
+    utterances[i]: {x, y, mask_interval} as for `generate`, plus `wav` ([1, n] original 16 kHz audio, or a path) when
+    `use_watermark` (the watermark decoder's skip input, inference_scale.py:67-78).
+    Replaces the reference's per-sample loop inference_v2.py:331-358 + inference_scale.py:63-86.
+    Returns (waves, (lo, hi), tokens): waves[j] = waveform [1, 1, n] of utterance lo + j; tokens = all utterances' codes."""
+    import time
+    from .inference_scale import render_many
+    tokens, (lo, hi, outs) = generate(model, utterances, seed=seed, stats=stats, force_collective=force_collective, **decode_kw)
+    t0 = time.perf_counter()
+    dev = getattr(model, "device", None)
+    # the gathered tokens are the codec's input (what any rank could decode); marks / kept intervals are this rank's own
+    results = [(tokens[lo + j].unsqueeze(0).to(dev if dev is not None else tokens[lo + j].device), o[1], o[2], o[3]) for j, o in enumerate(outs)]
+    waves = []
+    if results:
+        audio = [u.get("wav") for u in utterances[lo:hi]] if use_watermark else None
+        waves = render_many(audio_tokenizer, results, None, audio, bool(use_watermark), bool(tts))
+    if output_dir is not None and waves:
+        import os
+        from .data.tokenizer import write_wav
+        os.makedirs(output_dir, exist_ok=True)
+        for j, w in enumerate(waves):
+            name = names[lo + j] if names is not None else f"utt{lo + j:05d}"
+            write_wav(os.path.join(output_dir, f"{name}.wav"), w[0].cpu(), sample_rate)
+    if stats is not None:
+        if waves and waves[0].is_cuda:
+            torch.cuda.synchronize(waves[0].device)
+        stats["codec_s"] = time.perf_counter() - t0
+    return waves, (lo, hi), tokens

@@ -61,16 +61,37 @@ def kept_audio_track(wav: torch.Tensor, n_frames: int, kept_new: Sequence, kept_
     return track.reshape(1, n_frames * hop)
 
 
-def _render(audio_tokenizer, codes, marks, kept_new, kept_old, scale, audio_fn, use_watermark: bool) -> torch.Tensor:
-    if not use_watermark:
-        return audio_tokenizer.decode(codes, scale)
-    wav, _sr = read_wav(audio_fn)
+def _watermark_inputs(codes, kept_new, kept_old, audio_fn) -> torch.Tensor:
+    """The skip-encoder input of `wmdecode` for one utterance (:67-78): [1, 1, frames * HOP] on the codes' device."""
+    wav, _sr = read_wav(audio_fn) if isinstance(audio_fn, str) else (audio_fn, None)
     short = -wav.shape[-1] % HOP                                             # zero-extend to whole frames, like the encode side
     if short:
         wav = F.pad(wav, (0, short))
-    track = kept_audio_track(wav, codes.shape[-1], kept_new, kept_old)
-    dev = codes.device
-    return audio_tokenizer.wmdecode(codes, marks.to(dev), track.unsqueeze(0).to(dev), scale)
+    return kept_audio_track(wav, codes.shape[-1], kept_new, kept_old).unsqueeze(0).to(codes.device)
+
+
+def _render(audio_tokenizer, codes, marks, kept_new, kept_old, scale, audio_fn, use_watermark: bool) -> torch.Tensor:
+    if not use_watermark:
+        return audio_tokenizer.decode(codes, scale)
+    return audio_tokenizer.wmdecode(codes, marks.to(codes.device), _watermark_inputs(codes, kept_new, kept_old, audio_fn), scale)
+
+
+def render_many(audio_tokenizer, results: Sequence[tuple], scale, audio_fns, use_watermark: bool, tts: bool):
+    """`_render` of several utterances in ONE pass of the codec per length bucket (`AudioTokenizer.decode_batch` /
+    `wmdecode_batch`: items of different lengths, each with its own halo, so waveform i equals `_render` of utterance i alone).
+    results[i] = the 4-tuple of `SSR_Speech.inference`; audio_fns = one path / [1, n] tensor for all, or a list with one per
+    utterance (only read with `use_watermark`). For `tts` the prompt part (the first kept interval) is cut off (:85-86)."""
+    if not isinstance(audio_fns, (list, tuple)):
+        audio_fns = [audio_fns] * len(results)
+    codes = [r[0] for r in results]
+    if not use_watermark:
+        waves = audio_tokenizer.decode_batch(codes, scale)
+    else:
+        tracks = [_watermark_inputs(c, kn, ko, fn) for (c, _m, kn, ko), fn in zip(results, audio_fns)]
+        waves = audio_tokenizer.wmdecode_batch(codes, [r[1].to(r[0].device) for r in results], tracks, scale)
+    if tts:
+        waves = [w[..., int(r[2][0][1]) * HOP:] for w, r in zip(waves, results)]
+    return waves
 
 
 @torch.no_grad()
@@ -92,11 +113,9 @@ def inference_samples(model, model_args, phn2num, text_tokenizer, audio_tokenize
                                     temperature=decode_config["temperature"], stop_repetition=decode_config["stop_repetition"],
                                     cfg_coef=cfg_coef, cfg_stride=cfg_stride, aug_text=aug_text, seed=seeds[0])
     log.info("AR decode of %d samples in lock-step: %.3f s", len(seeds), time.perf_counter() - t0)
-    waves = []
-    for codes, marks, kept_new, kept_old in results:
-        wave = _render(audio_tokenizer, codes, marks, kept_new, kept_old, scale, audio_fn, bool(use_watermark))
-        waves.append(wave[..., int(kept_new[0][1]) * HOP:] if tts else wave)
-    return waves
+    # all samples through the codec in one ragged pass (they differ in length; each keeps its own halo): same waveforms as one
+    # `_render` per sample, which is what the reference's loop does (inference_v2.py:331-358)
+    return render_many(audio_tokenizer, results, scale, audio_fn, bool(use_watermark), bool(tts))
 
 
 @torch.no_grad()

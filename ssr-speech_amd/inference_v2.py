@@ -116,12 +116,16 @@ def main(argv=None):
         from .data.resample import resample
         wav, sr = resample(wav, sr, args.codec_audio_sr).cpu(), args.codec_audio_sr
     audio_dur = wav.shape[-1] / sr
+    # From here on the utterance is the CONVERTED audio (mono, codec rate), in both modes: the reference overwrites `audio_fn` with
+    # the 16 kHz mono file it writes to temp_folder (:216-219), and tokenize_audio / the watermark glue / `_orig.wav` all read that
+    # file — never the original-rate input (whose 320-sample hops would not be codec frames).
+    work_dir = args.temp_folder or args.output_dir
+    os.makedirs(work_dir, exist_ok=True)
     if args.tts:
         cut = args.prompt_end if args.prompt_end is not None else float(args.prompt_length)
         cut = min(cut, audio_dur)
         n = int(cut * sr)
-        audio_fn = os.path.join(args.temp_folder or args.output_dir, f"{args.savename}_prompt.wav")
-        os.makedirs(os.path.dirname(audio_fn), exist_ok=True)
+        audio_fn = os.path.join(work_dir, f"{args.savename}_prompt.wav")
         write_wav(audio_fn, wav[:, :n], sr)
         frames = round(n / sr * args.codec_sr)
         mask_interval = torch.LongTensor([[frames, frames]])                         # :320-326: empty span at the prompt's end
@@ -130,7 +134,8 @@ def main(argv=None):
     else:
         if args.mask_start is None or args.mask_end is None:
             raise SystemExit("speech editing without WhisperX needs --mask_start and --mask_end (seconds)")
-        audio_fn = args.orig_audio
+        audio_fn = os.path.join(work_dir, f"{args.savename}_16k.wav")
+        write_wav(audio_fn, wav, sr)
         s = max(args.mask_start - args.sub_amount, 0.0)                              # :307-312 (margins around the edited words)
         e = min(args.mask_end + args.sub_amount, audio_dur)
         morphed_span = [[s, e]]                                                      # :312-317 (one span: no WhisperX word alignment here)

@@ -144,3 +144,52 @@ def test_generate_failure_on_one_rank_raises_on_all_ranks():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, "another"), (1, "this")]
+
+
+class _StubTokenizer:
+    """Stands in for `AudioTokenizer` on the CPU: a waveform that depends only on the utterance's own codes."""
+
+    def decode_batch(self, frames, scale=None):
+        return [f.to(torch.float32).sum(1, keepdim=True).repeat_interleave(320, dim=-1) for f in frames]
+
+
+class _StubModelMasks(_StubModel):
+    def inference_batch(self, utterances, seed=0, first_index=0, **kw):
+        return [(r, torch.zeros(1, r.shape[-1], dtype=torch.long), [(0, 2)], [(0, 2)]) for r, _, _, _ in super().inference_batch(utterances, seed, first_index, **kw)]
+
+
+def _synth_worker(rank, world, port, n_total, outdir, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    utts = [dict(x=torch.zeros(1, 4 + i, dtype=torch.long)) for i in range(n_total)]
+    stats = {}
+    waves, (lo, hi), toks = dp.synthesize(_StubModelMasks(), _StubTokenizer(), utts, seed=40, tts=True, output_dir=outdir, stats=stats)
+    ref = _StubModelMasks().inference_batch(utts, seed=40, first_index=0)      # what ONE process would produce
+    ref_w = [w[..., 2 * 320:] for w in _StubTokenizer().decode_batch([r[0] for r in ref])]
+    ok = (lo, hi) == dp.shard_range(n_total, world, rank) and len(waves) == hi - lo and len(toks) == n_total \
+        and all(torch.equal(waves[j], ref_w[lo + j]) for j in range(hi - lo)) and "codec_s" in stats \
+        and all(os.path.exists(os.path.join(outdir, f"utt{i:05d}.wav")) for i in range(lo, hi))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [7, 1])
+def test_synthesize_world2_each_rank_decodes_its_own_slice(n_total, tmp_path):
+    """`dp.synthesize` on 2 ranks: tokens are all-gathered, then rank r renders the waveforms of ITS shard [lo, hi) only; together
+    the two ranks produce exactly the waveforms (and files) one process would (incl. an empty shard: n_total = 1)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_synth_worker, args=(r, 2, port, n_total, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+    assert sorted(os.listdir(tmp_path)) == [f"utt{i:05d}.wav" for i in range(n_total)]

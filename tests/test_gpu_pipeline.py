@@ -272,3 +272,41 @@ def test_cli_accepts_a_24k_stereo_prompt(tmp_path):
     # the 16 kHz file went through one more 16-bit quantisation than the in-memory resampled prompt: greedy tokens may differ by that; shapes may not
     assert outs["a"].shape[0] == 1 and outs["a"].shape[1] % 320 == 0 and outs["a"].shape[1] > 0
     assert read_wav(str(tmp_path / "a" / "utt_orig.wav"))[1] == 16000
+
+
+def test_cli_edit_with_watermark_on_a_24k_stereo_prompt_uses_the_converted_audio(tmp_path):
+    """in the edit (non --tts) branch the CLI must hand the CONVERTED audio (mono, 16 kHz; the reference
+    overwrites audio_fn with it, inference_v2.py:216-219) to tokenize_audio, to the watermark glue (`kept_audio_track` slices it in
+    320-sample frames) and to `_orig.wav` — not the original-rate stereo file. A 24 kHz stereo prompt therefore gives exactly the
+    outputs of the 16 kHz mono file the resampler makes of it (amplitudes < 0.5 so that 16-bit re-quantisation is idempotent)."""
+    from ssr_speech_amd import inference_v2 as CLI
+    from ssr_speech_amd.data.resample import resample
+    from ssr_speech_amd.data.tokenizer import read_wav
+    ccfg = W.CodecConfig(dimension=64, n_filters=8, ratios=(8, 5, 4, 2), bins=64)
+    csd = W.codec_state_dict(ccfg, seed=7)
+    args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
+    lsd = W.lm_state_dict(args, seed=8)
+    for k in range(4):
+        lsd[f"predict_layer.{k}.2.bias"][64:] = -30.0
+    phn2num = {c: i for i, c in enumerate("abcdefghijklmnopqrstuvwxyz")}
+    lm_ckpt, codec_ckpt = str(tmp_path / "lm.pth"), str(tmp_path / "codec.th")
+    torch.save({"config": argparse.Namespace(**vars(args)), "model": lsd, "phn2num": phn2num}, lm_ckpt)
+    torch.save({"codec_config": {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(ccfg).items()}, "model": csd}, codec_ckpt)
+    g = torch.Generator().manual_seed(4)
+    stereo24 = torch.randn(2, 36 * 320, generator=g).clamp(-3, 3) * 0.05          # 0.48 s at 24 kHz -> 24 frames at 16 kHz
+    fn24, fn16 = str(tmp_path / "orig24.wav"), str(tmp_path / "orig16.wav")
+    write_wav(fn24, stereo24, 24000)
+    q24, _ = read_wav(fn24)
+    write_wav(fn16, resample(q24.mean(0, keepdim=True), 24000, 16000).cpu(), 16000)
+    ids = lambda t: ",".join(str(phn2num[c]) for c in t if c != " ")
+    outs = {}
+    for name, fn in (("a", fn24), ("b", fn16)):
+        CLI.main(["--model_path", lm_ckpt, "--codec_path", codec_ckpt, "--orig_audio", fn, "--orig_transcript", "hello world", "--target_transcript", "again",
+                  "--output_dir", str(tmp_path / name), "--temp_folder", str(tmp_path / ("tmp" + name)), "--savename", "utt", "--seed", "5", "--top_k", "1",
+                  "--top_p", "1.0", "--cfg_stride", "2", "--aug_text", "--use_watermark", "--mask_start", "0.20", "--mask_end", "0.30",
+                  "--phoneme_ids", ids("again"), "--prompt_phoneme_ids", ids("hello world")])
+        outs[name] = (read_wav(str(tmp_path / name / "utt_new_seed5.wav")), read_wav(str(tmp_path / name / "utt_orig.wav")))
+    (new_a, sr_a), (orig_a, osr_a) = outs["a"]
+    (new_b, _), (orig_b, _) = outs["b"]
+    assert sr_a == 16000 and osr_a == 16000 and orig_a.shape == (1, 24 * 320)
+    assert torch.equal(orig_a, orig_b) and new_a.shape == new_b.shape and torch.equal(new_a, new_b)
