@@ -37,9 +37,13 @@ def _collective_device(hint=None) -> torch.device:
 def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token: int, device=None, force_collective: bool = False) -> List[torch.Tensor]:
     """local[i]: int tensor [K, T_i] of this rank's utterances (rank-contiguous shard of `n_total`).
     Returns the list of all `n_total` token tensors on every rank. One all_gather of lengths (n ints per
-    rank) and one all_gather of a padded [n_max, K, T_max] int32 block (a few KB..100 KB per rank)."""
+    rank) and one all_gather of a padded [n_max, K, T_max] int32 block (a few KB..100 KB per rank). A world of one returns the
+    local list without a collective unless `force_collective` (tests: a 1-rank nccl group then issues the very RCCL calls an
+    8-GPU job issues)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return [t.clone() for t in local]
+    if dist.get_world_size() == 1 and not force_collective:
         return [t.clone() for t in local]
     world, rank = dist.get_world_size(), dist.get_rank()
     if device is None:

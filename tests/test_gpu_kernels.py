@@ -556,6 +556,48 @@ def test_gemm_matches_torch(L, M, N, K, act, res):
     torch.testing.assert_close(dC.cpu(), ref, rtol=3e-5, atol=3e-5)
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(3000, 2056, 1000, 2, 1), (2300, 1280, 36, 0, 0), (50000, 128, 260, 1, 0)])
+def test_gemm_pipelined_tile_matches_torch(L, M, N, K, act, res):
+    """Shapes whose 128 x 128 tiling fills the GPU (>= 384 workgroups) take `gemm_pipe_kernel` (128 x 128 x 32, two LDS buffers,
+    XCD-aware tile order): ragged M / N tiles, a K that is no multiple of the 32-wide k-tile (incl. K < 64), every epilogue."""
+    test_gemm_matches_torch(L, M, N, K, act, res)
+
+
+def test_gemm_batched_strided_view_with_every_codec_extension(L):
+    """The codec's use of ssrhip_gemm in one call (include/ssrhip.h ssrhip_gemm_args): batch in grid.z with per-item strides, A a
+    STRIDED VIEW (lda < K: the im2col rows of a stride-2 convolution overlap), ELU on load, skip tensor R, the transposed
+    convolution's time mask, and the per-row class bias — large enough for the pipelined tile, against plain torch ops."""
+    g = torch.Generator().manual_seed(77)
+    B, Cin, k, s, Cout, T = 3, 32, 4, 2, 160, 20000
+    rows = T * s + k                                            # time rows of the (already padded) input
+    x = torch.randn(B, rows, Cin, generator=g)
+    Wt = torch.randn(Cout, k * Cin, generator=g) / math.sqrt(k * Cin)
+    bias = torch.randn(Cout, generator=g)
+    R = torch.randn(B, T, Cout, generator=g)
+    cls_bias = torch.randn(2, Cout, generator=g)
+    rep = 50
+    cls = torch.randint(0, 2, (B, T // rep), generator=g, dtype=torch.int32)
+    view = torch.stack([F.elu(x)[:, t * s: t * s + k].reshape(B, k * Cin) for t in range(0, T, 997)], 1)     # spot rows of the im2col matrix
+    ref_rows = list(range(0, T, 997))
+    ref = view @ Wt.t() + bias + R[:, ref_rows] + cls_bias[cls.long()[:, [t // rep for t in ref_rows]]]
+    dx, dW, db, dR, dcb, dcl = dev(x), dev(Wt), dev(bias), dev(R), dev(cls_bias), dev(cls)
+    out = torch.full((B, T, Cout), -7.0, device="cuda")
+    a = _lib.GemmArgs()
+    a.A, a.W, a.bias, a.C = dx.data_ptr(), dW.data_ptr(), db.data_ptr(), out.data_ptr()
+    a.M, a.N, a.K, a.lda, a.ldc = T, Cout, k * Cin, s * Cin, Cout
+    a.act_in, a.R, a.ldr, a.batch = _lib.ACT_ELU, dR.data_ptr(), Cout, B
+    a.strideA, a.strideC, a.strideR = rows * Cin, T * Cout, T * Cout
+    a.rbias, a.rclass, a.rrep, a.rclass_stride = dcb.data_ptr(), dcl.data_ptr(), rep, T // rep
+    lo, hi = 3, T - 5                                           # time mask in units of tm_c = Cout floats: rows outside [lo, hi) stay untouched
+    a.tm_c, a.tm_lo, a.tm_hi = Cout, lo, hi
+    _lib.check(L.ssrhip_gemm(C.byref(a), _lib.stream_ptr()))
+    sync()
+    got = out.cpu()
+    keep = [i for i, t in enumerate(ref_rows) if lo <= t < hi]
+    torch.testing.assert_close(got[:, [ref_rows[i] for i in keep]], ref[:, keep], rtol=3e-5, atol=3e-5)
+    assert (got[:, :lo] == -7.0).all() and (got[:, hi:] == -7.0).all()
+
+
 def test_gemm_is_transpose_safe(L):
     """A = I with an ASYMMETRIC W: catches a swapped C/D lane map (cdna guide §3)."""
     n = 96
