@@ -207,9 +207,14 @@ def rtf_leg(model, args_lm, dev, tmpdir):
 
 
 def dp64_leg(model, args_lm, dev, world, rank, dist):
-    """BASELINE config 4 through `dp.generate`: the code path tests/test_dp_gloo.py covers."""
-    from ssr_speech_amd import dp
+    """BASELINE config 4 end to end through `dp.synthesize`: shard -> lock-step decode (8 utterances x CFG per engine
+    pass) -> all-gather of the tokens -> every rank renders the waveforms of its own shard in one ragged pass of the wmencodec decoder
+    (the code path tests/test_dp_gloo.py and tests/test_gpu_ragged.py cover)."""
+    from ssr_speech_amd import dp, weights as W
+    from ssr_speech_amd.data.tokenizer import AudioTokenizer
     import zlib
+    ccfg = W.codec_config_full()
+    tok = AudioTokenizer(device=dev, config=ccfg, state_dict=W.codec_state_dict(ccfg, seed=0))
     utts = []
     for i in range(64):
         gx = torch.Generator().manual_seed(1000 + i)
@@ -217,32 +222,50 @@ def dp64_leg(model, args_lm, dev, world, rank, dist):
         utts.append({"x": torch.randint(0, 100, (1, 67), generator=gx), "y": torch.randint(0, 2048, (1, 150, 4), generator=gy),
                      "mask_interval": torch.LongTensor([[[150, 150]]])})
     kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, cfg_coef=1.5, cfg_stride=5, aug_text=True)
+    lo, hi = dp.shard_range(64, world, rank)
+    if hi > lo:        # untimed: the codec's kernels and allocator blocks for this shard's decode shape (the LM engine warmed up in the rtf leg / first pass)
+        tok.decode_batch([torch.zeros(1, 4, 520, dtype=torch.long, device=dev)] * (hi - lo))
     stats = {}
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    toks, (lo, hi, _) = dp.generate(model, utts, seed=0, device=dev, stats=stats, **kw)
+    waves, (lo, hi), toks = dp.synthesize(model, tok, utts, seed=0, tts=True, stats=stats, device=dev, **kw)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t1 = time.perf_counter()
     wall = t1 - t0
     if dist is not None:
-        tt = torch.tensor([wall, stats["decode_s"]], device=dev, dtype=torch.float64)
+        tt = torch.tensor([wall, stats["decode_s"], stats["codec_s"]], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, dec = float(tt[0]), float(tt[1])
+        wall, dec, cod = float(tt[0]), float(tt[1]), float(tt[2])
     else:
-        dec = stats["decode_s"]
+        dec, cod = stats["decode_s"], stats["codec_s"]
     n_new = sum(int(t.shape[1]) - 150 for t in toks)
     crc = 0
     for t in toks:
         crc = zlib.crc32(t.cpu().numpy().astype("<i8").tobytes(), crc)
-    return {"workload": "64 utterances, L=67, 150-frame prompts, greedy + CFG (stride 5), <= 8 utterances x 2 rows per engine pass",
+    # waveforms stay on the rank that rendered them; their CRCs are combined in utterance order on rank 0 (a few bytes per utterance)
+    wcrc = torch.zeros(64, dtype=torch.int64, device=dev)
+    wlen = torch.zeros(64, dtype=torch.int64, device=dev)
+    for j, w in enumerate(waves):
+        wcrc[lo + j] = zlib.crc32(w.detach().cpu().numpy().astype("<f4").tobytes())
+        wlen[lo + j] = w.shape[-1]
+    if dist is not None:
+        dist.all_reduce(wcrc, op=dist.ReduceOp.SUM)
+        dist.all_reduce(wlen, op=dist.ReduceOp.SUM)
+    wav_crc = zlib.crc32(wcrc.cpu().numpy().astype("<i8").tobytes())
+    gen_s = float(wlen.sum()) / 16000.0
+    return {"workload": "64 utterances, L=67, 150-frame prompts, greedy + CFG (stride 5), <= 8 utterances x 2 rows per engine pass; "
+                        "tokens all-gathered, then every rank renders its own shard's waveforms (ragged wmencodec decode, prompt cut off)",
             "n_gpus": world, "utterances_per_gpu": (64 + world - 1) // world, "new_frames_total": n_new,
-            "wall_ms": round(1000 * wall, 1), "decode_ms_max_rank": round(1000 * dec, 1), "allgather_ms": round(1000 * stats["allgather_s"], 3),
+            "wall_ms_with_codec": round(1000 * wall, 1), "decode_ms_max_rank": round(1000 * dec, 1), "allgather_ms": round(1000 * stats["allgather_s"], 3),
+            "codec_ms_max_rank": round(1000 * cod, 1), "generated_audio_s": round(gen_s, 2), "rtf": round(wall / max(gen_s, 1e-9), 5),
             "codec_tokens_per_s_per_gpu": round(4 * n_new / dec / world, 1), "codec_tokens_per_s_total": round(4 * n_new / wall, 1),
-            "tokens_crc32": f"{crc:08x}"}
+            "tokens_crc32": f"{crc:08x}", "wav_crc32": f"{wav_crc:08x}",
+            "note": "tokens_crc32 is identical for every world size by construction (utterance i uses seed + i); wav_crc32 (CRC of the per-utterance fp32 "
+                    "waveform CRCs) is too as long as every rank's shard takes the same LSTM step kernel (batches of 5..112 items all do)"}
 
 
 def codec256_leg(dev, world, rank, dist, all_ok=lambda ok: ok):
@@ -280,12 +303,40 @@ def codec256_leg(dev, world, rank, dist, all_ok=lambda ok: ok):
         err = e
     if not all_ok(err is None):
         raise RuntimeError(f"codec256 failed on {'this' if err is not None else 'another'} rank: {err!r}")
+    # wmdecode (the --use_watermark product path, seanet.py:555-600; SURVEY §8d config 5: marks = second half ones), without and with
+    # the detector pass. Its skip encoder keeps four feature maps alive beside the decoder's activations: run in 4 batch lanes
+    # (WMEncodecModel.lanes: same results, a quarter of the peak memory at 2-4 % of the throughput).
+    wm_ms = {}
+    peak_plain = torch.cuda.max_memory_allocated()
+    try:
+        del out
+        torch.cuda.empty_cache()
+        m.lanes = 4 if B >= 32 else 1
+        marks = torch.zeros(B, codes.shape[-1], dtype=torch.long, device=dev)
+        marks[:, codes.shape[-1] // 2:] = 1
+        for with_mark in (False, True):
+            m.wmdecode(codes, marks, wav, with_mark=with_mark)       # untimed pass (allocator)
+            torch.cuda.synchronize()
+            w0 = time.perf_counter()
+            out, _mk = m.wmdecode(codes, marks, wav, with_mark=with_mark)
+            torch.cuda.synchronize()
+            wm_ms[with_mark] = time.perf_counter() - w0
+            del _mk
+    except Exception as e:                                 # noqa: BLE001
+        err = e
+    if not all_ok(err is None):
+        raise RuntimeError(f"codec256 wmdecode failed on {'this' if err is not None else 'another'} rank: {err!r}")
     if dist is not None:
-        tt = torch.tensor([enc, dec], device=dev, dtype=torch.float64)
+        tt = torch.tensor([enc, dec, wm_ms[False], wm_ms[True]], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        enc, dec = float(tt[0]), float(tt[1])
+        enc, dec, wm_ms[False], wm_ms[True] = (float(v) for v in tt)
     GF, audio_s = 6.97e9, 256 * 30.0
     return {"workload": f"256 clips x 30 s, {B} per GPU, full wmencodec config, synthetic weights", "n_gpus": world,
+            "wmdecode_ms": round(1000 * wm_ms[False], 1), "wmdecode_with_detector_ms": round(1000 * wm_ms[True], 1),
+            "wmdecode_tflops_per_gpu": round(14.5e9 * audio_s / wm_ms[False] / 1e12 / world, 1),
+            "wmdecode_with_detector_tflops_per_gpu": round(21.69e9 * audio_s / wm_ms[True] / 1e12 / world, 1),
+            "wmdecode_note": f"marks = second half ones; {m.lanes} batch lane(s); 14.5 / 21.69 GFLOP per audio-second without / with the detector (SURVEY 8d)",
+            "peak_mem_gib_encode_decode": round(peak_plain / 2 ** 30, 1),
             "encode_ms": round(1000 * enc, 1), "decode_ms": round(1000 * dec, 1),
             "encode_audio_s_per_s": round(audio_s / enc, 1), "decode_audio_s_per_s": round(audio_s / dec, 1),
             "encode_tflops_per_gpu": round(GF * audio_s / enc / 1e12 / world, 1), "decode_tflops_per_gpu": round(GF * audio_s / dec / 1e12 / world, 1),

@@ -1,6 +1,7 @@
 """wmencodec throughput on one MI355X (BASELINE config 5 shape: 16 kHz x 30 s clips, full SEANet config, synthetic weights):
-encode (SEANet encoder + LSTM + RVQ search) and decode (dequant + LSTM + SEANet decoder), per chunk of B clips.
-Usage: python tools/codec_bench.py [B] [seconds]"""
+encode (SEANet encoder + LSTM + RVQ search), decode (dequant + LSTM + SEANet decoder) and — with `wm` — wmdecode (skip encoder +
+label-conditioned decoder, with and without the detector pass; marks = second half ones), per chunk of B clips.
+Usage: python tools/codec_bench.py [B] [seconds] [wm] [lanes]"""
 import os
 import sys
 import time
@@ -28,3 +29,22 @@ audio_s = B * secs
 GF = 6.97      # GFLOP per audio-second, encode and decode each
 print(f"B={B} x {secs:.0f}s: encode {1000*(t1-t0):.1f} ms ({audio_s/(t1-t0):.0f} audio-s/s, {GF*audio_s/(t1-t0)/1e3:.1f} TFLOP/s) | "
       f"decode {1000*(t2-t1):.1f} ms ({audio_s/(t2-t1):.0f} audio-s/s, {GF*audio_s/(t2-t1)/1e3:.1f} TFLOP/s) | peak mem {torch.cuda.max_memory_allocated()/1e9:.1f} GB")
+if len(sys.argv) > 3 and sys.argv[3] == "wm":
+    if len(sys.argv) > 4:
+        m.lanes = int(sys.argv[4])
+    Tf = codes.shape[-1]
+    marks = torch.zeros(B, Tf, dtype=torch.long, device="cuda")
+    marks[:, Tf // 2:] = 1
+    del out, emb
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    for with_mark, gf in ((False, 14.5), (True, 21.69)):            # GFLOP per audio-second
+        m.wmdecode(codes, marks, wav, with_mark=with_mark)           # untimed pass: allocator holds the blocks
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        w, mk = m.wmdecode(codes, marks, wav, with_mark=with_mark)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        print(f"B={B} x {secs:.0f}s: wmdecode(with_mark={with_mark}, lanes={m.lanes}) {1000*(t1-t0):.1f} ms ({audio_s/(t1-t0):.0f} audio-s/s, "
+              f"{gf*audio_s/(t1-t0)/1e3:.1f} TFLOP/s of {gf} GFLOP/audio-s) | peak mem {torch.cuda.max_memory_allocated()/1e9:.1f} GB")
+        del w, mk
