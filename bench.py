@@ -268,6 +268,40 @@ def dp64_leg(model, args_lm, dev, world, rank, dist):
                     "waveform CRCs) is too as long as every rank's shard takes the same LSTM step kernel (batches of 5..112 items all do)"}
 
 
+def dp64_ragged_leg(model, args_lm, dev):
+    """Continuous batching vs lock-step groups (one GPU): 64 utterances whose text length is uniform in 20..120 phonemes (so that the
+    reference's 10 x L cap ends them after ~45..1045 steps), 150-frame prompts, greedy + CFG, 8 utterance slots. Same tokens either way."""
+    import zlib
+    g = torch.Generator().manual_seed(77)
+    utts = []
+    for i in range(64):
+        L = int(torch.randint(20, 121, (1,), generator=g))
+        utts.append({"x": torch.randint(0, 100, (1, L), generator=g), "y": torch.randint(0, 2048, (1, 150, 4), generator=g),
+                     "mask_interval": torch.LongTensor([[[150, 150]]])})
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, cfg_coef=1.5, cfg_stride=5, aug_text=True)
+    out = {"workload": "64 utterances, L uniform in 20..120, 150-frame prompts, greedy + CFG (stride 5), 8 utterance slots x 2 rows, one GPU"}
+    crcs = []
+    for name, refill in (("lockstep_groups", False), ("refill", True), ("lockstep_groups", False), ("refill", True)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = model.inference_batch(utts, seed=0, refill=refill, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_new = sum(int(r[0].shape[-1]) - 150 for r in res)
+        crc = 0
+        for r in res:
+            crc = zlib.crc32(r[0].cpu().numpy().astype("<i8").tobytes(), crc)
+        crcs.append(crc)
+        tps = 4 * n_new / dt
+        if name + "_tokens_per_s" not in out or tps > out[name + "_tokens_per_s"]:
+            out[name + "_tokens_per_s"], out[name + "_wall_ms"] = round(tps, 1), round(1000 * dt, 1)
+        out["new_frames_total"] = n_new
+    out["speedup"] = round(out["refill_tokens_per_s"] / out["lockstep_groups_tokens_per_s"], 3)
+    out["same_tokens"] = len(set(crcs)) == 1
+    out["tokens_crc32"] = f"{crcs[0]:08x}"
+    return out
+
+
 def codec256_leg(dev, world, rank, dist, all_ok=lambda ok: ok):
     """BASELINE config 5: encode + decode of 256 clips x 30 s (16 kHz), 256 / N clips per rank, no collective."""
     from ssr_speech_amd import dp, weights as W
@@ -529,6 +563,8 @@ def main():
                 with tempfile.TemporaryDirectory() as td:
                     leg("rtf_10s_tts", lambda: rtf_leg(model, args_lm, dev, td))
             leg("dp64", lambda: dp64_leg(model, args_lm, dev, world, rank, dist))
+            if world == 1:
+                leg("dp64_ragged", lambda: dp64_ragged_leg(model, args_lm, dev))
             model._invalidate()
             del model
             torch.cuda.empty_cache()

@@ -128,7 +128,8 @@ int ssrhip_attn_rows(const ssrhip_attn_args* a, float* out /* [R][n_head*head_di
  * sequence s are rows seq_start[s] .. seq_start[s+1]-1 of q / out (positions 0 .. len-1, in order); K/V are read from the paged
  * cache (already scattered there), a query at position i sees keys 0..i. K/V tiles are staged in LDS once per 128 queries and
  * both products run on the matrix core (fp32). Uses a->q, q_stride, kv, layer, scale; `seq_start` is a DEVICE array of n_seq+1
- * ints, `max_len` an upper bound of the sequence lengths (grid size). out is row-major [R][n_head*head_dim]. */
+ * ints, `max_len` an upper bound of the sequence lengths (grid size). out is row-major [R][n_head*head_dim]. Segment s reads the cache
+ * of sequence a->row_seq[seq_start[s]] (row_seq == NULL: sequence s), so a SUBSET of an engine's rows can be prefilled. */
 int ssrhip_attn_prefill(const ssrhip_attn_args* a, const int32_t* seq_start, int32_t n_seq, int32_t max_len, float* out,
                         ssrhip_stream_t stream);
 

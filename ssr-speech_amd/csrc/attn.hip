@@ -342,7 +342,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const ssrhip_attn_arg
 #pragma unroll
     for (int j = 0; j < NJ; ++j) qr[j] = ld4(qp + 8 * j);
   }
-  const int32_t* tab = a.kv.table + (size_t)seq * a.kv.max_pages;
+  // segment `seq` of the flattened rows belongs to cache sequence row_seq[first row] (a prefill of SOME of the engine's rows while the
+  // others keep decoding); without row_seq segment i is sequence i
+  const int32_t* tab = a.kv.table + (size_t)(a.row_seq ? a.row_seq[r0] : seq) * a.kv.max_pages;
   const size_t page_stride = (size_t)a.kv.n_layer * 2 * H * SSRHIP_PAGE * HD;
   const float* pool = a.kv.pool + ((size_t)a.layer * 2 * H + h) * SSRHIP_PAGE * HD;
   const size_t v_off = (size_t)H * SSRHIP_PAGE * HD;

