@@ -58,40 +58,47 @@ def cpu_baseline(args_lm, sd_gpu, x, y, unc, n_steps=25):
     from oracle import lm as O
     ncpu = os.cpu_count() or 1
     # Thread count: the decode step is a memory-bound B=2 GEMV; torch with one thread per logical core of a
-    # 256-thread host is pathological (measured 22 s/step), so a few counts are tried on consecutive blocks of
-    # steps of the SAME run and the fastest block is reported (that favours the CPU).
+    # 256-thread host is pathological (measured 22 s/step), so a few counts are probed on consecutive blocks of
+    # steps of the SAME run and the >= 25 measured steps then run at the fastest one (that favours the CPU).
     trial_threads = [t for t in (16, 32, 64) if t <= ncpu] or [ncpu]
-    block = 6
-    n_steps = 4 + block * len(trial_threads)
+    probe = 4                       # steps per thread count in the probe phase (the first after a switch is dropped)
+    measured = max(int(n_steps), 25)  # >= 25 decode steps at ONE setting — the fastest of the probe
+    n_probe = 2 + probe * len(trial_threads)
+    total = n_probe + 1 + measured
     torch.set_num_threads(trial_threads[0])
     sd = O.reference_params({k: v.cpu() for k, v in sd_gpu.items()})
     marks = []
+    chosen = {}
 
     class Clock(dict):          # the oracle touches trace["samples"] once per finished step
         def setdefault(self, k, d=None):
             if k == "samples":
                 marks.append(time.perf_counter())
                 done = len(marks)
-                if done >= 4 and (done - 4) % block == 0 and (done - 4) // block < len(trial_threads):
-                    torch.set_num_threads(trial_threads[(done - 4) // block])
+                if done >= 2 and done < n_probe and (done - 2) % probe == 0:
+                    torch.set_num_threads(trial_threads[(done - 2) // probe])
+                if done == n_probe:                                  # probe finished: the rest of the run at the fastest count
+                    dts_ = np.diff(np.asarray(marks))
+                    per_ = {th: float(dts_[1 + i * probe + 1: 1 + (i + 1) * probe].mean()) for i, th in enumerate(trial_threads)}
+                    chosen.update(per_)
+                    torch.set_num_threads(min(per_, key=per_.get))
             return dict.setdefault(self, k, d)
 
     trace = Clock()
     mi = torch.LongTensor([[[y.shape[1], y.shape[1]]]])
     t0 = time.perf_counter()
-    O.inference(sd, args_lm, x, y, mi, uncond_x=unc, max_steps=n_steps, trace=trace, top_k=40, top_p=0.8, temperature=1.0,
+    O.inference(sd, args_lm, x, y, mi, uncond_x=unc, max_steps=total, trace=trace, top_k=40, top_p=0.8, temperature=1.0,
                 stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=5, aug_text=True)
     prefill_s = marks[0] - t0
     dts = np.diff(np.asarray(marks))
-    per = {}
-    for i, th in enumerate(trial_threads):
-        seg = dts[3 + i * block + 1: 3 + (i + 1) * block]      # drop the first step after each switch
-        per[th] = float(seg.mean())
-    best = min(per, key=per.get)
-    return dict(value=round(4.0 / per[best], 2), unit="codec-tokens/s", cores=best, kind="port",
+    best = min(chosen, key=chosen.get)
+    steady = dts[n_probe: n_probe + measured]                        # the step right after the switch is dropped
+    ms_step = float(steady.mean())
+    return dict(value=round(4.0 / ms_step, 2), unit="codec-tokens/s", cores=best, kind="port",
                 sample=f"oracle/lm.py (CPU restatement of models/ssr.py inference, op-for-op incl. per-step KV torch.cat), same 830M weights/inputs: "
-                       f"prefill S0={x.shape[1] + y.shape[1] + 10} x2 rows ({prefill_s:.2f} s, {trial_threads[0]} threads) + {n_steps} decode steps; "
-                       f"ms/step by threads {{{', '.join(f'{k}: {1000 * v:.1f}' for k, v in per.items())}}} on a {ncpu}-logical-core host; best reported")
+                       f"prefill S0={x.shape[1] + y.shape[1] + 10} x2 rows ({prefill_s:.2f} s, {trial_threads[0]} threads), a probe of {probe} steps per thread count "
+                       f"(ms/step {{{', '.join(f'{k}: {1000 * v:.1f}' for k, v in chosen.items())}}} on a {ncpu}-logical-core host), then {len(steady)} decode steps "
+                       f"at the fastest count ({best} threads): {1000 * ms_step:.1f} ms/step")
 
 
 def codec_leg(dev, with_cpu):

@@ -16,10 +16,12 @@
 //   * no LDS on the weight path (each weight element is used once: staging would be pure overhead);
 //     LDS only shares the prologue result between the 4 waves and adds the K-slices of one row;
 //   * wave reductions are DPP/permlane (no ds_bpermute).
-// The paragraph above describes the row-per-wave kernels (`gemv_kernel`, `gemv_fast_kernel`). Since the second half of round 2 the
-// shapes of the 830M step (K = 1024 * {1,2,4,8}, LayerNorm folded) run on `gemv_seg_kernel` further down — same fusion, a different
-// split of the work (contiguous rows per 512-thread workgroup, (row, 1024-float segment) units, 4 loads in flight per lane); the
-// row-per-wave kernels serve every other shape and `SSRHIP_GEMV_SEG=0`.
+// The paragraph above describes the generic row-per-wave kernel `gemv_kernel`. Since the second half of round 2 the shapes of the
+// 830M step (K = 1024 * {1,2,4,8}, LayerNorm folded) run on `gemv_seg_kernel` further down — same fusion, a different split of the
+// work (contiguous rows per 512-thread workgroup, (row, 1024-float segment) units, 4 loads in flight per lane); the generic kernel
+// serves every other shape (the narrow test models, an unfolded LayerNorm) and `SSRHIP_GEMV_SEG=0`. (Round 3 removed the
+// intermediate generation `gemv_fast_kernel` — the unconditional-load specialisation of the row-per-wave kernel for exactly the
+// shapes the segment kernel took over.)
 // Replaces F.linear (+LayerNorm / ReLU / GELU / residual) of the reference: see include/ssrhip.h.
 #include <stdlib.h>
 #include "common.h"
@@ -437,303 +439,8 @@ __global__ __launch_bounds__(256, (B <= 2 && PRO != SSRHIP_PRO_ATTN_COMBINE) ? 3
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Fast path (the shapes of the 830M decode step). Conditions, checked by the host: every K-slice is exactly NCH*256
-// floats, the first ROWS0 (1|2) rows of every wave-group exist, LayerNorm's gamma/beta are folded (ln_w == NULL), and for
-// the combine prologue K == 2048. Then EVERY load of the prologue and of the first weight rows is unconditional and in
-// program order, hipcc can count them (s_waitcnt vmcnt(N), not 0) and the prologue math really runs under the HBM
-// latency of the first rows. (With per-lane predicates / conditional issue the compiler drains the queue before the
-// prologue math and moves the weight loads behind it: 2-3 us per launch, measured.)
-template <int NCH>
-__device__ __forceinline__ void load_row_u(float4 (&w)[NCH], const float* wrow, int lane) {
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) w[i] = ld_nt(wrow + (i * 64 + lane) * 4);
-}
-
-template <int B, int NCH>
-__device__ __forceinline__ void consume_row_u(const GemvK& p, const float4 (&w)[NCH], const float4 (&xr)[B][NCH], int g, int n, int it, int lane,
-                                              int wave, float* part, const RowEpi& e, float* const (&kvb)[2]) {
-  float mine = 0.f;
-#pragma unroll
-  for (int b = 0; b < B; ++b) {
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; i += 2) {
-      s0 = dot4(w[i], xr[b][i], s0);
-      if (i + 1 < NCH) s1 = dot4(w[i + 1], xr[b][i + 1], s1);
-    }
-    const float s = wave_sum(s0 + s1);
-    if (lane == b) mine = s;
-  }
-  if (lane < B) {
-    if (p.nslice == 1) finalize(p, g, n, lane, mine, e, kvb);
-    else part[(wave * MAX_IT + it) * B + lane] = mine;
-  }
-}
-
-template <int B, int PRO, int NCH, int ROWS0>
-__global__ __launch_bounds__(256, (B <= 2 && PRO != SSRHIP_PRO_ATTN_COMBINE) ? 3 : 2) void gemv_fast_kernel(const GemvK p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const ssrhip_gemv_args& a = p.a;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int g = blockIdx.y;
-  const int K = a.K, N = a.N;
-  const int slice = wave % p.nslice, rg = wave / p.nslice, n_rg = 4 / p.nslice;
-  const int k0 = slice * p.slice_len;
-  const int G = blockIdx.x * n_rg + rg;
-  const float* Wg = a.W + (size_t)g * N * K + k0;
-  float* part = smem;
-  float* xs = smem + 4 * MAX_IT * B + 16;
-  constexpr int NJF = (NCH >= 4) ? NCH / 4 : 1;      // float4 of x per thread per row in the block-wide LayerNorm (K = NCH*256)
-  constexpr int CSF = (B <= 2) ? 6 : 2;              // pages whose partial outputs are prefetched (combine)
-
-  // ---- 1. prologue loads (activations: L2 hits), all unconditional
-  float4 xr[B][NCH];
-  float4 xv[(PRO == SSRHIP_PRO_LAYERNORM) ? B : 1][NJF];
-  float4 co[(PRO == SSRHIP_PRO_ATTN_COMBINE) ? B : 1][2][CSF];
-  float4 cml[4];
-  int ns[(PRO == SSRHIP_PRO_ATTN_COMBINE) ? B : 1];
-  if constexpr (PRO == SSRHIP_PRO_NONE) {
-#pragma unroll
-    for (int b = 0; b < B; ++b)
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) xr[b][i] = ld4(a.x + (size_t)b * a.x_stride + (size_t)g * K + k0 + (i * 64 + lane) * 4);
-  }
-  if constexpr (PRO == SSRHIP_PRO_LAYERNORM) {
-#pragma unroll
-    for (int b = 0; b < B; ++b)
-#pragma unroll
-      for (int j = 0; j < NJF; ++j) xv[b][j] = ld4(a.x + (size_t)b * a.x_stride + (size_t)g * K + t * 4 + j * 1024);
-  }
-  if constexpr (PRO == SSRHIP_PRO_ATTN_COMBINE) {    // K == 2048: thread t owns float4 columns t*4 and t*4+1024 of every row
-    const int hd = p.hd, H = K / hd, MS = a.max_splits;
-#pragma unroll
-    for (int b = 0; b < B; ++b) ns[b] = (a.row_len[b] + SSRHIP_PAGE - 1) / SSRHIP_PAGE;
-    const int tt = t % (B * H);                      // every thread loads an (m,l) block; only t < B*H uses it
-    const float* ml = a.part_ml + (size_t)tt * MS * 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) cml[i] = ld4(ml + 4 * min(i, (MS * 2 - 4) / 4));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = t * 4 + j * 1024, h = e / hd, d = e % hd;
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-        const float* po = a.part_o + (((size_t)b * H + h) * MS) * hd + d;
-#pragma unroll
-        for (int s2 = 0; s2 < CSF; ++s2) co[b][j][s2] = ld4(po + (size_t)min(s2, ns[b] - 1) * hd);
-      }
-    }
-  }
-  // ---- 2. first weight rows, unconditional
-  float4 wa[NCH], wb[NCH];
-  RowEpi ea, eb = {0.f, 0.f};
-  int na = G, nb = G + p.groups_x;
-  load_row_u<NCH>(wa, Wg + (size_t)na * K, lane);
-  if constexpr (ROWS0 == 2) load_row_u<NCH>(wb, Wg + (size_t)nb * K, lane);
-  {
-    const int bb = min(lane, B - 1);
-    ea.bias = a.bias ? a.bias[(size_t)g * N + na] : 0.f;
-    ea.resid = (a.epi == SSRHIP_EPI_RESIDUAL) ? a.y[(size_t)bb * a.y_stride + (size_t)g * N + na] : 0.f;
-    if constexpr (ROWS0 == 2) {
-      eb.bias = a.bias ? a.bias[(size_t)g * N + nb] : 0.f;
-      eb.resid = (a.epi == SSRHIP_EPI_RESIDUAL) ? a.y[(size_t)bb * a.y_stride + (size_t)g * N + nb] : 0.f;
-    }
-  }
-  // KV-append bases per batch row through the SCALAR memory path (uniform addresses -> s_load, lgkmcnt): the dependent
-  // kv_pos -> page-table chain must not sit in the vector-memory queue in front of the weight rows
-  float* kvb[2] = {nullptr, nullptr};
-  if (a.epi == SSRHIP_EPI_QKV_APPEND) {
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const int pos = a.kv_pos[b];
-      float* kb = kv_addr(a.kv, b, a.layer, 0, 0, pos);
-      float* vb = kv_addr(a.kv, b, a.layer, 1, 0, pos);
-      if (lane == b) { kvb[0] = kb; kvb[1] = vb; }
-    }
-  }
-  // split-K (FFN2): the threads that will add the slices and finalise a row fetch that row's bias / residual now
-  RowEpi efin = {0.f, 0.f};
-  int nfin = -1, bfin = 0;
-  if (p.nslice > 1) {
-    const int tt = min(t, n_rg * MAX_IT * B - 1);
-    bfin = tt % B;
-    const int i2 = (tt / B) % MAX_IT, rg2 = tt / (B * MAX_IT);
-    nfin = (blockIdx.x * n_rg + rg2) + i2 * p.groups_x;
-    const int nc = min(nfin, N - 1);
-    efin.bias = a.bias ? a.bias[(size_t)g * N + nc] : 0.f;
-    efin.resid = (a.epi == SSRHIP_EPI_RESIDUAL) ? a.y[(size_t)bfin * a.y_stride + (size_t)g * N + nc] : 0.f;
-  }
-  // ---- 3. prologue math (under the rows' latency)
-  if constexpr (PRO == SSRHIP_PRO_LAYERNORM) {
-    float* red = smem;                               // aliases `part`: not live yet
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      float s0 = 0.f;
-#pragma unroll
-      for (int j = 0; j < NJF; ++j) s0 += (xv[b][j].x + xv[b][j].y) + (xv[b][j].z + xv[b][j].w);
-      s0 = wave_sum(s0);
-      if (lane == 0) red[b * 4 + wave] = s0;
-    }
-    __syncthreads();
-    float mean[B];
-#pragma unroll
-    for (int b = 0; b < B; ++b) mean[b] = ((red[b * 4] + red[b * 4 + 1]) + (red[b * 4 + 2] + red[b * 4 + 3])) / (float)K;
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      float q = 0.f;
-#pragma unroll
-      for (int j = 0; j < NJF; ++j) {
-        const float dx = xv[b][j].x - mean[b], dy = xv[b][j].y - mean[b], dz = xv[b][j].z - mean[b], dw = xv[b][j].w - mean[b];
-        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      }
-      q = wave_sum(q);
-      if (lane == 0) red[b * 4 + wave] = q;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const float var = ((red[b * 4] + red[b * 4 + 1]) + (red[b * 4 + 2] + red[b * 4 + 3])) / (float)K;
-      const float rstd = 1.0f / sqrtf(var + a.ln_eps);
-#pragma unroll
-      for (int j = 0; j < NJF; ++j)
-        *reinterpret_cast<float4*>(xs + b * K + t * 4 + j * 1024) =
-            make_float4((xv[b][j].x - mean[b]) * rstd, (xv[b][j].y - mean[b]) * rstd, (xv[b][j].z - mean[b]) * rstd, (xv[b][j].w - mean[b]) * rstd);
-    }
-    __syncthreads();
-  }
-  if constexpr (PRO == SSRHIP_PRO_ATTN_COMBINE) {
-    const int hd = p.hd, H = K / hd, MS = a.max_splits;
-    float* wtab = xs + B * K;
-    if (t < B * H) {                                 // softmax-merge weights of (row, head) = t
-      const int n = ns[t / H];
-      const float* ml = a.part_ml + (size_t)t * MS * 2;
-      float M = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { if (2 * i < n) M = fmaxf(M, cml[i].x); if (2 * i + 1 < n) M = fmaxf(M, cml[i].z); }
-      for (int s2 = 8; s2 < n; ++s2) M = fmaxf(M, ml[2 * s2]);
-      float den = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (2 * i < n) den = fmaf(expf(cml[i].x - M), cml[i].y, den);
-        if (2 * i + 1 < n) den = fmaf(expf(cml[i].z - M), cml[i].w, den);
-      }
-      for (int s2 = 8; s2 < n; ++s2) den = fmaf(expf(ml[2 * s2] - M), ml[2 * s2 + 1], den);
-      const float inv = 1.0f / den;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (2 * i < n) wtab[t * MS + 2 * i] = expf(cml[i].x - M) * inv;
-        if (2 * i + 1 < n) wtab[t * MS + 2 * i + 1] = expf(cml[i].z - M) * inv;
-      }
-      for (int s2 = 8; s2 < n; ++s2) wtab[t * MS + s2] = expf(ml[2 * s2] - M) * inv;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = t * 4 + j * 1024, h = e / hd, d = e % hd;
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-        const float* w = wtab + (b * H + h) * MS;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int s2 = 0; s2 < CSF; ++s2) {
-          const float ws = (s2 < ns[b]) ? w[s2] : 0.f;
-          acc.x = fmaf(ws, co[b][j][s2].x, acc.x);
-          acc.y = fmaf(ws, co[b][j][s2].y, acc.y);
-          acc.z = fmaf(ws, co[b][j][s2].z, acc.z);
-          acc.w = fmaf(ws, co[b][j][s2].w, acc.w);
-        }
-        const float* po = a.part_o + (((size_t)b * H + h) * MS) * hd + d;
-        for (int s2 = CSF; s2 < ns[b]; ++s2) {       // long contexts: remaining pages, loaded late
-          const float ws = w[s2];
-          const float4 o = ld4(po + (size_t)s2 * hd);
-          acc.x = fmaf(ws, o.x, acc.x);
-          acc.y = fmaf(ws, o.y, acc.y);
-          acc.z = fmaf(ws, o.z, acc.z);
-          acc.w = fmaf(ws, o.w, acc.w);
-        }
-        *reinterpret_cast<float4*>(xs + b * K + e) = acc;
-      }
-    }
-    __syncthreads();
-  }
-  if constexpr (PRO != SSRHIP_PRO_NONE) {
-#pragma unroll
-    for (int b = 0; b < B; ++b)
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) xr[b][i] = *reinterpret_cast<const float4*>(xs + b * K + k0 + (i * 64 + lane) * 4);
-  }
-  // ---- 4. stream the rows (two in flight)
-  int it = 0;
-  const int step2 = 2 * p.groups_x;
-  while (na < N) {
-    consume_row_u<B, NCH>(p, wa, xr, g, na, it, lane, wave, part, ea, kvb);
-    ++it;
-    na += step2;
-    if (na < N) {
-      load_row_u<NCH>(wa, Wg + (size_t)na * K, lane);
-      if (p.nslice == 1) ea = load_epi(p, g, na, lane, B);
-    }
-    if (nb >= N) break;
-    if constexpr (ROWS0 != 2) {                      // second row of the pair was not prefetched ahead of the prologue
-      if (it == 1) { load_row_u<NCH>(wb, Wg + (size_t)nb * K, lane); if (p.nslice == 1) eb = load_epi(p, g, nb, lane, B); }
-    }
-    consume_row_u<B, NCH>(p, wb, xr, g, nb, it, lane, wave, part, eb, kvb);
-    ++it;
-    nb += step2;
-    if (nb < N) {
-      load_row_u<NCH>(wb, Wg + (size_t)nb * K, lane);
-      if (p.nslice == 1) eb = load_epi(p, g, nb, lane, B);
-    }
-  }
-  if (p.nslice > 1) {
-    __syncthreads();
-    if (t < n_rg * MAX_IT * B && nfin < N) {
-      const int i2 = (t / B) % MAX_IT, rg2 = t / (B * MAX_IT);
-      float v = 0.f;
-      for (int s = 0; s < p.nslice; ++s) v += part[((rg2 * p.nslice + s) * MAX_IT + i2) * B + bfin];
-      float* kv2[2] = {nullptr, nullptr};
-      finalize(p, g, nfin, bfin, v, efin, kv2);
-    }
-  }
-}
-
-template <int B, int PRO, int NCH>
-void launch_fast(const GemvK& p, dim3 grid, size_t smem, hipStream_t s, int rows0) {
-  if (rows0 == 2) hipLaunchKernelGGL((gemv_fast_kernel<B, PRO, NCH, 2>), grid, dim3(256), smem, s, p);
-  else hipLaunchKernelGGL((gemv_fast_kernel<B, PRO, NCH, 1>), grid, dim3(256), smem, s, p);
-}
-
-// true if the fast kernel was launched
-template <int B>
-bool try_fast(const GemvK& p, dim3 grid, size_t smem, hipStream_t s) {
-  const ssrhip_gemv_args& a = p.a;
-  if (a.K % p.nslice != 0 || p.slice_len * p.nslice != a.K || p.slice_len != p.nch * 256) return false;
-  if (a.N < p.groups_x) return false;
-  if (a.epi == SSRHIP_EPI_QKV_APPEND && p.nslice != 1) return false;
-  const int rows0 = (a.N >= 2 * p.groups_x) ? 2 : 1;
-  if (a.pro == SSRHIP_PRO_NONE) {
-    if (p.nch == 8) { launch_fast<B, SSRHIP_PRO_NONE, 8>(p, grid, smem, s, rows0); return true; }
-    if (p.nch == 4) { launch_fast<B, SSRHIP_PRO_NONE, 4>(p, grid, smem, s, rows0); return true; }
-    return false;
-  }
-  if (a.pro == SSRHIP_PRO_LAYERNORM) {
-    if (a.ln_w != nullptr || p.nslice != 1) return false;
-    if (p.nch == 8) { launch_fast<B, SSRHIP_PRO_LAYERNORM, 8>(p, grid, smem, s, rows0); return true; }
-    if (p.nch == 4) { launch_fast<B, SSRHIP_PRO_LAYERNORM, 4>(p, grid, smem, s, rows0); return true; }
-    return false;
-  }
-  if (a.pro == SSRHIP_PRO_ATTN_COMBINE) {
-    if (a.K != 2048 || p.nch != 8 || a.max_splits < 2 || (a.max_splits & 1) || B * (a.K / p.hd) > 256) return false;   // its (m, l) loads take two pages at a time
-    launch_fast<B, SSRHIP_PRO_ATTN_COMBINE, 8>(p, grid, smem, s, rows0);
-    return true;
-  }
-  return false;
-}
-
 template <int B>
 void launch_b(const GemvK& p, dim3 grid, size_t smem, hipStream_t s) {
-  if (try_fast<B>(p, grid, smem, s)) return;
   switch (p.a.pro) {
     case SSRHIP_PRO_LAYERNORM:
       if (p.a.ln_w == nullptr && p.nslice == 1) hipLaunchKernelGGL((gemv_kernel<B, PRO_LN_REGS>), grid, dim3(256), smem, s, p);

@@ -223,9 +223,25 @@ class TorchCpuNoiseFeed:
     `finish(u, n_taken)` puts that generator in the state it has after exactly `n_taken` per-step draws, i.e. where the
     reference leaves it — chunks drawn ahead of the stop are un-drawn."""
 
+    _chunk_ok: dict = {}             # (K, card) -> does ONE [n, K, card] draw consume the generator like n [K, card] draws on this build?
+
+    @classmethod
+    def chunked_draws_match(cls, K: int, card: int) -> bool:
+        """Self-check of the assumption above, once per shape and process: torch builds whose CPU `exponential_` seeds a per-call
+        stream (some MKL/VSL configurations) would give a chunked draw other numbers than per-step draws — sampled runs would then
+        silently stop reproducing `torch.multinomial`. On a mismatch the feed draws step by step into the same staging buffer."""
+        key = (int(K), int(card))
+        if key not in cls._chunk_ok:
+            g1, g2 = torch.Generator().manual_seed(987654321), torch.Generator().manual_seed(987654321)
+            a = torch.empty(3, K, card).exponential_(1, generator=g1)
+            b = torch.stack([torch.empty(K, card).exponential_(1, generator=g2) for _ in range(3)])
+            cls._chunk_ok[key] = bool(torch.equal(a, b)) and bool(torch.equal(g1.get_state(), g2.get_state()))
+        return cls._chunk_ok[key]
+
     def __init__(self, generators, K: int, card: int):
         self.gens = list(generators)
         self.K, self.card = K, card
+        self.chunked = self.chunked_draws_match(K, card)
         self.marks = [[] for _ in self.gens]      # per utterance: (first step of the chunk, generator state before drawing it)
         self.drawn = [0] * len(self.gens)
 
@@ -243,7 +259,11 @@ class TorchCpuNoiseFeed:
     def draw(self, u: int, out: torch.Tensor):
         """Fill `out` [n, K, card] (CPU, may be pinned) with the draws of the next n steps of utterance u."""
         self.marks[u].append((self.drawn[u], self._get(u)))
-        out.exponential_(1, generator=self.gens[u])
+        if self.chunked:
+            out.exponential_(1, generator=self.gens[u])
+        else:
+            for i in range(out.shape[0]):
+                out[i].exponential_(1, generator=self.gens[u])
         self.drawn[u] += out.shape[0]
 
     def reset_slot(self, u: int, generator):
@@ -258,7 +278,11 @@ class TorchCpuNoiseFeed:
         s0, st = [m for m in self.marks[u] if m[0] <= n_taken][-1]
         self._set(u, st)
         if n_taken > s0:
-            torch.empty(n_taken - s0, self.K, self.card).exponential_(1, generator=self.gens[u])
+            if self.chunked:
+                torch.empty(n_taken - s0, self.K, self.card).exponential_(1, generator=self.gens[u])
+            else:
+                for _ in range(n_taken - s0):
+                    torch.empty(self.K, self.card).exponential_(1, generator=self.gens[u])
         self.drawn[u] = n_taken
 
 

@@ -3,6 +3,9 @@ plus size-independent properties:
 
   config 2   830M, L=130 phonemes, 160-frame prompt, cfg_stride=5, top_k=40 / top_p=0.8 sampling — tokens identical to the
              oracle's under the same seed (the sampler consumes torch's CPU stream), 20 steps.
+  config 3   830M speech editing on the reference's demo prompt demo/84_121550_000074_000000.wav (tests/golden/, 126,880 samples =
+             397 frames, oracle/make_golden_demo.py): wav -> wmencodec codes -> single-span edit [150, 250) -> watermarked wav; the first
+             greedy steps against the oracle on the codes of the real file, the whole chain run to completion for its properties.
   config 4   830M, 8 utterances x CFG = 16 rows of different lengths in one engine (the per-GPU shard of the 64-utterance batch).
   config 5   wmencodec encode + decode of randn(256, 1, 480000) * 0.1 on ONE GPU: shapes, finiteness, code range, the
              decode_latent round trip, and three clips cut from the batch compared with the oracle.
@@ -151,3 +154,60 @@ def test_config5_codec_256_clips_of_30s_on_one_gpu():
         assert diff.float().mean() < 0.01, b
         o_dec = OC.decode(sd, codes[b:b + 1].cpu(), cfg)            # decode of the GPU's own codes: isolates the decoder
         np.testing.assert_allclose(dec[b:b + 1].cpu().numpy(), o_dec.numpy(), rtol=0, atol=2e-4)
+
+
+def test_config3_edit_of_the_reference_demo_wav_end_to_end():
+    """BASELINE config 3 on the file it names (the chain wav -> codes -> edit -> wav had only been run on random codes).
+    (a) the demo wav tokenises to 397 frames; the 830M LM's first 8 greedy CFG steps of the span [150, 250) edit on THOSE codes equal
+    the oracle's (token ids identical); (b) `inference_one_sample` (edit mode, --use_watermark) runs the whole chain to completion:
+    head + generated span + tail frames, 320 samples each, finite."""
+    import argparse
+    import json
+    from ssr_speech_amd.data.tokenizer import AudioTokenizer, tokenize_audio
+    from ssr_speech_amd.inference_scale import inference_one_sample
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    fn = os.path.join(gold, "demo_84_121550_000074_000000.wav")
+    facts = json.load(open(os.path.join(gold, "demo_84_121550_000074_000000.json")))
+    ccfg = W.codec_config_full()
+    tok = AudioTokenizer(device="cuda", config=ccfg, state_dict=W.codec_state_dict(ccfg, seed=0))
+    codes, _, _ = tokenize_audio(tok, fn)
+    assert tuple(codes.shape) == (1, 4, facts["frames_320"]) == (1, 4, 397)
+    args = W.lm_args_830m()
+    sd_gpu = W.lm_state_dict(args, seed=0, device="cuda")
+    for k in range(4):          # keep a random-weight LM off the special ids the RVQ decoder rejects (as the reference's F.embedding would)
+        sd_gpu[f"predict_layer.{k}.2.bias"][2048:] = -30.0
+    m = SSR_Speech(args)
+    m.load_state_dict({k: v.cpu() for k, v in sd_gpu.items()})
+    m = m.to("cuda").eval()
+    sd_cpu = O.reference_params({k: v.cpu() for k, v in sd_gpu.items()})
+    gen = torch.Generator().manual_seed(33)
+    L, steps = 120, 8
+    x = torch.randint(0, 52, (1, L), generator=gen)
+    unc = torch.randint(0, 101, (1, L), generator=gen)
+    mi = torch.LongTensor([[[150, 250]]])
+    y = codes.transpose(2, 1).cpu()
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=5, aug_text=True)
+    trace = {}
+    O.inference(sd_cpu, args, x, y, mi, uncond_x=unc, max_steps=steps, trace=trace, **kw)
+    ref_tok = torch.stack(trace["samples"]).numpy()
+    out = m.inference(x.cuda(), torch.LongTensor([L]), x.cuda(), torch.LongTensor([L]), y.cuda(), y.cuda(), mi.cuda(), uncond_x=unc, max_new_steps=steps, **kw)
+    assert out is None
+    got_tok = next(iter(m._engines.values())).generated[0, :steps].cpu().numpy()
+    assert np.array_equal(got_tok, ref_tok), (got_tok, ref_tok)
+    # (b) the public per-utterance entry point, to completion (the span ends by the reference's 10 x L cap: ~800 steps)
+    symbols = [chr(ord("a") + i) for i in range(26)] + [chr(ord("A") + i) for i in range(26)]
+    phn2num = {c: i for i, c in enumerate(symbols)}
+    text = "".join(symbols[int(i)] for i in x[0])
+
+    class Chars:
+        def __call__(self, texts):
+            return [[c for c in t if c != " "] for t in texts]
+
+    decode_config = {"top_k": 1, "top_p": 1.0, "temperature": 1, "stop_repetition": 2, "kvcache": 1, "codec_audio_sr": 16000, "codec_sr": 50}
+    torch.manual_seed(1)
+    wav = inference_one_sample(m, argparse.Namespace(**vars(args)), phn2num, Chars(), tok, fn, text, text, mi[0], 1.5, 5, True, False, True, False, "cuda", decode_config)
+    lr = m.last_run
+    assert lr["done"] == 1 and wav.dim() == 3 and tuple(wav.shape[:2]) == (1, 1) and wav.shape[-1] % 320 == 0 and bool(torch.isfinite(wav).all())
+    # frames: kept head [0, 150) + the generated span (steps - 3 delay columns - 1 eog column) + kept tail [250, 397)
+    assert wav.shape[-1] // 320 == 150 + (lr["steps"] - 4) + (397 - 250), (wav.shape, lr["steps"])

@@ -74,3 +74,32 @@ def test_private_generators_match_the_global_stream_and_do_not_interact():
     torch.randint(0, 101, (1, 12), generator=ref)
     per_step(13, generator=ref)
     assert torch.equal(gens[0].get_state(), ref.get_state())
+
+
+def test_self_check_and_the_per_step_fallback(monkeypatch):
+    """the chunked draw is an assumption about this torch build — the feed checks it once per shape and, on a build where
+    it fails, draws step by step into the same staging buffer (same numbers, same generator end state, `finish` included)."""
+    assert TorchCpuNoiseFeed.chunked_draws_match(K, CARD) is True            # this image's build
+    monkeypatch.setitem(TorchCpuNoiseFeed._chunk_ok, (K, CARD), False)      # pretend the build fails the check
+    torch.manual_seed(11)
+    want = per_step(40)
+    torch.manual_seed(11)
+    feed = TorchCpuNoiseFeed([None], K, CARD)
+    assert feed.chunked is False
+    got = []
+    for c in (16, 16, 16):
+        buf = torch.empty(c, K, CARD)
+        feed.draw(0, buf)
+        got.append(buf)
+    assert torch.equal(torch.cat(got)[:40], want)
+    feed.finish(0, 40)
+    torch.manual_seed(11)
+    per_step(40)
+    assert torch.equal(torch.get_rng_state(), torch.get_rng_state())
+    ref_next = torch.rand(2)
+    torch.manual_seed(11)
+    feed2 = TorchCpuNoiseFeed([None], K, CARD)
+    for c in (16, 16, 16):
+        feed2.draw(0, torch.empty(c, K, CARD))
+    feed2.finish(0, 40)
+    assert torch.equal(torch.rand(2), ref_next)
