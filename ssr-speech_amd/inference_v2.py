@@ -54,6 +54,9 @@ EXTRA_FLAGS = [
     ("--prompt_end", dict(type=float, default=None, help="--tts: cut the prompt audio at this time in seconds (default --prompt_length)")),
     ("--phoneme_ids", dict(type=str, default=None, help="comma separated phoneme ids of the target transcript (skips espeak)")),
     ("--prompt_phoneme_ids", dict(type=str, default=None, help="comma separated phoneme ids of the prompt transcript")),
+    ("--manifest", dict(type=str, default=None, help="--tts only: JSON list of utterances {orig_audio, savename, target_transcript | phoneme_ids, "
+                                                     "orig_transcript, prompt_end}; all of them are decoded in lock-step (sharded over the ranks of a "
+                                                     "torchrun job) and rendered in one ragged codec pass per rank")),
 ]
 
 
@@ -88,6 +91,60 @@ class _IdTokenizer:
         return [self.table[t.strip()] for t in texts]
 
 
+def _prompt_16k(path: str, codec_audio_sr: int):
+    """--orig_audio as the codec wants it: mono, codec rate (the reference's librosa step, inference_v2.py:216-219)."""
+    from .data.tokenizer import read_wav
+    wav, sr = read_wav(path)
+    if wav.shape[0] > 1:
+        wav = wav.mean(0, keepdim=True)
+    if sr != codec_audio_sr:
+        from .data.resample import resample
+        wav, sr = resample(wav, sr, codec_audio_sr).cpu(), codec_audio_sr
+    return wav, sr
+
+
+def run_manifest(args, model, phn2num, audio_tokenizer, device) -> list:
+    """`--manifest`: many zero-shot TTS utterances in one job (BASELINE config 4 as a command line). Utterance i is what a single
+    `--tts` run with `--seed (seed + i)` produces; the utterances are sharded over the ranks of the process group (if any), decoded in
+    lock-step with row refill, their tokens all-gathered, and every rank renders and writes the waveforms of its own shard
+    (`dp.synthesize`). Returns the paths this rank wrote."""
+    import json
+    from . import dp
+    from .data.tokenizer import TextTokenizer, tokenize_audio, write_wav
+    entries = json.load(open(args.manifest))
+    if not args.tts:
+        raise SystemExit("--manifest needs --tts (speech editing spans come from one alignment per file)")
+    work_dir = args.temp_folder or args.output_dir
+    os.makedirs(work_dir, exist_ok=True)
+    os.makedirs(args.output_dir, exist_ok=True)
+    text_tokenizer = None
+    utts, names = [], []
+    for i, e in enumerate(entries):
+        wav, sr = _prompt_16k(e["orig_audio"], args.codec_audio_sr)
+        cut = float(e.get("prompt_end", args.prompt_end if args.prompt_end is not None else args.prompt_length))
+        n = int(min(cut, wav.shape[-1] / sr) * sr)
+        name = e.get("savename", f"utt{i:05d}")
+        prompt_fn = os.path.join(work_dir, f"{name}_prompt.wav")
+        write_wav(prompt_fn, wav[:, :n], sr)
+        codes, _scale, _emb = tokenize_audio(audio_tokenizer, prompt_fn)
+        frames = codes.shape[-1]
+        if "phoneme_ids" in e:
+            ids = [int(v) for v in e["phoneme_ids"]]
+        else:
+            if text_tokenizer is None:
+                text_tokenizer = TextTokenizer(backend="espeak", language="en-us" if args.language != "zh" else "cmn")
+            text = ((e.get("orig_transcript") or "") + " " + e["target_transcript"]).strip()
+            ids = [phn2num[p] for p in text_tokenizer([text])[0] if p in phn2num]
+        utts.append({"x": torch.tensor(ids, dtype=torch.long).view(1, -1), "y": codes.transpose(2, 1).cpu(),
+                     "mask_interval": torch.LongTensor([[[frames, frames]]]), "wav": prompt_fn})
+        names.append(f"{name}_new_seed{args.seed + i}")
+    waves, (lo, hi), _tokens = dp.synthesize(model, audio_tokenizer, utts, seed=args.seed, use_watermark=bool(args.use_watermark), tts=True,
+                                             output_dir=args.output_dir, names=names, sample_rate=args.codec_audio_sr,
+                                             top_k=args.top_k, top_p=args.top_p, temperature=args.temperature, stop_repetition=args.stop_repetition,
+                                             cfg_coef=args.cfg_coef, cfg_stride=args.cfg_stride, aug_text=args.aug_text)
+    return [os.path.join(args.output_dir, names[i] + ".wav") for i in range(lo, hi)]
+
+
 def main(argv=None):
     args = parse_args(argv)
     seed_everything(args.seed)
@@ -95,6 +152,8 @@ def main(argv=None):
     from .inference_scale import inference_one_sample, inference_samples
     from .models.ssr import SSR_Speech
 
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and torch.cuda.is_available():        # torchrun: this rank's GPU before anything is allocated
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     device = "cuda" if torch.cuda.is_available() else "cpu"
     ckpt = torch.load(args.model_path, map_location="cpu", weights_only=False)      # inference_v2.py:197-204
     model = SSR_Speech(ckpt["config"])
@@ -104,6 +163,17 @@ def main(argv=None):
     model.to(device)
     model.eval()
     audio_tokenizer = AudioTokenizer(device=device, signature=args.codec_path)        # :205
+
+    if args.manifest is not None:
+        import torch.distributed as dist
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1 and not dist.is_initialized():                                   # launched by torchrun: one rank per GPU over RCCL
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl")
+        t0 = time.time()
+        written = run_manifest(args, model, phn2num, audio_tokenizer, device)
+        print(f"Running time: {time.time() - t0:.4f} s ({len(written)} utterances on this rank)")
+        return written
 
     start_time = time.time()
     os.makedirs(args.output_dir, exist_ok=True)

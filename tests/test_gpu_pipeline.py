@@ -310,3 +310,43 @@ def test_cli_edit_with_watermark_on_a_24k_stereo_prompt_uses_the_converted_audio
     (new_b, _), (orig_b, _) = outs["b"]
     assert sr_a == 16000 and osr_a == 16000 and orig_a.shape == (1, 24 * 320)
     assert torch.equal(orig_a, orig_b) and new_a.shape == new_b.shape and torch.equal(new_a, new_b)
+
+
+def test_cli_manifest_equals_one_tts_run_per_utterance(tmp_path):
+    """`--manifest`: three zero-shot TTS utterances (different prompts, texts, prompt cuts) in ONE job — lock-step decode with row
+    refill + one ragged codec pass (`dp.synthesize`) — write exactly the wavs three single `--tts` runs with `--seed (seed + i)` write
+    (sampling mode; the reference would loop the three through inference_v2.py one process each)."""
+    import json
+    from ssr_speech_amd import inference_v2 as CLI
+    from ssr_speech_amd.data.tokenizer import read_wav
+    ccfg = W.CodecConfig(dimension=64, n_filters=8, ratios=(8, 5, 4, 2), bins=64)
+    csd = W.codec_state_dict(ccfg, seed=7)
+    args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
+    lsd = W.lm_state_dict(args, seed=8)
+    for k in range(4):
+        lsd[f"predict_layer.{k}.2.bias"][64:] = -30.0
+    phn2num = {c: i for i, c in enumerate("abcdefghijklmnopqrstuvwxyz")}
+    lm_ckpt, codec_ckpt = str(tmp_path / "lm.pth"), str(tmp_path / "codec.th")
+    torch.save({"config": argparse.Namespace(**vars(args)), "model": lsd, "phn2num": phn2num}, lm_ckpt)
+    torch.save({"codec_config": {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(ccfg).items()}, "model": csd}, codec_ckpt)
+    g = torch.Generator().manual_seed(21)
+    ids = lambda t: [phn2num[c] for c in t if c != " "]
+    entries, singles = [], []
+    for i, (prompt, target, cut) in enumerate([("hello world", "again", 0.4), ("abc", "the quick brown fox", 0.3), ("speech", "editing works", 0.5)]):
+        fn = str(tmp_path / f"orig{i}.wav")
+        write_wav(fn, torch.randn(1, 30 * 320, generator=g) * 0.2, 16000)
+        full = (prompt + " " + target).strip()
+        entries.append({"orig_audio": fn, "savename": f"u{i}", "phoneme_ids": ids(full), "prompt_end": cut})
+        singles.append((fn, prompt, target, full, cut))
+    man = str(tmp_path / "manifest.json")
+    json.dump(entries, open(man, "w"))
+    common = ["--model_path", lm_ckpt, "--codec_path", codec_ckpt, "--top_k", "12", "--top_p", "0.9", "--cfg_stride", "2", "--aug_text", "--tts"]
+    written = CLI.main(common + ["--manifest", man, "--seed", "40", "--output_dir", str(tmp_path / "many"), "--temp_folder", str(tmp_path / "tmpm")])
+    assert [os.path.basename(w) for w in written] == [f"u{i}_new_seed{40 + i}.wav" for i in range(3)]
+    for i, (fn, prompt, target, full, cut) in enumerate(singles):
+        CLI.main(common + ["--orig_audio", fn, "--orig_transcript", prompt, "--target_transcript", target, "--savename", f"u{i}", "--seed", str(40 + i),
+                           "--prompt_end", str(cut), "--phoneme_ids", ",".join(map(str, ids(full))), "--prompt_phoneme_ids", ",".join(map(str, ids(prompt))),
+                           "--output_dir", str(tmp_path / f"one{i}"), "--temp_folder", str(tmp_path / f"tmp{i}")])
+        a, _ = read_wav(written[i])
+        b, _ = read_wav(str(tmp_path / f"one{i}" / f"u{i}_new_seed{40 + i}.wav"))
+        assert a.shape == b.shape and (a - b).abs().max() <= 2.0 / 32768, (i, a.shape, b.shape)      # 16-bit files: at most one LSB apart (batch-1 vs batched LSTM step kernel)
