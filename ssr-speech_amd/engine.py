@@ -664,7 +664,10 @@ class DecodeEngine:
         K, card = self.a.K, self.a.card
         slot_job: List[Optional[int]] = [None] * self.n_utt
         local: List[int] = [0] * self.n_utt           # steps enqueued for the slot's current utterance
-        pending = list(range(n_jobs))
+        # longest (by its step cap) first: the utterances that will run longest start earliest and the short ones fill the slots freed
+        # towards the end — the tail with a few long utterances on a mostly idle engine shrinks (simulated on the bench's ragged queue:
+        # 344 -> 327 chunks). Which utterance sits in which slot when does not change any result.
+        pending = sorted(range(n_jobs), key=lambda j: -int(jobs[j]["cap"])) if n_jobs > self.n_utt else list(range(n_jobs))
         feed = TorchCpuNoiseFeed([None] * self.n_utt, K, card) if sampling else None
         main = torch.cuda.current_stream(dev)
         if sampling and (self._pinned is None or self._pinned[0].shape[1] != chunk or len(self._pinned) < 3):

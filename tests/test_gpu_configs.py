@@ -105,6 +105,31 @@ def test_config4_830m_sixteen_rows_match_oracle():
     print(f"830M x 16 rows: max |logit diff| at step {steps}: {worst:.2e}")
 
 
+def test_config4_830m_sampled_queue_through_eight_slots_matches_oracle():
+    """multi-utterance parity at the 830M shape had been greedy only. 9 short utterances, SAMPLED (top_k 20 /
+    top_p 0.9, CFG), run to completion through `inference_batch` = 8 utterance slots x 2 rows (the 16-row matrix-core path) with one
+    refill; every utterance's tokens equal the oracle's CPU run under `torch.manual_seed(seed + i)` (the per-utterance RNG contract)."""
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    args, m, _, sd_cpu = _model_830m()
+    gen = torch.Generator().manual_seed(91)
+    utts = []
+    for i in range(9):
+        L, T = 5 + i % 4, 10 + 3 * i
+        utts.append(dict(x=torch.randint(0, 100, (1, L), generator=gen), y=torch.randint(0, 2048, (1, T, 4), generator=gen),
+                         mask_interval=torch.LongTensor([[[T, T]]])))
+    kw = dict(top_k=20, top_p=0.9, temperature=1.0, stop_repetition=2, cfg_coef=1.5, cfg_stride=2, aug_text=True)
+    got = m.inference_batch(utts, seed=900, **kw)
+    eng = next(iter(m._engines.values()))
+    assert eng.B == 16 and eng.n_admitted == 9 and eng.n_refills == 1
+    n_steps = 0
+    for i, u in enumerate(utts):
+        torch.manual_seed(900 + i)
+        res, marks, masks, nmi = O.inference(sd_cpu, args, u["x"], u["y"], u["mask_interval"], kvcache=1, **kw)
+        assert torch.equal(got[i][0].cpu(), res) and torch.equal(got[i][1], marks) and got[i][2] == masks, i
+        n_steps += res.shape[-1] - u["y"].shape[1]
+    assert n_steps > 100
+
+
 def test_config5_codec_256_clips_of_30s_on_one_gpu():
     from ssr_speech_amd.codec.wmencodec import WMEncodecModel
     from helpers_codec import code_margins
