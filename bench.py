@@ -394,7 +394,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--utts", type=int, default=1, help="utterances decoded in lock-step per GPU (default 1 = the headline configuration)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the rtf_10s_tts / dp64 / codec256 / wmencodec legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rtf_10s_tts / dp64 / dp64_ragged / codec256 / wmencodec legs")
+    ap.add_argument("--legs", type=str, default="", help="comma separated subset of the extra legs to run (default: all)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -548,7 +549,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return bool(int(t.item()))
 
+        wanted = {v for v in a.legs.split(",") if v}
+
         def leg(name, fn):
+            if wanted and name not in wanted:
+                return
             # the headline metric must not depend on an extra: a failure becomes an "error" entry. dp64's collective is guarded
             # inside dp.generate (ranks agree on success before the all-gather); codec256's only collective is a timing all-reduce
             # behind all_ok().
