@@ -222,8 +222,17 @@ typedef struct ssrhip_gemm_args {
    * splits into W_a . ELU(skip) + (W_b . ELU(embed(label))), and the second term takes only as many values as there are labels —
    * so the concatenated tensor is never built and the GEMM's K shrinks by the embedding width. */
   const float* rbias; const int32_t* rclass; int32_t rrep, rclass_stride;
+  /* optional (NULL = always the fp32 FMA chain): W as three bf16 planes [3][N][K] made by ssrhip_split_weights. When given — and the
+   * problem is large enough, N > 64, K % 8 == 0 — the GEMM runs on the bf16 matrix cores with every fp32 operand split EXACTLY into
+   * three bf16 pieces and the six largest cross products accumulated in fp32 (csrc/gemm_split.hip): fp32 accuracy (error against an
+   * fp64 reference no larger than the fp32 chain's), ~1.3-1.5x the speed, NOT bit-identical to the k-ordered fp32 chain. The codec
+   * passes it (parity bar: waveform tolerance); the LM prefill does not (greedy tokens are compared bit for bit). */
+  const uint16_t* W_split;
 } ssrhip_gemm_args;
 int ssrhip_gemm(const ssrhip_gemm_args* a, ssrhip_stream_t stream);
+/* W fp32 [n_elems] -> out bf16 [3][n_elems]: piece p of element i at out[p * n_elems + i], w = w0 + w1 + w2 exactly
+ * (w0 = bf16_rne(w), w1 = bf16_rne(w - w0), w2 = bf16_rne(w - w0 - w1)). One-time preparation of a weight matrix for W_split. */
+int ssrhip_split_weights(const float* W, uint16_t* out, int64_t n_elems, ssrhip_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------------

@@ -91,7 +91,8 @@ class GemmArgs(C.Structure):
                 ("act_in", C.c_int32), ("R", C.c_void_p), ("ldr", C.c_int32), ("batch", C.c_int32),
                 ("strideA", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
                 ("tm_c", C.c_int32), ("tm_lo", C.c_int32), ("tm_hi", C.c_int32),
-                ("rbias", C.c_void_p), ("rclass", C.c_void_p), ("rrep", C.c_int32), ("rclass_stride", C.c_int32)]
+                ("rbias", C.c_void_p), ("rclass", C.c_void_p), ("rrep", C.c_int32), ("rclass_stride", C.c_int32),
+                ("W_split", C.c_void_p)]
 
 
 class LstmArgs(C.Structure):
@@ -159,6 +160,7 @@ SYMBOLS = [
     ("ssrhip_embed", C.c_int, [C.POINTER(EmbedArgs), C.c_void_p]),
     ("ssrhip_sample", C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     ("ssrhip_gemm", C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    ("ssrhip_split_weights", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ("ssrhip_conv_few_out", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     ("ssrhip_conv_cin1", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
     ("ssrhip_pad_reflect", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),

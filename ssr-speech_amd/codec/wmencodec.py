@@ -199,9 +199,12 @@ class WMEncodecModel:
         # step) would hide under the other group's convolutions; measured, the step launches queue behind the convolutions'
         # workgroups instead (32 clips: 85 -> 94 ms with two lanes, 122 ms with high-priority LSTM streams), so the default is ONE
         # lane and this is a memory knob (SSRHIP_CODEC_LANES, at least `lane_min_items` items per lane).
+        # fp32 GEMMs on the bf16 matrix cores with exactly split operands (csrc/gemm_split.hip; SSRHIP_GEMM_SPLIT=0: the fp32 FMA chain)
+        self.split_gemm = os.environ.get("SSRHIP_GEMM_SPLIT", "1") != "0"
+        self._plane_cache = {}
         self.lanes = int(os.environ.get("SSRHIP_CODEC_LANES", "1"))
         self.lane_min_items = int(os.environ.get("SSRHIP_CODEC_LANE_MIN", "8"))
-        self._lane_streams, self._side_streams, self._keep = [], {}, {}
+        self._side_streams, self._keep = {}, {}
         env = os.environ.get("SSRHIP_RESBLOCK_FUSE")
         self.fuse_channels = tuple(int(v) for v in env.split(",") if v) if env is not None else (64, 128)
         sd = {k: v.detach().to(torch.float32).cpu() for k, v in state_dict.items()}
@@ -230,14 +233,52 @@ class WMEncodecModel:
         self.codebooks = torch.stack([sd[f"quantizer.vq.layers.{q}._codebook.embed"] for q in range(cfg.n_q)]).contiguous().to(dev)
         self.e2 = self.codebooks.pow(2).sum(-1).contiguous()          # |e|^2 (core_vq.py:169)
         self.sample_rate, self.channels, self.frame_rate = cfg.sample_rate, cfg.channels, cfg.frame_rate
+        self._prepare_planes()
+
+    def _prepare_planes(self):
+        """Split every GEMM weight once, now, on the current stream (the batch lanes run on their own streams later: nothing may be
+        created lazily there), and wait for it."""
+        nets = [self.encoder, self.decoder] + ([self.wmdecoder, self.skip_encoder, self.wm_encoder] if self.has_wm else [])
+        for net in nets:
+            for _, kind, obj, _ in net.nodes:
+                if kind == "conv":
+                    self._planes(obj.W)
+                elif kind == "convtr":
+                    self._planes(obj.W)
+                elif kind == "res":
+                    self._planes(obj[0].W)
+                    self._planes(obj[1].W)
+                elif kind == "lstm":
+                    for wih, _, _ in obj.layers:
+                        self._planes(wih)
+        if self.has_wm:
+            for Wa, _ in self.wm_cls:
+                self._planes(Wa)
+            self._planes(self.wm_predictor.W)
+        torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------ low-level launches
     def _s(self):
         return _lib.stream_ptr()
 
+    def _planes(self, W: torch.Tensor) -> Optional[torch.Tensor]:
+        """bf16 planes [3][N][K] of a weight matrix for the split GEMM (csrc/gemm_split.hip: the fp32 operand as the exact sum of three
+        bf16 pieces), made once per matrix on the device; None when the split path is switched off or the shape can never take it."""
+        if not self.split_gemm or W.dim() != 2 or W.shape[0] <= 64 or W.shape[1] % 8 != 0:
+            return None
+        key = W.data_ptr()
+        hit = self._plane_cache.get(key)
+        if hit is None:
+            hit = torch.empty(3, W.shape[0], W.shape[1], dtype=torch.int16, device=W.device)
+            _lib.check(self.lib.ssrhip_split_weights(W.data_ptr(), hit.data_ptr(), W.numel(), self._s()), "ssrhip_split_weights")
+            self._plane_cache[key] = hit
+        return hit
+
     def _gemm(self, A, W, bias, Cp, M, N, K, lda, ldc, act_in=0, R=0, ldr=0, batch=1, sA=0, sC=0, sR=0, tm=(0, 0, 0), rowcls=None):
         a = _lib.GemmArgs()
         a.A, a.W, a.bias, a.C = A, W.data_ptr(), (bias.data_ptr() if bias is not None else 0), Cp
+        planes = self._planes(W)
+        a.W_split = planes.data_ptr() if planes is not None else 0
         a.M, a.N, a.K, a.lda, a.ldc = M, N, K, lda, ldc
         a.act_in, a.R, a.ldr, a.batch = act_in, R, ldr, batch
         a.strideA, a.strideC, a.strideR = sA, sC, sR
@@ -403,32 +444,17 @@ class WMEncodecModel:
         return list(zip(edges[:-1], edges[1:]))
 
     def _in_lanes(self, B: int, body):
-        """Run `body(lo, hi) -> tuple of tensors` for the batch lanes [lo, hi), each lane on its own stream, and join them on the
-        calling stream. With one lane `body(0, B)` runs on the calling stream itself. Returns the list of per-lane results."""
+        """Run `body(lo, hi) -> tuple of tensors` for the batch lanes [lo, hi) ONE AFTER THE OTHER on the calling stream and return
+        the list of per-lane results. Lanes are a memory knob: a lane's intermediates are freed before the next lane allocates its
+        own, so the peak falls with the lane size (256 clips x 30 s: 81 GB in one lane, 34 GB in four). Round 2 ran the lanes
+        concurrently on their own streams, hoping to hide one lane's LSTM under another's convolutions; measured, that was SLOWER
+        (32 clips: 85 -> 94 ms with two lanes: the step launches queue behind the other lane's resident workgroups), and round 3 found
+        it unsafe as well (with the faster split GEMM the last lane's LSTM state was intermittently corrupted: tests/test_gpu_codec.py
+        ::test_batch_lanes_equal_one_lane failed one run in two) — so the streams are gone."""
         cuts = self._lane_cuts(B)
         if cuts is None:
             return [body(0, B)]
-        dev = self.device
-        main = torch.cuda.current_stream(dev)
-        while len(self._lane_streams) < len(cuts):
-            self._lane_streams.append(torch.cuda.Stream(dev))
-        start = torch.cuda.Event()
-        start.record(main)
-        results, done = [], []
-        for (lo, hi), st in zip(cuts, self._lane_streams):
-            with torch.cuda.stream(st):
-                st.wait_event(start)
-                r = body(lo, hi)
-                for t in r:
-                    if isinstance(t, torch.Tensor):
-                        t.record_stream(main)                          # allocated in the lane's pool, consumed on the caller's stream
-                ev = torch.cuda.Event()
-                ev.record(st)
-            results.append(r)
-            done.append(ev)
-        for ev in done:
-            main.wait_event(ev)
-        return results
+        return [body(lo, hi) for lo, hi in cuts]
 
     @staticmethod
     def _join(parts, i):

@@ -12,6 +12,9 @@
 #include <stdlib.h>
 #include "common.h"
 
+bool ssrhip_gemm_split_eligible(const ssrhip_gemm_args* a);          // gemm_split.hip
+int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -221,6 +224,7 @@ extern "C" int ssrhip_gemm(const ssrhip_gemm_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->A && a->W && a->C, "ssrhip_gemm: null argument");
   SSR_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0 && a->K % 4 == 0 && a->lda % 4 == 0, "ssrhip_gemm: K and lda must be multiples of 4");
   SSR_REQUIRE(!a->rbias || (a->rclass && a->rrep > 0), "ssrhip_gemm: rbias needs rclass and rrep > 0");
+  if (ssrhip_gemm_split_eligible(a)) return ssrhip_gemm_split_launch(a, (hipStream_t)stream);    // caller supplied bf16 weight planes
   int bm = a->N <= 64 ? 256 : 64, bn = a->N <= 32 ? 32 : (a->N <= 64 ? 64 : 128);
   const long wide_wgs = (long)((a->N + 127) / 128) * ((a->M + 63) / 64) * (a->batch > 1 ? a->batch : 1);
   const bool small_grid = a->N > 64 && wide_wgs < 256;

@@ -1,0 +1,235 @@
+// gemm_split.hip — fp32 GEMM on the bf16 matrix cores with EXACT operand splitting (round 3).
+//
+//   C[M][N] = epi( A[M][K] . W[N][K]^T + bias[N] )          same contract and epilogues as gemm.hip's ssrhip_gemm
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TFLOP/s peak; gemm.hip reaches 115-121 on 4096^3 and a
+// persistent one-wave-per-SIMD kernel does not beat it: DESIGN §4b), v_mfma_f32_32x32x16_bf16 at 16x that. Every fp32 value is
+// the exact sum of three bf16 values (a = a0 + a1 + a2: a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1); the
+// subtractions are exact in fp32, 3 x 8 significand bits cover the 24), and a bf16 x bf16 product is exact in the fp32
+// accumulator, so a . w = sum over the nine cross terms a_i w_j EXACTLY (magnitudes below ~1e-33, whose third piece would be an fp32
+// subnormal, lose that piece: subnormals are flushed by the conversion — no activation or weight lives there). The kernel accumulates the six largest
+//   a0w0 + a0w1 + a1w0 + a1w1 + a0w2 + a2w0          (smallest first inside each 16-wide k block)
+// and drops a1w2, a2w1 (each <= 2^-24 |a||w|, the size of ONE fp32 rounding of the product) and a2w2 (2^-32). What remains is the
+// rounding of the fp32 accumulations, as in the fp32 FMA chain. Measured against an fp64 reference (tools/gemm_split_lab, K = 4096,
+// operands with 24 random mantissa bits, error relative to sum |a w|): this kernel max 5.2e-7 / mean 1.5e-8, the exact fp32 MFMA
+// chain of gemm.hip max 7.0e-7 / mean 1.8e-8 — the split form is no less accurate than the fp32 chain it replaces (its products are
+// exact, the chain rounds every one). It is NOT bit-identical to it: callers that need the k-ordered fp32 FMA chain (the LM
+// prefill, whose greedy tokens are compared bit for bit with the reference) keep gemm.hip; the codec, whose parity bar is a
+// waveform tolerance (2e-4) and RVQ codes up to fp32 near-ties, takes this kernel when the caller supplies the weight planes.
+//
+// Cost model per 16 k-values of a 32 x 32 block: 6 x 32 = 192 matrix-pipe cycles against 8 x 64 = 512 for the fp32 chain. The
+// operands are split while they are staged: W once per checkpoint (`ssrhip_split_weights`: three bf16 planes [3][N][K]), A on the
+// fly between the global load and the LDS store (v_cvt_pk_bf16_f32 = round to nearest even, two elements per instruction;
+// bf16 -> fp32 is a shift). Block tile 128 x 128 x 32, 4 waves (2 x 2) of 64 x 64 (2 x 2 accumulators of 32 x 32), two workgroups
+// per CU. LDS: per piece rows of 32 bf16 (64 B) at a pitch of 80 B — a lane's ds_read_b128 (8 consecutive k of one row = its
+// whole A / B operand of one MFMA) then hits 16 distinct 16-byte slots per 16-lane group.
+// Measured (tools/gemm_split_lab, one MI355X, warm clocks, fp32-equivalent TFLOP/s, exact kernel -> this one): 4096^3 121 -> 187,
+// LSTM input GEMM 117 -> 168, the codec's batched strided views 91..107 -> 99..141 (the ELU-on-load layers gain least: the
+// staging VALU work, not the matrix pipe, is what they wait for).
+#include <stdlib.h>
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bfx2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+  if (act == SSRHIP_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == SSRHIP_ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  return v;
+}
+
+// exact three-way split of 4 consecutive k-values: piece p of element e in out[p][e]
+__device__ __forceinline__ void split4(const float4 v, bf16x4 (&out)[3]) {
+  f32x2 r[2] = {{v.x, v.y}, {v.z, v.w}};
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bfx2 b = __builtin_convertvector(r[h], bfx2);                   // v_cvt_pk_bf16_f32 (RNE)
+      const unsigned bits = __builtin_bit_cast(unsigned, b);
+      out[p][2 * h] = (short)(bits & 0xFFFFu);
+      out[p][2 * h + 1] = (short)(bits >> 16);
+      if (p < 2) {
+        const f32x2 back = {__builtin_bit_cast(float, bits << 16), __builtin_bit_cast(float, bits & 0xFFFF0000u)};
+        r[h] = r[h] - back;                                                 // exact: the residual has fewer significant bits than fp32 holds
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ W, short* __restrict__ out, size_t n_elems) {
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n_elems; i += (size_t)gridDim.x * blockDim.x * 4) {
+    bf16x4 p[3];
+    split4(ld4(W + i), p);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(out + (size_t)q * n_elems + i) = p[q];
+  }
+}
+
+constexpr int BN = 128, BK = 32, PITCH = 40;                                // pitch in bf16 elements (80 B)
+
+// BM = 128: 2 x 2 waves of 64 x 64 (2 x 2 accumulators); BM = 64: 1 x 4 waves of 64 x 32 (2 x 1) for grids that 128-row tiles would not
+// fill. Per output element both do the same arithmetic (k blocks of 16 in order, the six products in the same order), so a result does
+// not depend on which tile shape — i.e. on which batch size — computed it.
+template <int BM, bool ELU>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(const ssrhip_gemm_args a0) {
+  constexpr int MT = 2, NT = BM == 128 ? 2 : 1;
+  constexpr int LA = BM / 32;
+  __shared__ __attribute__((aligned(16))) short As[3][BM * PITCH];
+  __shared__ __attribute__((aligned(16))) short Ws[3][BN * PITCH];
+  ssrhip_gemm_args a = a0;
+  {   // batched problems: grid.z
+    const size_t z = blockIdx.z;
+    a.A += z * (size_t)a.strideA;
+    a.C += z * (size_t)a.strideC;
+    if (a.R) a.R += z * (size_t)a.strideR;
+    if (a.rclass) a.rclass += z * (size_t)a.rclass_stride;
+  }
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = BM == 128 ? wave >> 1 : 0, wn = BM == 128 ? wave & 1 : wave;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int lr = t >> 3, lc = (t & 7) * 4;                                  // A loader: 8 threads per row (32 k), 32 rows per pass
+  const int lw = t >> 2, cw = (t & 3) * 8;                                  // W loader: 4 threads per row (8 k each), 64 rows per pass
+  const int M = a.M, N = a.N, K = a.K;
+  const short* Wp = reinterpret_cast<const short*>(a.W_split);
+  const size_t plane = (size_t)N * K;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[LA];
+  bf16x8 rwp[3][2];
+  auto gload = [&](int k0) {
+    const bool kin = (k0 + lc) < K;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int m = m0 + lr + 32 * i;
+      ra[i] = (kin && m < M) ? ld4(a.A + (size_t)m * a.lda + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ELU) { ra[i].x = elu1(ra[i].x); ra[i].y = elu1(ra[i].y); ra[i].z = elu1(ra[i].z); ra[i].w = elu1(ra[i].w); }
+    }
+    const bool kinw = (k0 + cw) < K;                                        // K % 8 == 0 (checked by the host)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = n0 + lw + 64 * i;
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        rwp[q][i] = (kinw && n < N) ? *reinterpret_cast<const bf16x8*>(Wp + (size_t)q * plane + (size_t)n * K + k0 + cw) : z;
+      }
+  };
+  auto lds_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      bf16x4 p[3];
+      split4(ra[i], p);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(&As[q][(lr + 32 * i) * PITCH + lc]) = p[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<bf16x8*>(&Ws[q][(lw + 64 * i) * PITCH + cw]) = rwp[q][i];
+  };
+  auto mma_tile = [&]() {
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      bf16x8 fa[3][MT], fb[3][NT];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[q][i] = *reinterpret_cast<const bf16x8*>(&As[q][((wm * MT + i) * 32 + li) * PITCH + kk + lh * 8]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[q][j] = *reinterpret_cast<const bf16x8*>(&Ws[q][((wn * NT + j) * 32 + li) * PITCH + kk + lh * 8]);
+      }
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // a2w0, a0w2, a1w1, a1w0, a0w1, a0w0
+#pragma unroll
+      for (int pq = 0; pq < 6; ++pq)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pq]][i], fb[PB[pq]][j], acc[i][j], 0, 0, 0);
+    }
+  };
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();                                                       // previous tile fully consumed
+    lds_store();
+    __syncthreads();
+    if (k0 + BK < K) gload(k0 + BK);                                        // prefetch next tile under the MFMAs
+    mma_tile();
+  }
+  // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) — identical to gemm.hip's
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + (wn * NT + j) * 32 + li;
+    if (n >= N) continue;
+    const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M) {
+          if (a.tm_c > 0) {
+            const long u = ((long)m * N + n) / a.tm_c;
+            if (u < a.tm_lo || u >= a.tm_hi) continue;
+          }
+          float v = act_fn(acc[mt][j][r] + bias, a.act);
+          float* c = a.C + (size_t)m * a.ldc + n;
+          if (a.residual) v += *c;
+          if (a.R) v += a.R[(size_t)m * a.ldr + n];
+          if (a.rbias) v += a.rbias[(size_t)a.rclass[m / a.rrep] * N + n];
+          *c = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// true when the split kernel applies to this call (decided by ssrhip_gemm). It depends on the matrix (N, K) and on what the caller
+// supplied — never on M or the batch: an item's result must not change with the batch it is computed in (codec batch lanes,
+// decode_ragged == batch-1 decode).
+bool ssrhip_gemm_split_eligible(const ssrhip_gemm_args* a) {
+  if (!a->W_split || a->N <= 64 || a->K % 8 != 0 || a->lda % 4 != 0) return false;
+  static const int off = getenv("SSRHIP_GEMM_SPLIT") && getenv("SSRHIP_GEMM_SPLIT")[0] == '0';   // A/B knob: always the exact fp32 chain
+  return !off && (a->M + 63) / 64 <= 65535 && a->batch <= 65535;
+}
+
+int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
+  const long nb = a->batch > 1 ? a->batch : 1;
+  const long tiles128 = (long)((a->N + BN - 1) / BN) * ((a->M + 127) / 128) * nb;
+  const bool elu = a->act_in == SSRHIP_ACT_ELU;
+  if (tiles128 >= 384) {                                             // enough 128-row tiles for two workgroups on most CUs
+    dim3 grid((a->N + BN - 1) / BN, (a->M + 127) / 128, (unsigned)nb);
+    if (elu) hipLaunchKernelGGL((gemm_split_kernel<128, true>), grid, dim3(256), 0, s, *a);
+    else hipLaunchKernelGGL((gemm_split_kernel<128, false>), grid, dim3(256), 0, s, *a);
+  } else {
+    dim3 grid((a->N + BN - 1) / BN, (a->M + 63) / 64, (unsigned)nb);
+    if (elu) hipLaunchKernelGGL((gemm_split_kernel<64, true>), grid, dim3(256), 0, s, *a);
+    else hipLaunchKernelGGL((gemm_split_kernel<64, false>), grid, dim3(256), 0, s, *a);
+  }
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ssrhip_split_weights(const float* W, uint16_t* out, int64_t n_elems, ssrhip_stream_t stream) {
+  SSR_REQUIRE(W && out && n_elems > 0 && n_elems % 4 == 0, "ssrhip_split_weights: bad argument (n_elems must be a positive multiple of 4)");
+  long blocks = (n_elems / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, W, reinterpret_cast<short*>(out), (size_t)n_elems);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}

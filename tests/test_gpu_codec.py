@@ -132,8 +132,9 @@ def test_lstm_wide_step_kernel_large_batch(B):
 
 @pytest.mark.parametrize("lanes,B", [(2, 20), (3, 27), (2, 17)])
 def test_batch_lanes_equal_one_lane(lanes, B):
-    """A batch is cut into lanes that run on their own streams (one lane's LSTM overlaps the other's convolutions). Every public
-    entry point must return what the single-lane run returns: same kernels per item, only the launch grouping differs."""
+    """A batch is cut into lanes that run one after the other (a memory knob: a lane's intermediates are freed before the next
+    lane allocates). Every public entry point must return what the single-lane run returns: same arithmetic per item, only the
+    launch grouping (and with it the tile shape of the large GEMMs and the LSTM's batch tile) differs."""
     cfg = W.codec_config_full()
     sd = W.codec_state_dict(cfg, seed=21)
     m = WMEncodecModel(cfg, sd, "cuda")

@@ -598,6 +598,90 @@ def test_gemm_batched_strided_view_with_every_codec_extension(L):
     assert (got[:, :lo] == -7.0).all() and (got[:, hi:] == -7.0).all()
 
 
+def _split_planes(L, dW):
+    planes = torch.empty(3, dW.shape[0], dW.shape[1], dtype=torch.int16, device="cuda")
+    _lib.check(L.ssrhip_split_weights(dW.data_ptr(), planes.data_ptr(), dW.numel(), _lib.stream_ptr()))
+    return planes
+
+
+def test_split_weights_is_an_exact_three_way_split(L):
+    """w == w0 + w1 + w2 EXACTLY (bf16 pieces, fp32 sums in any order of the two small ones first), for random full-mantissa values,
+    tiny and huge magnitudes, zeros and negative values (magnitudes whose 2^-16 residual would be an fp32 subnormal, |w| < ~1e-33, lose the third piece: subnormals are flushed)."""
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(64, 96, generator=g) * torch.logspace(-20, 20, 64 * 96).view(64, 96)[torch.randperm(64, generator=g)]
+    w[0, :8] = 0.0
+    w[1, :8] = torch.tensor([1.0, -1.0, 3.0e-29, 65504.0, -1.0000001, 0.33333334, 1e-30, -7.5])
+    planes = _split_planes(L, dev(w)).cpu()
+    pieces = (planes.to(torch.int32) << 16).view(torch.float32)           # bf16 bits -> fp32
+    recon = (pieces[2].double() + pieces[1].double() + pieces[0].double())
+    assert torch.equal(recon.float(), w) and torch.equal(recon, w.double())      # exact, not merely close
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(3000, 2056, 1000, 2, 1), (4096, 512, 2048, 0, 0), (50000, 128, 264, 1, 0), (300, 200, 64, 0, 1), (77, 1030, 8, 2, 0)])
+def test_gemm_split_bf16x3_is_as_accurate_as_the_fp32_chain(L, M, N, K, act, res):
+    """csrc/gemm_split.hip (taken when the caller supplies the bf16 weight planes and the grid is large): fp32 operands split exactly
+    into three bf16 pieces, six cross products on the bf16 matrix cores. Against an fp64 reference its error must be no worse than
+    1.5x the exact fp32 MFMA chain's (it is usually smaller: its products are exact), and within the GEMM's usual 3e-5 of torch."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    Wt = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    c0 = torch.randn(M, N, generator=g)
+    ref64 = A.double() @ Wt.double().t() + bias.double()
+    ref64 = F.relu(ref64) if act == 1 else (F.gelu(ref64) if act == 2 else ref64)
+    ref64 = c0.double() + ref64 if res else ref64
+    dA, dW, db = dev(A), dev(Wt), dev(bias)
+    planes = _split_planes(L, dW)
+    outs = []
+    for use_split in (False, True):
+        dC = dev(c0.clone())
+        a = _lib.GemmArgs(dA.data_ptr(), dW.data_ptr(), db.data_ptr(), dC.data_ptr(), M, N, K, K, N, act, res)
+        a.W_split = planes.data_ptr() if use_split else 0
+        _lib.check(L.ssrhip_gemm(C.byref(a), _lib.stream_ptr()))
+        sync()
+        outs.append(dC.cpu())
+    exact, split = outs
+    assert not torch.equal(exact, split)                                   # really another kernel
+    e_exact = (exact.double() - ref64).abs().max().item()
+    e_split = (split.double() - ref64).abs().max().item()
+    assert e_split <= 1.5 * e_exact + 1e-7, (e_split, e_exact)
+    torch.testing.assert_close(split, ref64.float(), rtol=3e-5, atol=3e-5)
+
+
+def test_gemm_split_takes_every_codec_extension(L, monkeypatch):
+    """The split kernel behind the same call as `test_gemm_batched_strided_view_with_every_codec_extension` (strided view, ELU on load,
+    skip tensor, time mask, per-row class bias, batch): equal to the exact kernel within the GEMM tolerance."""
+    g = torch.Generator().manual_seed(78)
+    B, Cin, k, s, Cout, T = 3, 32, 4, 2, 160, 20000
+    rows = T * s + k
+    x = torch.randn(B, rows, Cin, generator=g)
+    Wt = torch.randn(Cout, k * Cin, generator=g) / math.sqrt(k * Cin)
+    bias = torch.randn(Cout, generator=g)
+    R = torch.randn(B, T, Cout, generator=g)
+    cls_bias = torch.randn(2, Cout, generator=g)
+    rep = 50
+    cls = torch.randint(0, 2, (B, T // rep), generator=g, dtype=torch.int32)
+    dx, dW, db, dR, dcb, dcl = dev(x), dev(Wt), dev(bias), dev(R), dev(cls_bias), dev(cls)
+    planes = _split_planes(L, dW)
+    outs = []
+    for use_split in (False, True):
+        out = torch.full((B, T, Cout), -7.0, device="cuda")
+        a = _lib.GemmArgs()
+        a.A, a.W, a.bias, a.C = dx.data_ptr(), dW.data_ptr(), db.data_ptr(), out.data_ptr()
+        a.M, a.N, a.K, a.lda, a.ldc = T, Cout, k * Cin, s * Cin, Cout
+        a.act_in, a.R, a.ldr, a.batch = _lib.ACT_ELU, dR.data_ptr(), Cout, B
+        a.strideA, a.strideC, a.strideR = rows * Cin, T * Cout, T * Cout
+        a.rbias, a.rclass, a.rrep, a.rclass_stride = dcb.data_ptr(), dcl.data_ptr(), rep, T // rep
+        a.tm_c, a.tm_lo, a.tm_hi = Cout, 3, T - 5
+        a.W_split = planes.data_ptr() if use_split else 0
+        _lib.check(L.ssrhip_gemm(C.byref(a), _lib.stream_ptr()))
+        sync()
+        outs.append(out.cpu())
+    assert not torch.equal(outs[0], outs[1])
+    torch.testing.assert_close(outs[1], outs[0], rtol=3e-5, atol=3e-5)
+    assert (outs[1][:, :3] == -7.0).all() and (outs[1][:, T - 5:] == -7.0).all()
+
+
 def test_gemm_is_transpose_safe(L):
     """A = I with an ASYMMETRIC W: catches a swapped C/D lane map (cdna guide §3)."""
     n = 96
@@ -828,3 +912,29 @@ def test_sampler_filter_golden(L, golden_dir):
                 want = torch.argmax(probs / noise, -1)
                 for row in (0, 3):
                     assert got[3, row] == want[row], (k, p, trial, row)
+
+
+def test_gemm_split_result_of_an_item_does_not_depend_on_the_batch(L):
+    """The split GEMM picks 64- or 128-row tiles by the size of the grid (i.e. by the batch); per output element both do the same
+    arithmetic, so item 0 of a batch of 12 (128-row tiles) must be BIT-identical to the same item computed alone (64-row tiles)."""
+    g = torch.Generator().manual_seed(91)
+    M, N, K, B = 1500, 512, 1024, 12
+    A = torch.randn(B, M, K, generator=g)
+    Wt = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    dA, dW, db = dev(A), dev(Wt), dev(bias)
+    planes = _split_planes(L, dW)
+
+    def run(batch):
+        out = torch.zeros(batch, M, N, device="cuda")
+        a = _lib.GemmArgs()
+        a.A, a.W, a.bias, a.C = dA.data_ptr(), dW.data_ptr(), db.data_ptr(), out.data_ptr()
+        a.M, a.N, a.K, a.lda, a.ldc = M, N, K, K, N
+        a.act_in, a.batch, a.strideA, a.strideC = _lib.ACT_ELU, batch, M * K, M * N
+        a.W_split = planes.data_ptr()
+        _lib.check(L.ssrhip_gemm(C.byref(a), _lib.stream_ptr()))
+        sync()
+        return out.cpu()
+
+    alone, many = run(1), run(B)
+    assert torch.equal(alone[0], many[0])
