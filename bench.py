@@ -344,6 +344,29 @@ def codec256_leg(dev, world, rank, dist, all_ok=lambda ok: ok):
         err = e
     if not all_ok(err is None):
         raise RuntimeError(f"codec256 failed on {'this' if err is not None else 'another'} rank: {err!r}")
+    # the same encode + decode with every GEMM on the exact fp32 FMA chain (the default path runs the codec's large GEMMs on the bf16
+    # matrix cores with exactly split fp32 operands, csrc/gemm_split.hip: fp32-accurate, not bit-identical to the chain)
+    exact = {}
+    try:
+        m.split_gemm = False
+        m.encode(wav[: max(B // 8, 1)])                       # touch the exact kernels once
+        torch.cuda.synchronize()
+        x0 = time.perf_counter()
+        c_ex, _, _ = m.encode(wav)
+        torch.cuda.synchronize()
+        x1 = time.perf_counter()
+        o_ex = m.decode(c_ex)
+        torch.cuda.synchronize()
+        x2 = time.perf_counter()
+        exact = {"enc": x1 - x0, "dec": x2 - x1, "max_abs_wav_diff_vs_default": float((o_ex - out).abs().max()) if torch.equal(c_ex, codes) else None,
+                 "code_mismatch_vs_default": float((c_ex != codes).float().mean())}
+        del c_ex, o_ex
+    except Exception as e:                                 # noqa: BLE001
+        err = e
+    finally:
+        m.split_gemm = True
+    if not all_ok(err is None):
+        raise RuntimeError(f"codec256 exact-fp32 pass failed on {'this' if err is not None else 'another'} rank: {err!r}")
     # wmdecode (the --use_watermark product path, seanet.py:555-600; SURVEY §8d config 5: marks = second half ones), without and with
     # the detector pass. Its skip encoder keeps four feature maps alive beside the decoder's activations: run in 4 batch lanes
     # (WMEncodecModel.lanes: same results, a quarter of the peak memory at 2-4 % of the throughput).
@@ -370,9 +393,9 @@ def codec256_leg(dev, world, rank, dist, all_ok=lambda ok: ok):
     if not all_ok(err is None):
         raise RuntimeError(f"codec256 wmdecode failed on {'this' if err is not None else 'another'} rank: {err!r}")
     if dist is not None:
-        tt = torch.tensor([enc, dec, wm_ms[False], wm_ms[True]], device=dev, dtype=torch.float64)
+        tt = torch.tensor([enc, dec, wm_ms[False], wm_ms[True], exact["enc"], exact["dec"]], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        enc, dec, wm_ms[False], wm_ms[True] = (float(v) for v in tt)
+        enc, dec, wm_ms[False], wm_ms[True], exact["enc"], exact["dec"] = (float(v) for v in tt)
     GF, audio_s = 6.97e9, 256 * 30.0
     return {"workload": f"256 clips x 30 s, {B} per GPU, full wmencodec config, synthetic weights", "n_gpus": world,
             "wmdecode_ms": round(1000 * wm_ms[False], 1), "wmdecode_with_detector_ms": round(1000 * wm_ms[True], 1),
@@ -380,6 +403,13 @@ def codec256_leg(dev, world, rank, dist, all_ok=lambda ok: ok):
             "wmdecode_with_detector_tflops_per_gpu": round(21.69e9 * audio_s / wm_ms[True] / 1e12 / world, 1),
             "wmdecode_note": f"marks = second half ones; {m.lanes} batch lane(s); 14.5 / 21.69 GFLOP per audio-second without / with the detector (SURVEY 8d)",
             "peak_mem_gib_encode_decode": round(peak_plain / 2 ** 30, 1),
+            "gemm": "large GEMMs (N > 64) on the bf16 matrix cores, fp32 operands split exactly into 3 bf16 pieces, 6 cross products, fp32 accumulation "
+                    "(csrc/gemm_split.hip: error vs fp64 <= the fp32 FMA chain's); SSRHIP_GEMM_SPLIT=0 = the chain",
+            "exact_fp32_chain": {"encode_ms": round(1000 * exact["enc"], 1), "decode_ms": round(1000 * exact["dec"], 1),
+                                 "encode_tflops_per_gpu": round(GF * audio_s / exact["enc"] / 1e12 / world, 1),
+                                 "decode_tflops_per_gpu": round(GF * audio_s / exact["dec"] / 1e12 / world, 1),
+                                 "code_mismatch_vs_default": exact.get("code_mismatch_vs_default"),
+                                 "max_abs_wav_diff_vs_default": exact.get("max_abs_wav_diff_vs_default")},
             "encode_ms": round(1000 * enc, 1), "decode_ms": round(1000 * dec, 1),
             "encode_audio_s_per_s": round(audio_s / enc, 1), "decode_audio_s_per_s": round(audio_s / dec, 1),
             "encode_tflops_per_gpu": round(GF * audio_s / enc / 1e12 / world, 1), "decode_tflops_per_gpu": round(GF * audio_s / dec / 1e12 / world, 1),

@@ -228,6 +228,10 @@ typedef struct ssrhip_gemm_args {
    * fp64 reference no larger than the fp32 chain's), ~1.3-1.5x the speed, NOT bit-identical to the k-ordered fp32 chain. The codec
    * passes it (parity bar: waveform tolerance); the LM prefill does not (greedy tokens are compared bit for bit). */
   const uint16_t* W_split;
+  /* SSRHIP_ACT_ELU: apply ELU(alpha = 1) LAST — after act, residual, R and the class bias — i.e. store what the consumer would compute
+   * on load. For tensors that are only ever read through ELU (SEANet: a residual block's output feeds `ELU -> conv`, seanet.py:137-141,
+   * 236-247) the activation then runs once per element in the producer instead of once per (tap, column block) in every consumer. */
+  int32_t act_out;
 } ssrhip_gemm_args;
 int ssrhip_gemm(const ssrhip_gemm_args* a, ssrhip_stream_t stream);
 /* W fp32 [n_elems] -> out bf16 [3][n_elems]: piece p of element i at out[p * n_elems + i], w = w0 + w1 + w2 exactly
@@ -279,6 +283,7 @@ typedef struct ssrhip_lstm_args {
    * packed[C/4 tiles][C/16 k-steps][4 k-slots][16 rows][4 floats] with row r of tile j = W_hh[(r % 4) * C + 4j + r / 4] (gate r % 4 of
    * hidden unit 4j + r / 4), so that one wave-level load is one contiguous KiB instead of 64 pieces of 16 rows */
   int32_t w_packed;
+  int32_t out_act;   /* SSRHIP_ACT_ELU: out = ELU(h_t (+ skip)) (the layer's only consumer is `ELU -> conv`: seanet.py:147-150, 226-236) */
 } ssrhip_lstm_args;
 int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stream);
 /* residual vector quantisation (quantization/core_vq.py:164-179, 382-400): emb [B][T][D] time-major;
@@ -297,6 +302,7 @@ typedef struct ssrhip_resblock_args {
   const float* w3; const float* b3; const float* w1; const float* b1;
   int32_t B, T, C;
   int64_t x_bstride, y_bstride;   /* elements between items */
+  int32_t out_act;                /* SSRHIP_ACT_ELU: y = ELU(block(x)): the block's only consumer is `ELU -> conv` */
 } ssrhip_resblock_args;
 int ssrhip_resblock(const ssrhip_resblock_args* a, ssrhip_stream_t stream);
 

@@ -92,7 +92,7 @@ class GemmArgs(C.Structure):
                 ("strideA", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
                 ("tm_c", C.c_int32), ("tm_lo", C.c_int32), ("tm_hi", C.c_int32),
                 ("rbias", C.c_void_p), ("rclass", C.c_void_p), ("rrep", C.c_int32), ("rclass_stride", C.c_int32),
-                ("W_split", C.c_void_p)]
+                ("W_split", C.c_void_p), ("act_out", C.c_int32)]
 
 
 class LstmArgs(C.Structure):
@@ -100,7 +100,7 @@ class LstmArgs(C.Structure):
                 ("hbuf", C.c_void_p), ("cbuf", C.c_void_p), ("gates", C.c_void_p),
                 ("B", C.c_int32), ("T", C.c_int32), ("C", C.c_int32),
                 ("gin_bstride", C.c_int64), ("out_bstride", C.c_int64), ("skip_bstride", C.c_int64),
-                ("t_begin", C.c_int32), ("t_end", C.c_int32), ("w_packed", C.c_int32)]
+                ("t_begin", C.c_int32), ("t_end", C.c_int32), ("w_packed", C.c_int32), ("out_act", C.c_int32)]
 
 
 _PP = C.POINTER(C.c_void_p)
@@ -108,7 +108,8 @@ _PP = C.POINTER(C.c_void_p)
 
 class ResblockArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
-                ("B", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("x_bstride", C.c_int64), ("y_bstride", C.c_int64)]
+                ("B", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("x_bstride", C.c_int64), ("y_bstride", C.c_int64),
+                ("out_act", C.c_int32)]
 
 
 class LMWeights(C.Structure):

@@ -33,6 +33,7 @@ class TM:
     def __init__(self, B: int, T: int, Cc: int, padL: int, padR: int, device, lens: "Optional[Ragged]" = None):
         self.B, self.T, self.C, self.padL, self.padR = B, T, Cc, padL, padR
         self.lens = lens                   # ragged batch: per-item valid rows (None = every item has T rows)
+        self.elu = False                   # True: the producer stored ELU(y) (its only consumers read it through ELU: they skip theirs)
         self.rows = padL + T + padR
         # every producer writes the whole interior; only the halo rows need a defined value before the consumer reads them
         # (zero for constant / structural padding; reflect padding overwrites them). A torch.zeros of the whole buffer was 24
@@ -202,6 +203,8 @@ class WMEncodecModel:
         # fp32 GEMMs on the bf16 matrix cores with exactly split operands (csrc/gemm_split.hip; SSRHIP_GEMM_SPLIT=0: the fp32 FMA chain)
         self.split_gemm = os.environ.get("SSRHIP_GEMM_SPLIT", "1") != "0"
         self._plane_cache = {}
+        # ELU on store instead of ELU on load wherever a tensor is only read through ELU (SSRHIP_ELU_ON_STORE=0: every consumer applies it)
+        self.elu_on_store = os.environ.get("SSRHIP_ELU_ON_STORE", "1") != "0"
         self.lanes = int(os.environ.get("SSRHIP_CODEC_LANES", "1"))
         self.lane_min_items = int(os.environ.get("SSRHIP_CODEC_LANE_MIN", "8"))
         self._side_streams, self._keep = {}, {}
@@ -274,8 +277,9 @@ class WMEncodecModel:
             self._plane_cache[key] = hit
         return hit
 
-    def _gemm(self, A, W, bias, Cp, M, N, K, lda, ldc, act_in=0, R=0, ldr=0, batch=1, sA=0, sC=0, sR=0, tm=(0, 0, 0), rowcls=None):
+    def _gemm(self, A, W, bias, Cp, M, N, K, lda, ldc, act_in=0, R=0, ldr=0, batch=1, sA=0, sC=0, sR=0, tm=(0, 0, 0), rowcls=None, act_out=0):
         a = _lib.GemmArgs()
+        a.act_out = act_out
         a.A, a.W, a.bias, a.C = A, W.data_ptr(), (bias.data_ptr() if bias is not None else 0), Cp
         planes = self._planes(W)
         a.W_split = planes.data_ptr() if planes is not None else 0
@@ -322,22 +326,32 @@ class WMEncodecModel:
         return TM(B, T, Cc, pl, pr, self.device, lens)
 
     # ------------------------------------------------------------------ nodes
-    def _conv(self, c: _Conv, x: TM, nxt, R: Optional[TM] = None) -> TM:
+    def _act_in(self, wants_elu: bool, x: TM) -> int:
+        """ELU-on-load flag of a consumer: needed unless the producer already stored ELU(x) (`x.elu`). A consumer that wants the RAW
+        tensor must never be handed an ELU'd one."""
+        if x.elu and not wants_elu:
+            raise AssertionError("a layer that reads its input without ELU was given a tensor stored through ELU")
+        return _lib.ACT_ELU if (wants_elu and not x.elu) else 0
+
+    def _conv(self, c: _Conv, x: TM, nxt, R: Optional[TM] = None, post_elu: bool = False) -> TM:
+        """`post_elu`: store ELU(result) (the caller knows that every consumer reads this output through ELU; `self.elu_on_store`)."""
         B = x.B
         T_out = (x.T + x.padL + x.padR - c.k) // c.s + 1
         out = self._alloc_for(B, T_out, c.Cout, nxt, x.lens.scaled(1, c.s) if x.lens is not None else None)
+        act_in = self._act_in(bool(c.act_in), x)
         if c.Cin == 1:
-            assert c.act_in == 0
+            assert c.act_in == 0 and not post_elu
             _lib.check(self.lib.ssrhip_conv_cin1(x.base, c.Wraw.data_ptr(), c.b.data_ptr(), out.interior, B, T_out, c.k, c.s, c.Cout,
                                                  x.bstride, out.bstride, self._s()), "ssrhip_conv_cin1")
-        elif c.Cout <= 4 and c.s == 1 and R is None and c.Cin % 8 == 0 and (T_out >= 4096 or self.force_few_out):
+        elif c.Cout <= 4 and c.s == 1 and R is None and c.Cin % 8 == 0 and (T_out >= 4096 or self.force_few_out) and not post_elu:
             # the 1-channel output layer at the sample rate: a read-bound dot-product kernel instead of a GEMM tile with 1 useful column
             _lib.check(self.lib.ssrhip_conv_few_out(x.base, c.W.data_ptr(), c.b.data_ptr(), out.interior, B, T_out, c.k, c.Cin, c.Cout,
-                                                    (_lib.ACT_ELU if c.act_in else 0), x.bstride, out.bstride, self._s()), "ssrhip_conv_few_out")
+                                                    act_in, x.bstride, out.bstride, self._s()), "ssrhip_conv_few_out")
         else:
-            self._gemm(x.base, c.W, c.b, out.interior, T_out, c.Cout, c.k * c.Cin, c.s * c.Cin, c.Cout, act_in=(_lib.ACT_ELU if c.act_in else 0),
+            self._gemm(x.base, c.W, c.b, out.interior, T_out, c.Cout, c.k * c.Cin, c.s * c.Cin, c.Cout, act_in=act_in,
                        R=(R.interior if R is not None else 0), ldr=(R.C if R is not None else 0), batch=B, sA=x.bstride, sC=out.bstride,
-                       sR=(R.bstride if R is not None else 0))
+                       sR=(R.bstride if R is not None else 0), act_out=(_lib.ACT_ELU if post_elu else 0))
+        out.elu = post_elu
         self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
         return out
 
@@ -346,13 +360,14 @@ class WMEncodecModel:
         T_out = x.T * c.s
         out = self._alloc_for(x.B, T_out, c.Cout, nxt, x.lens.scaled(c.s) if x.lens is not None else None)
         Cp = out.interior - 4 * c.trim_l * c.Cout
-        self._gemm(x.base, c.W, c.b, Cp, x.T + 1, c.s * c.Cout, 2 * c.Cin, c.Cin, c.s * c.Cout, act_in=_lib.ACT_ELU, batch=x.B,
+        self._gemm(x.base, c.W, c.b, Cp, x.T + 1, c.s * c.Cout, 2 * c.Cin, c.Cin, c.s * c.Cout, act_in=self._act_in(True, x), batch=x.B,
                    sA=x.bstride, sC=out.bstride, tm=(c.Cout, c.trim_l, c.trim_l + T_out))
         self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
         return out
 
-    def _res(self, cs, x: TM, nxt) -> TM:
+    def _res(self, cs, x: TM, nxt, post_elu: bool = False) -> TM:
         c3, c1 = cs
+        assert not x.elu, "a residual block adds its RAW input back (seanet.py:58-60)"
         if self.fuse_resblock and c3.Cin in self.fuse_channels and c3.Cout * 2 == c3.Cin and c3.k == 3 and c3.s == 1 and c1.k == 1 and c1.s == 1 \
                 and x.padL == 1 and x.padR == 1:
             # the whole block as one kernel (csrc/resblock.hip): one read + one write of the activation, the C/2 intermediate stays on chip
@@ -362,22 +377,24 @@ class WMEncodecModel:
             a.w3, a.b3, a.w1, a.b1 = c3.W.data_ptr(), c3.b.data_ptr(), c1.W.data_ptr(), c1.b.data_ptr()
             a.B, a.T, a.C = x.B, x.T, c3.Cin
             a.x_bstride, a.y_bstride = x.bstride, out.bstride
+            a.out_act = _lib.ACT_ELU if post_elu else 0
             _lib.check(self.lib.ssrhip_resblock(C.byref(a), self._s()), "ssrhip_resblock")
+            out.elu = post_elu
             self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
             return out
-        h = self._conv(c3, x, None)
-        return self._conv(c1, h, nxt, R=x)
+        h = self._conv(c3, x, None, post_elu=self.elu_on_store)        # the intermediate feeds only `ELU -> 1x1 conv`
+        return self._conv(c1, h, nxt, R=x, post_elu=post_elu)
 
     LSTM_CHUNK = 64          # time steps per pipeline stage of the two stacked LSTM layers
 
-    def _lstm(self, L: _Lstm, x: TM, nxt) -> TM:
+    def _lstm(self, L: _Lstm, x: TM, nxt, post_elu: bool = False) -> TM:
         """2-layer LSTM + skip (lstm.py:10-25). Each layer: input GEMM over time (MFMA) + one launch per time step. With two
         layers the recurrences are software-pipelined over chunks of LSTM_CHUNK steps on two streams: layer 2 works on chunk
         i (its input GEMM for that chunk, then its steps) while layer 1 already runs chunk i+1 — the step kernels are
         latency-bound and leave most of the GPU idle, so the two chains overlap almost completely."""
         B, T, Cc = x.B, x.T, x.C
         dev = self.device
-        assert x.padL == 0 and x.padR == 0
+        assert x.padL == 0 and x.padR == 0 and not x.elu
         nl = len(L.layers)
         rows = (B + 15) // 16 * 16                                     # include/ssrhip.h ssrhip_lstm_args
         gins = [torch.empty(B, T, 4 * Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
@@ -402,6 +419,7 @@ class WMEncodecModel:
             a.B, a.T, a.C = B, T, Cc
             a.gin_bstride, a.out_bstride, a.skip_bstride = T * 4 * Cc, outs[l].bstride, x.bstride
             a.t_begin, a.t_end = t0, t1
+            a.out_act = _lib.ACT_ELU if (post_elu and l == nl - 1) else 0
             _lib.check(self.lib.ssrhip_lstm_layer(C.byref(a), self._s()), "ssrhip_lstm_layer")
 
         if nl == 2 and T > self.LSTM_CHUNK:
@@ -425,6 +443,7 @@ class WMEncodecModel:
                 in_gemm(l, 0, T)
                 steps(l, 0, T)
         out = outs[-1]
+        out.elu = post_elu
         self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
         self._keep[torch.cuda.current_stream(dev).cuda_stream] = (gins, hbufs, cbufs, outs)
         return out
@@ -464,18 +483,22 @@ class WMEncodecModel:
         return vals[0] if len(vals) == 1 else torch.cat(vals, dim=0)
 
     def _run(self, nodes, x: TM, after=None) -> TM:
-        """Run consecutive nodes; `after` = the node that will consume the result (decides its halo)."""
+        """Run consecutive nodes; `after` = the node that will consume the result (decides its halo and whether the result is stored
+        through ELU: a residual block's or the LSTM's output goes into `ELU -> conv / convtr` and nowhere else — the watermark
+        decoder's skip taps are read through ELU as well, seanet.py:577-591 — so the producer applies the ELU once, on store)."""
         for idx, node in enumerate(nodes):
             nxt = nodes[idx + 1] if idx + 1 < len(nodes) else after
             kind, obj = node[1], node[2]
+            post = self.elu_on_store and kind in ("res", "lstm") and nxt is not None and \
+                ((nxt[1] == "conv" and bool(nxt[2].act_in)) or nxt[1] == "convtr")
             if kind == "conv":
                 x = self._conv(obj, x, nxt)
             elif kind == "convtr":
                 x = self._convtr(obj, x, nxt)
             elif kind == "res":
-                x = self._res(obj, x, nxt)
+                x = self._res(obj, x, nxt, post_elu=post)
             elif kind == "lstm":
-                x = self._lstm(obj, x, nxt)
+                x = self._lstm(obj, x, nxt, post_elu=post)
         return x
 
     def _input_tm(self, wav: torch.Tensor, first, lens: Optional[Ragged] = None) -> TM:
@@ -643,7 +666,8 @@ class WMEncodecModel:
         c, (Wa, cls) = self.wm_proj[j], self.wm_cls[j]
         assert skip.T == x.T and skip.C == Wa.shape[1] and labels32.shape[1] * rep >= skip.T, (skip.T, x.T, skip.C, Wa.shape, labels32.shape, rep)
         out = self._alloc_for(skip.B, skip.T, c.Cout, nxt, skip.lens)
-        self._gemm(skip.interior, Wa, c.b, out.interior, skip.T, c.Cout, skip.C, skip.C, c.Cout, act_in=_lib.ACT_ELU, R=x.interior, ldr=x.C,
+        assert not x.elu
+        self._gemm(skip.interior, Wa, c.b, out.interior, skip.T, c.Cout, skip.C, skip.C, c.Cout, act_in=self._act_in(True, skip), R=x.interior, ldr=x.C,
                    batch=skip.B, sA=skip.bstride, sC=out.bstride, sR=x.bstride, rowcls=(cls, labels32, rep))
         self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
         return out

@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const ssrhip_lstm_args a
     hnext[(size_t)b * C + j] = hn;
     float o = hn;
     if (a.skip) o += a.skip[(size_t)b * a.skip_bstride + (size_t)t * C + j];
+    if (a.out_act == SSRHIP_ACT_ELU) o = elu1(o);
     a.out[(size_t)b * a.out_bstride + (size_t)t * C + j] = o;
   }
 }
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(const ssrhip_lstm_a
     hnext[(size_t)bt * 16 * C + SSRHIP_TILED(c, j)] = hn;
     float o = hn;
     if (a.skip) o += a.skip[(size_t)b * a.skip_bstride + (size_t)t * C + j];
+    if (a.out_act == SSRHIP_ACT_ELU) o = elu1(o);
     a.out[(size_t)b * a.out_bstride + (size_t)t * C + j] = o;
   }
 }
@@ -409,6 +411,7 @@ __global__ __launch_bounds__(256) void lstm_step_wide_kernel(const ssrhip_lstm_a
         hnext[(size_t)bt * 16 * C + SSRHIP_TILED(c, j)] = hn;
         float o = hn;
         if (a.skip) o += a.skip[(size_t)b * a.skip_bstride + (size_t)t * C + j];
+        if (a.out_act == SSRHIP_ACT_ELU) o = elu1(o);
         a.out[(size_t)b * a.out_bstride + (size_t)t * C + j] = o;
       }
     }

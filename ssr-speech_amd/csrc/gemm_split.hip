@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const ssrhip_gemm_ar
           if (a.residual) v += *c;
           if (a.R) v += a.R[(size_t)m * a.ldr + n];
           if (a.rbias) v += a.rbias[(size_t)a.rclass[m / a.rrep] * N + n];
+          if (a.act_out == SSRHIP_ACT_ELU) v = elu1(v);          // the consumer's ELU-on-load, done once here
           *c = v;
         }
       }

@@ -128,9 +128,9 @@ __global__ __launch_bounds__(NWAVE * 64) void resblock64_kernel(const ssrhip_res
       const float4 xr = ld4(xin + (size_t)(tt + 1) * C + c4 * 4);
       const float4 v = *reinterpret_cast<const float4*>(xs + row * XS + c4 * 4);
       const float4 bb = ld4(a.b1 + c4 * 4);
-      if (t0 + row < T)
-        *reinterpret_cast<float4*>(yout + (size_t)tt * C + c4 * 4) =
-            make_float4(xr.x + (v.x + bb.x), xr.y + (v.y + bb.y), xr.z + (v.z + bb.z), xr.w + (v.w + bb.w));
+      float4 o = make_float4(xr.x + (v.x + bb.x), xr.y + (v.y + bb.y), xr.z + (v.z + bb.z), xr.w + (v.w + bb.w));
+      if (a.out_act == SSRHIP_ACT_ELU) { o.x = elu_fast(o.x); o.y = elu_fast(o.y); o.z = elu_fast(o.z); o.w = elu_fast(o.w); }
+      if (t0 + row < T) *reinterpret_cast<float4*>(yout + (size_t)tt * C + c4 * 4) = o;
     }
   }
 }
@@ -270,7 +270,11 @@ __global__ __launch_bounds__(256) void resblock_chain_kernel(const ssrhip_resblo
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < T) yout[(size_t)m * CC + n] = xin[(size_t)(m + 1) * CC + n] + (acc2[i][j][r] + b1);
+        if (m < T) {
+          float o = xin[(size_t)(m + 1) * CC + n] + (acc2[i][j][r] + b1);
+          if (a.out_act == SSRHIP_ACT_ELU) o = elu_fast(o);
+          yout[(size_t)m * CC + n] = o;
+        }
       }
   }
 }

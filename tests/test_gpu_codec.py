@@ -282,7 +282,7 @@ def test_every_seanet_layer_matches_the_reference(golden_dir, name):
         m._fill_pads(buf, structural_zero=(nxt is not None and nxt[1] == "convtr"))
         return buf
 
-    checked = 0
+    checked = stored_through_elu = 0
     for pfx, net, first_in in (("enc_", m.encoder, None), ("dec_", m.decoder, None)):
         nodes = net.nodes
         for idx, node in enumerate(nodes):
@@ -296,8 +296,53 @@ def test_every_seanet_layer_matches_the_reference(golden_dir, name):
                 x = as_tm(g[f"{pfx}{nodes[idx - 1][3]}"], node)          # the reference's output of the previous node
             y = m._run([node], x, after=nxt)
             want = g[f"{pfx}{node[3]}"]
+            if y.elu:        # a residual block / the LSTM stores ELU(output): its only consumers read it through ELU (wmencodec._run)
+                want = torch.nn.functional.elu(torch.from_numpy(want)).numpy()
+                stored_through_elu += 1
             got = y.interior_view().permute(0, 2, 1).cpu().numpy()
             assert got.shape == want.shape, (pfx, node[0], node[1], got.shape, want.shape)
             np.testing.assert_allclose(got, want, rtol=0, atol=5e-5, err_msg=f"{pfx}{node[3]} ({node[1]})")
             checked += 1
     assert checked == len(m.encoder.nodes) + len(m.decoder.nodes) >= 22
+    assert stored_through_elu == 10            # 4 + 4 residual blocks and the two LSTMs
+
+
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+def test_elu_on_store_and_split_gemm_equal_the_plain_path(pad_mode, monkeypatch):
+    """Round 3's two codec changes against the path they replace, end to end at the full config (encode, decode, wmdecode with the
+    detector, 5 clips of odd length): (a) ELU applied once by the producer (`elu_on_store`) instead of by every consumer on load — the
+    same function on the same values, so BIT-identical; (b) the GEMMs on the bf16 matrix cores with exactly split operands
+    (`split_gemm`) instead of the fp32 FMA chain — fp32-accurate, so equal within the codec's tolerance, and both within it of the oracle."""
+    import dataclasses
+    cfg = dataclasses.replace(W.codec_config_full(), pad_mode=pad_mode)
+    sd = W.codec_state_dict(cfg, seed=31)
+    g = torch.Generator().manual_seed(8)
+    wav = torch.randn(5, 1, cfg.hop * 13 + 57, generator=g) * 0.2
+
+    def run(split, on_store):
+        m = WMEncodecModel(cfg, sd, "cuda")
+        m.split_gemm, m.elu_on_store = split, on_store
+        if not split:
+            m._plane_cache.clear()
+        codes, _, emb = m.encode(wav.cuda())
+        return m, codes, emb
+
+    m_new, c_new, e_new = run(True, True)
+    m_a, c_a, e_a = run(True, False)
+    m_old, c_old, e_old = run(False, False)
+    assert torch.equal(e_new, e_a) and torch.equal(c_new, c_a)                          # (a) bit-identical
+    torch.testing.assert_close(e_new, e_old, rtol=0, atol=5e-5)                          # (b)
+    o_codes, _, o_emb = OC.encode(sd, wav, cfg)
+    np.testing.assert_allclose(e_new.cpu().numpy(), o_emb.numpy(), rtol=0, atol=ATOL)
+    T = o_codes.shape[-1]
+    labels = (torch.arange(T).unsqueeze(0).repeat(5, 1) % 3 == 0).long()
+    wav_pad = torch.nn.functional.pad(wav, (0, T * cfg.hop - wav.shape[-1]))
+    outs = [(m.decode(o_codes.cuda()),) + m.wmdecode(o_codes.cuda(), labels.cuda(), wav_pad.cuda()) for m in (m_new, m_a, m_old)]
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    for x, y in zip(outs[0], outs[2]):
+        torch.testing.assert_close(x, y, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), OC.decode(sd, o_codes, cfg).numpy(), rtol=0, atol=ATOL)
+    o_w, o_m = OC.wmdecode(sd, o_codes, labels, wav_pad, cfg)
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), o_w.numpy(), rtol=0, atol=ATOL)
+    np.testing.assert_allclose(outs[0][2].cpu().numpy(), o_m.numpy(), rtol=0, atol=ATOL)
