@@ -213,7 +213,12 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
   const long nb = a->batch > 1 ? a->batch : 1;
   const long tiles128 = (long)((a->N + BN - 1) / BN) * ((a->M + 127) / 128) * nb;
   const bool elu = a->act_in == SSRHIP_ACT_ELU;
-  if (tiles128 >= 384) {                                             // enough 128-row tiles for two workgroups on most CUs
+  // 128-row tiles when there are enough of them for two workgroups on most CUs — unless they would be half empty: the LSTM's second
+  // layer projects 64-step chunks (M = 64 per item: a 128-row tile wastes half of its MFMAs; seen in the codec trace: 96 launches of
+  // 212 us at 32 clips)
+  const int waste128 = (a->M + 127) / 128 * 128 - a->M, waste64 = (a->M + 63) / 64 * 64 - a->M;
+  const bool half_empty = waste128 - waste64 >= 64 && 8 * (waste128 - waste64) >= a->M;
+  if (tiles128 >= 384 && !half_empty) {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 127) / 128, (unsigned)nb);
     if (elu) hipLaunchKernelGGL((gemm_split_kernel<128, true>), grid, dim3(256), 0, s, *a);
     else hipLaunchKernelGGL((gemm_split_kernel<128, false>), grid, dim3(256), 0, s, *a);

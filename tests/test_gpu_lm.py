@@ -477,3 +477,42 @@ def test_refill_with_fewer_jobs_than_slots_and_three_rows():
             one = m.inference(u["x"].cuda(), torch.LongTensor([L]), u["x"].cuda(), torch.LongTensor([L]), u["y"].cuda(), u["y"].cuda(),
                               u["mask_interval"].cuda(), kvcache=1, **kw)
             assert torch.equal(res[i][0], one[0]) and res[i][2] == one[2], i
+
+
+def test_run_queue_parks_an_utterance_that_exceeds_its_cap_and_keeps_serving_the_others():
+    """`DecodeEngine.run_queue` with one job whose step cap is far too small: that job comes back unfinished (done == 0, exactly one
+    16-step chunk long) and its slot is parked and refilled; every other job still equals its batch-1 run. `inference_batch` turns
+    such a job into a RuntimeError."""
+    from ssr_speech_amd import layout as LY
+    from ssr_speech_amd.engine import DecodeKnobs
+    args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
+    m = _model(args, 63)
+    g = torch.Generator().manual_seed(15)
+    utts = [dict(x=torch.randint(0, 30, (1, 8 + i), generator=g), y=torch.randint(0, 64, (1, 10 + 2 * i, 4), generator=g),
+                 mask_interval=torch.LongTensor([[[10 + 2 * i, 10 + 2 * i]]])) for i in range(5)]
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, silence_tokens=(3, 7, 11), cfg_coef=1.5, cfg_stride=2)
+    jobs = []
+    for i, u in enumerate(utts):
+        x_np = u["x"].numpy()
+        L = x_np.shape[1]
+        rng = torch.Generator().manual_seed(50 + i)
+        unc = torch.randint(0, m.n_text_tokens, (1, L), generator=rng).numpy()[0]
+        y_np = u["y"][0].transpose(1, 0).numpy()
+        cated, _, num_task, nmi = LY.build_layout(y_np, u["mask_interval"][0].numpy(), m.args)
+        cap = max(10 * L + 2 - cated.shape[1], 1) + num_task * 5
+        jobs.append(dict(text_rows=[x_np[0], unc], audio_cols=cated, gen=rng, cap=(8 if i == 1 else cap),
+                         knobs=DecodeKnobs(use_cfg=True, text_len=L, n_spans=num_task, seed=50 + i, **kw)))
+    eng = m._get_engine(2, True, 512, 256)
+    outs = eng.run_queue(jobs, chunk=16, sampling=False)
+    assert outs[1][0].done == 0 and outs[1][1].shape[0] == 16                    # parked after its first chunk
+    assert eng.pages.n_free == eng.pages.n_pages and eng.n_admitted == 5
+    for i in (0, 2, 3, 4):
+        st, gen = outs[i]
+        assert st.done == 1
+        torch.manual_seed(50 + i)
+        u = utts[i]
+        L = u["x"].shape[1]
+        one = m.inference(u["x"].cuda(), torch.LongTensor([L]), u["x"].cuda(), torch.LongTensor([L]), u["y"].cuda(), u["y"].cuda(),
+                          u["mask_interval"].cuda(), kvcache=1, aug_text=True, top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2,
+                          silence_tokens=[3, 7, 11], cfg_coef=1.5, cfg_stride=2)
+        assert one[0].shape[-1] == u["y"].shape[1] + int(st.n_steps) - 4, i          # generated frames = steps - 3 delay columns - 1 eog column
