@@ -279,6 +279,189 @@ __global__ __launch_bounds__(256) void resblock_chain_kernel(const ssrhip_resblo
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The chained block once more with both GEMMs on the bf16 matrix cores and EXACTLY split fp32 operands (round 3; the arithmetic
+// of csrc/gemm_split.hip: a = a0 + a1 + a2 in bf16 pieces, the six largest cross products accumulated in fp32, error against fp64
+// no larger than the fp32 FMA chain's). Built for C = 128 (the 8 kHz stage: 11 % of the codec's time at 256 clips x 30 s, 65 TFLOP/s
+// on the fp32 pipe). Same structure as the kernel above; what changes:
+//   * A (ELU of the x window) and the W3 / W1 tiles are split between the global load and the LDS store (three bf16 planes per tile,
+//     16 k-values per tile, rows at a 48-byte pitch: a lane's ds_read_b128 = its whole 8-k MFMA operand, conflict-free);
+//   * the C/2-channel intermediate stays in LDS as fp32 (35 KB: three bf16 planes of it would push the workgroup past half a CU's
+//     LDS) and is split by the reading lane into its stage-2 A operand;
+//   * per 16 k-values of a 32 x 32 block: 6 x v_mfma_f32_32x32x16_bf16 = 192 matrix-pipe cycles instead of 8 x 64 = 512.
+typedef short bf16x8_ __attribute__((ext_vector_type(8)));
+typedef short bf16x4_ __attribute__((ext_vector_type(4)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bfx2_ __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split4_(const float4 v, bf16x4_ (&out)[3]) {       // exact three-way split (see gemm_split.hip)
+  f32x2_ r[2] = {{v.x, v.y}, {v.z, v.w}};
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bfx2_ b = __builtin_convertvector(r[h], bfx2_);
+      const unsigned bits = __builtin_bit_cast(unsigned, b);
+      out[p][2 * h] = (short)(bits & 0xFFFFu);
+      out[p][2 * h + 1] = (short)(bits >> 16);
+      if (p < 2) {
+        const f32x2_ back = {__builtin_bit_cast(float, bits << 16), __builtin_bit_cast(float, bits & 0xFFFF0000u)};
+        r[h] = r[h] - back;
+      }
+    }
+  }
+}
+
+template <int CC, int BM>
+__global__ __launch_bounds__(256, 2) void resblock_chain_split_kernel(const ssrhip_resblock_args a) {
+  constexpr int HH = CC / 2, MW = BM / 64, NW = 4 / MW;
+  constexpr int NT1 = HH / (NW * 32), NT2 = CC / (NW * 32);
+  static_assert(MW * NW == 4 && NT1 >= 1 && NT2 >= 1 && NT1 * NW * 32 == HH && NT2 * NW * 32 == CC, "bad tile");
+  constexpr int BKc = 16, PT = 24, LDH = HH + 4;                   // PT: bf16 row pitch (48 B)
+  constexpr int LA = BM / 64, LW3 = HH / 64, LW1 = CC / 64;
+  static_assert(LW3 >= 1, "C >= 128");
+  extern __shared__ __attribute__((aligned(16))) float smem[];    // 70 KB: above the static limit, requested at launch
+  float* Hs = smem;                                                // [BM][LDH] fp32 intermediate
+  short (*As)[BM * PT] = reinterpret_cast<short (*)[BM * PT]>(Hs + BM * LDH);            // [3][BM * PT]
+  short (*Ws)[CC * PT] = reinterpret_cast<short (*)[CC * PT]>(&As[3][0]);                // [3][CC * PT]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / NW, wn = wave % NW;
+  const int lr = t >> 2, lc = (t & 3) * 4;
+  const int T = a.T, m0 = blockIdx.x * BM;
+  const float* xin = a.x + (size_t)blockIdx.y * a.x_bstride;      // row 0 = the halo row in front of t = 0
+  float* yout = a.y + (size_t)blockIdx.y * a.y_bstride;
+  constexpr int K3c = 3 * CC;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // a2w0, a0w2, a1w1, a1w0, a0w1, a0w0 (smallest first)
+
+  // ---------------- stage 1: Hm[BM][HH] = ELU(x-window)[BM][3C] . W3^T
+  f32x16 acc1[2][NT1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT1; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+  float4 ra[LA], rw[LW1];
+  auto gload1 = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const int m = min(m0 + lr + 64 * i, T - 1);                  // rows past T: clamped (their outputs are not stored)
+      const float4 v = ld4(xin + (size_t)m * CC + k0 + lc);        // window of time m = padded rows m, m+1, m+2 = 3C contiguous floats
+      ra[i] = make_float4(elu_fast(v.x), elu_fast(v.y), elu_fast(v.z), elu_fast(v.w));
+    }
+#pragma unroll
+    for (int i = 0; i < LW3; ++i) rw[i] = ld4(a.w3 + (size_t)(lr + 64 * i) * K3c + k0 + lc);
+  };
+  gload1(0);
+  for (int k0 = 0; k0 < K3c; k0 += BKc) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      bf16x4_ p[3];
+      split4_(ra[i], p);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4_*>(&As[q][(lr + 64 * i) * PT + lc]) = p[q];
+    }
+#pragma unroll
+    for (int i = 0; i < LW3; ++i) {
+      bf16x4_ p[3];
+      split4_(rw[i], p);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4_*>(&Ws[q][(lr + 64 * i) * PT + lc]) = p[q];
+    }
+    __syncthreads();
+    if (k0 + BKc < K3c) gload1(k0 + BKc);
+    bf16x8_ fa[3][2], fb[3][NT1];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[q][i] = *reinterpret_cast<const bf16x8_*>(&As[q][(wm * 64 + i * 32 + li) * PT + lh * 8]);
+#pragma unroll
+      for (int j = 0; j < NT1; ++j) fb[q][j] = *reinterpret_cast<const bf16x8_*>(&Ws[q][((wn * NT1 + j) * 32 + li) * PT + lh * 8]);
+    }
+#pragma unroll
+    for (int pq = 0; pq < 6; ++pq)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT1; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pq]][i], fb[PB[pq]][j], acc1[i][j], 0, 0, 0);
+  }
+  // intermediate -> LDS (fp32) with bias + ELU
+#pragma unroll
+  for (int j = 0; j < NT1; ++j) {
+    const int hc = (wn * NT1 + j) * 32 + li;
+    const float b3 = a.b3[hc];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Hs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDH + hc] = elu_fast(acc1[i][j][r] + b3);
+  }
+  // ---------------- stage 2: Y[BM][C] = Hm[BM][HH] . W1^T  (+ b1 + x)
+  f32x16 acc2[2][NT2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+  auto gload2 = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < LW1; ++i) rw[i] = ld4(a.w1 + (size_t)(lr + 64 * i) * HH + k0 + lc);
+  };
+  gload2(0);
+  for (int k0 = 0; k0 < HH; k0 += BKc) {
+    __syncthreads();                                               // first pass: Hs complete and the W3 tile consumed
+#pragma unroll
+    for (int i = 0; i < LW1; ++i) {
+      bf16x4_ p[3];
+      split4_(rw[i], p);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4_*>(&Ws[q][(lr + 64 * i) * PT + lc]) = p[q];
+    }
+    __syncthreads();
+    if (k0 + BKc < HH) gload2(k0 + BKc);
+    bf16x8_ fa[3][2], fb[3][NT2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                  // this lane's 8 k-values of the intermediate, split here
+      const float* hp = &Hs[(wm * 64 + i * 32 + li) * LDH + k0 + lh * 8];
+      bf16x4_ p0[3], p1[3];
+      split4_(*reinterpret_cast<const float4*>(hp), p0);
+      split4_(*reinterpret_cast<const float4*>(hp + 4), p1);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) fa[q][i] = __builtin_shufflevector(p0[q], p1[q], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int j = 0; j < NT2; ++j) fb[q][j] = *reinterpret_cast<const bf16x8_*>(&Ws[q][((wn * NT2 + j) * 32 + li) * PT + lh * 8]);
+#pragma unroll
+    for (int pq = 0; pq < 6; ++pq)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT2; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pq]][i], fb[PB[pq]][j], acc2[i][j], 0, 0, 0);
+  }
+  // ---------------- epilogue: + b1 + x (raw, the centre tap's row)
+#pragma unroll
+  for (int j = 0; j < NT2; ++j) {
+    const int n = (wn * NT2 + j) * 32 + li;
+    const float b1 = a.b1[n];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < T) {
+          float o = xin[(size_t)(m + 1) * CC + n] + (acc2[i][j][r] + b1);
+          if (a.out_act == SSRHIP_ACT_ELU) o = elu_fast(o);
+          yout[(size_t)m * CC + n] = o;
+        }
+      }
+  }
+}
+
 template <int CC, int BM>
 int launch_resblock_chain(const ssrhip_resblock_args* a, hipStream_t s) {
   constexpr int HH = CC / 2;
@@ -301,6 +484,18 @@ extern "C" int ssrhip_resblock(const ssrhip_resblock_args* a, ssrhip_stream_t st
     static const int big = getenv("SSRHIP_RESCHAIN_BIG") ? atoi(getenv("SSRHIP_RESCHAIN_BIG")) : 0;   // tuning knob: the larger row block
     hipStream_t s = (hipStream_t)stream;
     int rc;
+    static const bool split_off = getenv("SSRHIP_GEMM_SPLIT") && getenv("SSRHIP_GEMM_SPLIT")[0] == '0';   // A/B knob: the fp32 FMA chain everywhere
+    if (a->C == 128 && !split_off && !big) {
+      constexpr int SPLIT_SMEM = 128 * 68 * 4 + 3 * 128 * 24 * 2 + 3 * 128 * 24 * 2;     // Hs + As planes + Ws planes = 71,680 B
+      static bool attr_set = false;
+      if (!attr_set) {
+        SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_chain_split_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_SMEM));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((resblock_chain_split_kernel<128, 128>), dim3((a->T + 127) / 128, a->B), dim3(256), SPLIT_SMEM, s, *a);
+      SSR_LAUNCH_CHECK();
+      return 0;
+    }
     if (a->C == 128) rc = big ? launch_resblock_chain<128, 256>(a, s) : launch_resblock_chain<128, 128>(a, s);
     else if (a->C == 256) rc = big ? launch_resblock_chain<256, 128>(a, s) : launch_resblock_chain<256, 64>(a, s);
     else rc = launch_resblock_chain<512, 64>(a, s);
