@@ -86,3 +86,25 @@ def test_generic_and_matrix_core_gemv_kernels_do_not_spill(gemv_asm, tmp_path_fa
     assert len(used) >= 4, sorted(mfma)
     for sym in used:
         assert mfma[sym][1] == 0 and mfma[sym][0] <= 256, (sym, mfma[sym])
+
+
+def test_split_gemm_kernels_use_the_bf16_matrix_core_and_do_not_spill(tmp_path_factory):
+    """Round 3's split kernels (csrc/gemm_split.hip, resblock_chain_split_kernel): two workgroups per CU need <= 256 VGPRs and no
+    scratch; the k-loop must really issue v_mfma_f32_32x32x16_bf16 (six per 16 k-values and accumulator) and v_cvt_pk_bf16_f32 for the
+    on-the-fly split — and no fp32 MFMA at all."""
+    asm = _asm(tmp_path_factory, "gemm_split")
+    meta = {k: v for k, v in _kernel_meta(asm).items() if "gemm_split_kernel" in k}
+    assert len(meta) == 4, sorted(meta)                              # 128- / 64-row tiles x ELU on load or not
+    for sym, (vgpr, scratch) in meta.items():
+        assert vgpr <= 256 and scratch == 0, (sym, vgpr, scratch)
+        body = _body(asm, sym)
+        n_mfma = body.count("v_mfma_f32_32x32x16_bf16")
+        assert n_mfma >= 24 and n_mfma % 6 == 0, (sym, n_mfma)
+        assert "v_cvt_pk_bf16_f32" in body and "v_mfma_f32_32x32x2_f32" not in body, sym
+    rb = _asm(tmp_path_factory, "resblock")
+    chain = {k: v for k, v in _kernel_meta(rb).items() if "resblock_chain_split_kernel" in k}
+    assert len(chain) == 1
+    for sym, (vgpr, scratch) in chain.items():
+        assert vgpr <= 256 and scratch == 0, (sym, vgpr, scratch)
+        body = _body(rb, sym)
+        assert body.count("v_mfma_f32_32x32x16_bf16") >= 36 and "v_mfma_f32_32x32x2_f32" not in body, sym
