@@ -198,6 +198,154 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const ssrhip_gemm_ar
   }
 }
 
+// ---- the 128-row tile, second generation (round 3, after the counters in profiles/r03_split_gemm_pmc.md): same tile, same arithmetic
+// per output element (bit-identical results), restructured for latency hiding:
+//   * 8 waves per workgroup (2 x 4, wave tile 64 x 32 = 2 x 1 accumulators), <= 128 VGPRs: two workgroups per CU = FOUR waves per SIMD
+//     (the 4-wave kernel above keeps two per SIMD waiting on s_waitcnt half of the time: SQ_WAIT_INST_ANY 59 %, MfmaUtil 45 %);
+//   * W goes global -> LDS by the DMA path (buffer_load_dwordx4 ... lds: no staging registers, no ds_write), ONE TILE AHEAD into a second
+//     W stage, so its latency runs under the previous tile's MFMAs; A (which has to pass through the VALU for the split) keeps one stage;
+//   * XOR-swizzled 64-byte rows instead of padded 80-byte ones: row r keeps its 16-byte chunk c in slot c ^ ((r >> 2) & 3). A lane group of
+//     ds_read_b128 (rows {0-3, 12-15, 20-27} or {4-11, 16-19, 28-31} of a 32-row block, one chunk index) touches 16 different slots of
+//     the 256-byte bank row; two rows per 16-lane group of ds_write_b64 = all 32 banks once (the padded rows were 2-way on every store:
+//     SQ_LDS_BANK_CONFLICT = 29 % of the LDS cycles); and the DMA's lane-linear KiB is exactly 16 rows. 73,728 B per workgroup (dynamic);
+//   * branch-free loads: buffer descriptors that end with the tile's last valid row (rows past M / N read as zero, the DMA writes zeros),
+//     a k past K sends the lane's offset out of range (a plain load + select is turned back into a branch around the load, and the branch
+//     makes every wait a vmcnt(0)); the loads are pinned behind the second barrier (sched_barrier: the scheduler sinks them to the end of
+//     the MFMA block otherwise and the next iteration waits for their whole latency).
+// Measured (tools/gemm_split_lab db, one MI355X, fp32-equivalent TFLOP/s, 4-wave kernel -> this one): 4096^3 186 -> 207, LSTM input GEMM
+// 167 -> 196, the codec's strided views 99..137 -> 124..158.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int DMA_PLANE = 128 * 64, DMA_LDS = 9 * DMA_PLANE;          // bytes: one bf16 plane of a 128 x 32 tile; A 3 planes + W 2 x 3 planes
+
+template <bool ELU>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_split_dma_kernel(const ssrhip_gemm_args a0) {
+  extern __shared__ __attribute__((aligned(1024))) char ldsb[];
+  char* const As = ldsb;                                             // [3][128][64 B]
+  char* const Wsb = ldsb + 3 * DMA_PLANE;                            // [2][3][128][64 B]
+  ssrhip_gemm_args a = a0;
+  {   // batched problems: grid.z
+    const size_t z = blockIdx.z;
+    a.A += z * (size_t)a.strideA;
+    a.C += z * (size_t)a.strideC;
+    if (a.R) a.R += z * (size_t)a.strideR;
+    if (a.rclass) a.rclass += z * (size_t)a.rclass_stride;
+  }
+  const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = (wave >> 2) & 1, wn = wave & 3;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * 128;
+  const int lr = t >> 3, lc = (t & 7) * 4;                           // A loader: 8 threads per row (32 k), 64 rows per pass, 2 passes
+  const int M = a.M, N = a.N, K = a.K;
+  const short* Wp = reinterpret_cast<const short*>(a.W_split);
+  const size_t plane = (size_t)N * K;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  float4 ra[2];
+  const int rows_a = min(128, M - m0), rows_w = min(128, N - n0);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A + (size_t)m0 * a.lda), 0,
+                                                                        (int)(((size_t)(rows_a - 1) * a.lda + K) * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    rsW[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(Wp + (size_t)q * plane + (size_t)n0 * K), 0, (int)((size_t)rows_w * K * 2), 0x00020000);
+  unsigned offA[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) offA[i] = (unsigned)(((size_t)(lr + 64 * i) * a.lda + lc) * 4);
+  constexpr unsigned OOB = 0x80000000u;                              // >= every descriptor's extent (checked by the host): reads as zero
+  // W by DMA: wave w brings rows 16w .. 16w+15 of a plane with one instruction; lane l lands in slot l of the wave's KiB = (row 16w + l/4,
+  // slot l%4), which has to hold chunk (l%4) ^ ((row >> 2) & 3)
+  const int wrow = 16 * wave + (lane >> 2), wchunk = (lane & 3) ^ ((lane >> 4) & 3);
+  const unsigned offW = (unsigned)(((size_t)wrow * K + wchunk * 8) * 2);
+  auto gload_a = [&](int k0) {
+    const bool kin = (k0 + lc) < K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, kin ? offA[i] + (unsigned)k0 * 4 : OOB, 0, 0));
+  };
+  auto dma_w = [&](int k0, int stage) {
+    const bool kin = (k0 + wchunk * 8) < K;                          // K % 8 == 0 (checked by the host)
+    const unsigned off = kin ? offW + (unsigned)k0 * 2 : OOB;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW[q], (lds_ptr_t)(Wsb + (stage * 3 + q) * DMA_PLANE + wave * 1024), 16, off, 0, 0, 0);
+  };
+  const int aswz = (((lc >> 3) ^ ((lr >> 2) & 3)) << 4) + ((lc >> 2) & 1) * 8;   // rows lr and lr + 64 share (row >> 2) & 3
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 v = ra[i];
+      if (ELU) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
+      bf16x4 p[3];
+      split4(v, p);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(As + q * DMA_PLANE + (lr + 64 * i) * 64 + aswz) = p[q];
+    }
+  };
+  const int fsw = (li >> 2) & 3;
+  auto mma_tile = [&](int stage) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // a2w0, a0w2, a1w1, a1w0, a0w1, a0w0
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      const int coff = (((kk >> 3) + lh) ^ fsw) << 4;
+      bf16x8 fa[3][2], fb[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[q][i] = *reinterpret_cast<const bf16x8*>(As + q * DMA_PLANE + ((wm * 2 + i) * 32 + li) * 64 + coff);
+        fb[q] = *reinterpret_cast<const bf16x8*>(Wsb + (stage * 3 + q) * DMA_PLANE + (wn * 32 + li) * 64 + coff);
+      }
+#pragma unroll
+      for (int pq = 0; pq < 6; ++pq)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pq]][i], fb[PB[pq]], acc[i], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  gload_a(0);
+  dma_w(0, 0);
+  int stage = 0;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();                                                 // the previous tile is consumed (the A stage, W stage ^ 1)
+    store_a();
+    __syncthreads();                                                 // A(k0) stored, W(k0) landed (the compiler waits for the DMA here)
+    gload_a(k0 + BK);                                                // past K: zeros, never used
+    dma_w(k0 + BK, stage ^ 1);
+    __builtin_amdgcn_sched_barrier(0);                               // keep the loads HERE
+    mma_tile(stage);
+    stage ^= 1;
+  }
+  // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int n = n0 + wn * 32 + li;
+  if (n >= N) return;
+  const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (wm * 2 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < M) {
+        if (a.tm_c > 0) {
+          const long u = ((long)m * N + n) / a.tm_c;
+          if (u < a.tm_lo || u >= a.tm_hi) continue;
+        }
+        float v = act_fn(acc[mt][r] + bias, a.act);
+        float* c = a.C + (size_t)m * a.ldc + n;
+        if (a.residual) v += *c;
+        if (a.R) v += a.R[(size_t)m * a.ldr + n];
+        if (a.rbias) v += a.rbias[(size_t)a.rclass[m / a.rrep] * N + n];
+        if (a.act_out == SSRHIP_ACT_ELU) v = elu1(v);
+        *c = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // true when the split kernel applies to this call (decided by ssrhip_gemm). It depends on the matrix (N, K) and on what the caller
@@ -220,7 +368,19 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
   const bool half_empty = waste128 - waste64 >= 64 && 8 * (waste128 - waste64) >= a->M;
   if (tiles128 >= 384 && !half_empty) {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 127) / 128, (unsigned)nb);
-    if (elu) hipLaunchKernelGGL((gemm_split_kernel<128, true>), grid, dim3(256), 0, s, *a);
+    // the DMA kernel addresses a tile through 32-bit buffer offsets: 128 rows of A (and of a W plane) have to stay below 2 GiB
+    static const bool dma_off = getenv("SSRHIP_GEMM_SPLIT_DMA") && getenv("SSRHIP_GEMM_SPLIT_DMA")[0] == '0';   // A/B knob: the 4-wave kernel
+    const bool dma = !dma_off && ((size_t)127 * a->lda + a->K) * 4 < 0x7FFFFFF0ull && (size_t)128 * a->K * 2 < 0x7FFFFFF0ull;
+    if (dma) {
+      static const int attr = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS);
+        return (int)e;
+      }();
+      SSR_REQUIRE(attr == 0, "ssrhip_gemm: cannot reserve %d bytes of LDS for the split kernel (hip error %d)", DMA_LDS, attr);
+      if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<true>), grid, dim3(512), DMA_LDS, s, *a);
+      else hipLaunchKernelGGL((gemm_split_dma_kernel<false>), grid, dim3(512), DMA_LDS, s, *a);
+    } else if (elu) hipLaunchKernelGGL((gemm_split_kernel<128, true>), grid, dim3(256), 0, s, *a);
     else hipLaunchKernelGGL((gemm_split_kernel<128, false>), grid, dim3(256), 0, s, *a);
   } else {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 63) / 64, (unsigned)nb);
