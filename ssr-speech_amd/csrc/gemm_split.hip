@@ -216,13 +216,17 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const ssrhip_gemm_ar
 // 167 -> 196, the codec's strided views 99..137 -> 124..158.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-constexpr int DMA_PLANE = 128 * 64, DMA_LDS = 9 * DMA_PLANE;          // bytes: one bf16 plane of a 128 x 32 tile; A 3 planes + W 2 x 3 planes
+constexpr int DMA_PLANE = 128 * 64;                                   // bytes: one bf16 plane of a 128 x 32 tile
+constexpr int dma_lds(int bm) { return 3 * bm * 64 + 6 * DMA_PLANE; }  // A 3 planes of BM rows + W 2 stages x 3 planes
 
-template <bool ELU>
+// BM = 128: waves 2 x 4 of 64 x 32; BM = 64 (grids that 128-row tiles would not fill, half-empty tiles): waves 2 x 4 of 32 x 32. Same
+// arithmetic per output element in both (and in the 4-wave kernels above).
+template <int BM, bool ELU>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_split_dma_kernel(const ssrhip_gemm_args a0) {
+  constexpr int MT = BM / 64, LA = BM / 64, APL = BM * 64;           // accumulators per wave, A loader passes, bytes per A plane
   extern __shared__ __attribute__((aligned(1024))) char ldsb[];
-  char* const As = ldsb;                                             // [3][128][64 B]
-  char* const Wsb = ldsb + 3 * DMA_PLANE;                            // [2][3][128][64 B]
+  char* const As = ldsb;                                             // [3][BM][64 B]
+  char* const Wsb = ldsb + 3 * APL;                                  // [2][3][128][64 B]
   ssrhip_gemm_args a = a0;
   {   // batched problems: grid.z
     const size_t z = blockIdx.z;
@@ -234,29 +238,29 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = (wave >> 2) & 1, wn = wave & 3;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * 128;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
   const int lr = t >> 3, lc = (t & 7) * 4;                           // A loader: 8 threads per row (32 k), 64 rows per pass, 2 passes
   const int M = a.M, N = a.N, K = a.K;
   const short* Wp = reinterpret_cast<const short*>(a.W_split);
   const size_t plane = (size_t)N * K;
 
-  f32x16 acc[2];
+  f32x16 acc[MT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  float4 ra[2];
-  const int rows_a = min(128, M - m0), rows_w = min(128, N - n0);
+  float4 ra[LA];
+  const int rows_a = min(BM, M - m0), rows_w = min(128, N - n0);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A + (size_t)m0 * a.lda), 0,
                                                                         (int)(((size_t)(rows_a - 1) * a.lda + K) * 4), 0x00020000);
   __amdgpu_buffer_rsrc_t rsW[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q)
     rsW[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(Wp + (size_t)q * plane + (size_t)n0 * K), 0, (int)((size_t)rows_w * K * 2), 0x00020000);
-  unsigned offA[2];
+  unsigned offA[LA];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) offA[i] = (unsigned)(((size_t)(lr + 64 * i) * a.lda + lc) * 4);
+  for (int i = 0; i < LA; ++i) offA[i] = (unsigned)(((size_t)(lr + 64 * i) * a.lda + lc) * 4);
   constexpr unsigned OOB = 0x80000000u;                              // >= every descriptor's extent (checked by the host): reads as zero
   // W by DMA: wave w brings rows 16w .. 16w+15 of a plane with one instruction; lane l lands in slot l of the wave's KiB = (row 16w + l/4,
   // slot l%4), which has to hold chunk (l%4) ^ ((row >> 2) & 3)
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   auto gload_a = [&](int k0) {
     const bool kin = (k0 + lc) < K;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, kin ? offA[i] + (unsigned)k0 * 4 : OOB, 0, 0));
+    for (int i = 0; i < LA; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, kin ? offA[i] + (unsigned)k0 * 4 : OOB, 0, 0));
   };
   auto dma_w = [&](int k0, int stage) {
     const bool kin = (k0 + wchunk * 8) < K;                          // K % 8 == 0 (checked by the host)
@@ -277,13 +281,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   const int aswz = (((lc >> 3) ^ ((lr >> 2) & 3)) << 4) + ((lc >> 2) & 1) * 8;   // rows lr and lr + 64 share (row >> 2) & 3
   auto store_a = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < LA; ++i) {
       float4 v = ra[i];
       if (ELU) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
       bf16x4 p[3];
       split4(v, p);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(As + q * DMA_PLANE + (lr + 64 * i) * 64 + aswz) = p[q];
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(As + q * APL + (lr + 64 * i) * 64 + aswz) = p[q];
     }
   };
   const int fsw = (li >> 2) & 3;
@@ -293,17 +297,17 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
       const int coff = (((kk >> 3) + lh) ^ fsw) << 4;
-      bf16x8 fa[3][2], fb[3];
+      bf16x8 fa[3][MT], fb[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[q][i] = *reinterpret_cast<const bf16x8*>(As + q * DMA_PLANE + ((wm * 2 + i) * 32 + li) * 64 + coff);
+        for (int i = 0; i < MT; ++i) fa[q][i] = *reinterpret_cast<const bf16x8*>(As + q * APL + ((wm * MT + i) * 32 + li) * 64 + coff);
         fb[q] = *reinterpret_cast<const bf16x8*>(Wsb + (stage * 3 + q) * DMA_PLANE + (wn * 32 + li) * 64 + coff);
       }
 #pragma unroll
       for (int pq = 0; pq < 6; ++pq)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pq]][i], fb[PB[pq]], acc[i], 0, 0, 0);
+        for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pq]][i], fb[PB[pq]], acc[i], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -325,10 +329,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   if (n >= N) return;
   const float bias = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + (wm * 2 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m < M) {
         if (a.tm_c > 0) {
           const long u = ((long)m * N + n) / a.tm_c;
@@ -366,25 +370,32 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
   // 212 us at 32 clips)
   const int waste128 = (a->M + 127) / 128 * 128 - a->M, waste64 = (a->M + 63) / 64 * 64 - a->M;
   const bool half_empty = waste128 - waste64 >= 64 && 8 * (waste128 - waste64) >= a->M;
+  // the DMA kernels address a tile through 32-bit buffer offsets: 128 rows of A (and of a W plane) have to stay below 2 GiB
+  static const bool dma_off = getenv("SSRHIP_GEMM_SPLIT_DMA") && getenv("SSRHIP_GEMM_SPLIT_DMA")[0] == '0';   // A/B knob: the 4-wave kernels
+  const bool dma = !dma_off && ((size_t)127 * a->lda + a->K) * 4 < 0x7FFFFFF0ull && (size_t)128 * a->K * 2 < 0x7FFFFFF0ull;
+  if (dma) {
+    static const int attr = [] {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(128));
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(128));
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(64));
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(64));
+      return (int)e;
+    }();
+    SSR_REQUIRE(attr == 0, "ssrhip_gemm: cannot reserve %d bytes of LDS for the split kernel (hip error %d)", dma_lds(128), attr);
+  }
   if (tiles128 >= 384 && !half_empty) {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 127) / 128, (unsigned)nb);
-    // the DMA kernel addresses a tile through 32-bit buffer offsets: 128 rows of A (and of a W plane) have to stay below 2 GiB
-    static const bool dma_off = getenv("SSRHIP_GEMM_SPLIT_DMA") && getenv("SSRHIP_GEMM_SPLIT_DMA")[0] == '0';   // A/B knob: the 4-wave kernel
-    const bool dma = !dma_off && ((size_t)127 * a->lda + a->K) * 4 < 0x7FFFFFF0ull && (size_t)128 * a->K * 2 < 0x7FFFFFF0ull;
     if (dma) {
-      static const int attr = [] {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS);
-        return (int)e;
-      }();
-      SSR_REQUIRE(attr == 0, "ssrhip_gemm: cannot reserve %d bytes of LDS for the split kernel (hip error %d)", DMA_LDS, attr);
-      if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<true>), grid, dim3(512), DMA_LDS, s, *a);
-      else hipLaunchKernelGGL((gemm_split_dma_kernel<false>), grid, dim3(512), DMA_LDS, s, *a);
+      if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<128, true>), grid, dim3(512), dma_lds(128), s, *a);
+      else hipLaunchKernelGGL((gemm_split_dma_kernel<128, false>), grid, dim3(512), dma_lds(128), s, *a);
     } else if (elu) hipLaunchKernelGGL((gemm_split_kernel<128, true>), grid, dim3(256), 0, s, *a);
     else hipLaunchKernelGGL((gemm_split_kernel<128, false>), grid, dim3(256), 0, s, *a);
   } else {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 63) / 64, (unsigned)nb);
-    if (elu) hipLaunchKernelGGL((gemm_split_kernel<64, true>), grid, dim3(256), 0, s, *a);
+    if (dma) {
+      if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<64, true>), grid, dim3(512), dma_lds(64), s, *a);
+      else hipLaunchKernelGGL((gemm_split_dma_kernel<64, false>), grid, dim3(512), dma_lds(64), s, *a);
+    } else if (elu) hipLaunchKernelGGL((gemm_split_kernel<64, true>), grid, dim3(256), 0, s, *a);
     else hipLaunchKernelGGL((gemm_split_kernel<64, false>), grid, dim3(256), 0, s, *a);
   }
   SSR_LAUNCH_CHECK();

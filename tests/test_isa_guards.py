@@ -104,12 +104,12 @@ def test_split_gemm_kernels_use_the_bf16_matrix_core_and_do_not_spill(tmp_path_f
     # the 8-wave DMA kernel: four waves per SIMD need <= 128 VGPRs; W reaches LDS through buffer_load ... lds (three planes per tile, in the
     # prologue and in the loop), A through branch-free buffer loads (no exec-mask branch around a load anywhere in the k-loop)
     dma = {k: v for k, v in _kernel_meta(asm).items() if "gemm_split_dma_kernel" in k}
-    assert len(dma) == 2, sorted(dma)
+    assert len(dma) == 4, sorted(dma)                                # 128- / 64-row tiles x ELU on load or not
     for sym, (vgpr, scratch) in dma.items():
         assert vgpr <= 128 and scratch == 0, (sym, vgpr, scratch)
         body = _body(asm, sym)
         n_mfma = body.count("v_mfma_f32_32x32x16_bf16")
-        assert n_mfma >= 24 and n_mfma % 6 == 0, (sym, n_mfma)
+        assert n_mfma >= 12 and n_mfma % 6 == 0, (sym, n_mfma)           # 2 k-steps x 6 products x 1 or 2 accumulators
         n_dma = len([ln for ln in body.splitlines() if "buffer_load_dwordx4" in ln and ln.rstrip().endswith("lds")])
         assert n_dma >= 6, (sym, n_dma)
         assert "v_cvt_pk_bf16_f32" in body and "v_mfma_f32_32x32x2_f32" not in body and "s_setprio 1" in body, sym
