@@ -25,6 +25,20 @@ void ssrhip_set_error(const char* fmt, ...);
     }                                                                         \
   } while (0)
 
+// hipFuncSetAttribute (the dynamic-LDS limit of a kernel) is per DEVICE: one flag per device id, so that a process which drives several
+// GPUs raises the limit on each of them (a lost race sets the attribute twice, which is harmless)
+struct ssr_once_per_device {
+  unsigned long long mask[2] = {0ull, 0ull};
+  bool need() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return true;
+    d &= 127;
+    const bool n = !((mask[d >> 6] >> (d & 63)) & 1ull);
+    mask[d >> 6] |= 1ull << (d & 63);
+    return n;
+  }
+};
+
 #define SSR_LAUNCH_CHECK()                                                    \
   do {                                                                        \
     hipError_t _e = hipGetLastError();                                        \

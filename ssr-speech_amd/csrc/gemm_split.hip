@@ -374,14 +374,13 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
   static const bool dma_off = getenv("SSRHIP_GEMM_SPLIT_DMA") && getenv("SSRHIP_GEMM_SPLIT_DMA")[0] == '0';   // A/B knob: the 4-wave kernels
   const bool dma = !dma_off && ((size_t)127 * a->lda + a->K) * 4 < 0x7FFFFFF0ull && (size_t)128 * a->K * 2 < 0x7FFFFFF0ull;
   if (dma) {
-    static const int attr = [] {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(128));
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(128));
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(64));
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(64));
-      return (int)e;
-    }();
-    SSR_REQUIRE(attr == 0, "ssrhip_gemm: cannot reserve %d bytes of LDS for the split kernel (hip error %d)", dma_lds(128), attr);
+    static ssr_once_per_device once;
+    if (once.need()) {
+      SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(128)));
+      SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(128)));
+      SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(64)));
+      SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(64)));
+    }
   }
   if (tiles128 >= 384 && !half_empty) {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 127) / 128, (unsigned)nb);

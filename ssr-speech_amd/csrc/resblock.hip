@@ -466,11 +466,8 @@ template <int CC, int BM>
 int launch_resblock_chain(const ssrhip_resblock_args* a, hipStream_t s) {
   constexpr int HH = CC / 2;
   const size_t smem = ((size_t)BM * (HH + 4) + (size_t)BM * 20 + (size_t)CC * 20) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_chain_kernel<CC, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_set = true;
-  }
+  static ssr_once_per_device once;
+  if (once.need()) SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_chain_kernel<CC, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL((resblock_chain_kernel<CC, BM>), dim3((a->T + BM - 1) / BM, a->B), dim3(256), smem, s, *a);
   return 0;
 }
@@ -487,11 +484,8 @@ extern "C" int ssrhip_resblock(const ssrhip_resblock_args* a, ssrhip_stream_t st
     static const bool split_off = getenv("SSRHIP_GEMM_SPLIT") && getenv("SSRHIP_GEMM_SPLIT")[0] == '0';   // A/B knob: the fp32 FMA chain everywhere
     if (a->C == 128 && !split_off && !big) {
       constexpr int SPLIT_SMEM = 128 * 68 * 4 + 3 * 128 * 24 * 2 + 3 * 128 * 24 * 2;     // Hs + As planes + Ws planes = 71,680 B
-      static bool attr_set = false;
-      if (!attr_set) {
-        SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_chain_split_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_SMEM));
-        attr_set = true;
-      }
+      static ssr_once_per_device once;
+      if (once.need()) SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_chain_split_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_SMEM));
       hipLaunchKernelGGL((resblock_chain_split_kernel<128, 128>), dim3((a->T + 127) / 128, a->B), dim3(256), SPLIT_SMEM, s, *a);
       SSR_LAUNCH_CHECK();
       return 0;
