@@ -722,7 +722,8 @@ int main(int argc, char** argv) {
     ssrhip_gemm_args a; memset(&a, 0, sizeof(a));
     a.A = A; a.W = W; a.bias = bias; a.M = 4096; a.N = 4096; a.K = 4096; a.lda = 4096; a.ldc = 4096; a.C = C1;
     hipLaunchKernelGGL(split_weights_kernel, dim3(2048), dim3(256), 0, s, W, g_wp, (size_t)4096 * 4096);
-    for (int v = 0; v < 2; ++v) { g_db = v ? 0 : -1; for (int i = 0; i < 3; ++i) launch_split(&a, s); }
+    const bool dma = argc > 2 && !strcmp(argv[2], "dma");               // prof dma: the 8-wave DMA kernel instead of the double-buffered one
+    for (int v = 0; v < 2; ++v) { g_db = v ? (dma ? 9 : 0) : -1; g_mode = dma ? 1 : 0; for (int i = 0; i < 3; ++i) launch_split(&a, s); }
     CK(hipStreamSynchronize(s));
     return 0;
   }
