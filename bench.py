@@ -404,7 +404,8 @@ def codec256_leg(dev, world, rank, dist, all_ok=lambda ok: ok):
             "wmdecode_note": f"marks = second half ones; {m.lanes} batch lane(s); 14.5 / 21.69 GFLOP per audio-second without / with the detector (SURVEY 8d)",
             "peak_mem_gib_encode_decode": round(peak_plain / 2 ** 30, 1),
             "gemm": "large GEMMs (N > 64) on the bf16 matrix cores, fp32 operands split exactly into 3 bf16 pieces, 6 cross products, fp32 accumulation "
-                    "(csrc/gemm_split.hip: error vs fp64 <= the fp32 FMA chain's); SSRHIP_GEMM_SPLIT=0 = the chain",
+                    "(csrc/gemm_split.hip, gemm_split_dma_kernel: 8 waves per workgroup, W global -> LDS by DMA; error vs fp64 <= the fp32 FMA chain's); "
+                    "SSRHIP_GEMM_SPLIT=0 = the chain",
             "exact_fp32_chain": {"encode_ms": round(1000 * exact["enc"], 1), "decode_ms": round(1000 * exact["dec"], 1),
                                  "encode_tflops_per_gpu": round(GF * audio_s / exact["enc"] / 1e12 / world, 1),
                                  "decode_tflops_per_gpu": round(GF * audio_s / exact["dec"] / 1e12 / world, 1),
