@@ -1,0 +1,93 @@
+"""Host-side replay of `gemm_split_dma_kernel`'s addressing (csrc/gemm_split.hip): the kernel reads A and the three W planes through
+buffer descriptors whose extent ends with the tile's last valid row, and sends a lane out of range (offset 0x80000000) when its k is
+past K. No GPU: the same integer formulas in NumPy, checked for the properties the kernel relies on —
+
+  * a lane that should read element (m, k) reads exactly A[m * lda + k .. + 4) (or W[n * K + k .. + 8) of its plane), and that access lies
+    inside the descriptor;
+  * a lane whose k chunk starts at or past K is out of range; with lda >= K every row past M (past N for W) is out of range as well, i.e.
+    reads as zero (for overlapping views, lda < K, such rows may read a neighbour's data — their outputs are never stored);
+  * together the lanes of a workgroup cover the BM x 32 (128 x 32) tile exactly once;
+  * every in-range offset stays below the out-of-range marker when the launcher's 2 GiB guard holds.
+The GPU side of the same contract is `tests/test_gpu_kernels.py` (tails in M, N and K against fp64)."""
+import numpy as np
+import pytest
+
+OOB = 0x80000000
+
+
+def _a_lanes(BM, M, K, lda, m0, k0):
+    """(offset or OOB, row, k) of every A load of one k-tile: 512 threads, 8 per row (4 floats each), 64 rows per pass, BM / 64 passes."""
+    t = np.arange(512)
+    lr, lc = t >> 3, (t & 7) * 4
+    rows_a = min(BM, M - m0)
+    extent = ((rows_a - 1) * lda + K) * 4                                # num_records of the descriptor based at A + m0 * lda
+    out = []
+    for i in range(BM // 64):
+        kin = (k0 + lc) < K
+        off = np.where(kin, ((lr + 64 * i) * lda + lc) * 4 + k0 * 4, OOB)
+        out.append((off, lr + 64 * i, k0 + lc))
+    return out, extent, rows_a
+
+
+def _w_lanes(N, K, n0, k0):
+    """W by DMA: wave w, lane l -> row 16 w + l / 4, chunk (l & 3) ^ ((l >> 4) & 3) (8 bf16 = 16 bytes)."""
+    t = np.arange(512)
+    wave, lane = t >> 6, t & 63
+    wrow = 16 * wave + (lane >> 2)
+    wchunk = (lane & 3) ^ ((lane >> 4) & 3)
+    rows_w = min(128, N - n0)
+    extent = rows_w * K * 2
+    kin = (k0 + wchunk * 8) < K
+    off = np.where(kin, (wrow * K + wchunk * 8) * 2 + k0 * 2, OOB)
+    return off, wrow, k0 + wchunk * 8, extent, rows_w
+
+
+@pytest.mark.parametrize("BM", [128, 64])
+@pytest.mark.parametrize("M,N,K,lda", [(3000, 2056, 1000, 1000), (50000, 128, 264, 264), (300, 200, 64, 96), (1500, 512, 384, 128), (77, 1030, 8, 8)])
+def test_a_operand_addressing(BM, M, N, K, lda):
+    for m0 in {0, (M - 1) // BM * BM}:                                   # first and last row block
+        for k0 in {0, (K - 1) // 32 * 32}:                               # first and last k-tile
+            lanes, extent, rows_a = _a_lanes(BM, M, K, lda, m0, k0)
+            seen = set()
+            for off, row, k in lanes:
+                for o, r, kk in zip(off.tolist(), row.tolist(), k.tolist()):
+                    if kk >= K:
+                        assert o == OOB
+                        continue
+                    assert o < OOB
+                    if r < rows_a:                                       # a row of the problem: the right address, inside the extent
+                        assert o == (r * lda + kk) * 4 and o + 16 <= extent
+                        assert (r, kk) not in seen
+                        seen.add((r, kk))
+                    elif lda >= K:                                       # a row past M: reads as zero
+                        assert o >= extent
+            want = {(r, kk) for r in range(rows_a) for kk in range(k0, min(k0 + 32, K), 4)}
+            assert seen == want
+
+
+@pytest.mark.parametrize("N,K", [(2056, 1000), (128, 264), (200, 64), (1030, 8), (4096, 1024)])
+def test_w_planes_addressing(N, K):
+    for n0 in {0, (N - 1) // 128 * 128}:
+        for k0 in {0, (K - 1) // 32 * 32}:
+            off, row, k, extent, rows_w = _w_lanes(N, K, n0, k0)
+            seen = set()
+            for o, r, kk in zip(off.tolist(), row.tolist(), k.tolist()):
+                if kk >= K:
+                    assert o == OOB
+                elif r < rows_w:
+                    assert o == (r * K + kk) * 2 and o + 16 <= extent and (r, kk) not in seen
+                    seen.add((r, kk))
+                else:
+                    assert extent <= o < OOB                             # a row past N: the DMA writes zeros
+            assert seen == {(r, kk) for r in range(rows_w) for kk in range(k0, min(k0 + 32, K), 8)}
+
+
+def test_the_launchers_guard_keeps_every_offset_below_the_marker():
+    # ssrhip_gemm_split_launch takes the DMA kernels only if (127 * lda + K) * 4 and 128 * K * 2 stay below 0x7FFFFFF0
+    for lda, K in [(4_000_000, 4_000_000), (1_000_000, 3_000_000), (4096, 4096)]:
+        ok = (127 * lda + K) * 4 < 0x7FFFFFF0 and 128 * K * 2 < 0x7FFFFFF0
+        biggest_a = (127 * lda + (K - 4)) * 4 + 16                       # last row, last chunk, last byte + 1
+        biggest_w = (127 * K + (K - 8)) * 2 + 16
+        if ok:
+            assert biggest_a <= 0x7FFFFFF0 + 16 and biggest_a < OOB and biggest_w < OOB
+    assert not ((127 * 5_000_000 + 4096) * 4 < 0x7FFFFFF0)              # a row pitch that does not fit is refused (4-wave kernel instead)
