@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSRHIP_VERSION 100
+#define SSRHIP_VERSION 101
 #define SSRHIP_PAGE 128          /* KV-cache page = 128 positions */
 #define SSRHIP_MAX_CODEBOOKS 4
 #define SSRHIP_MAX_SILENCE 8
@@ -132,6 +132,20 @@ int ssrhip_attn_rows(const ssrhip_attn_args* a, float* out /* [R][n_head*head_di
  * of sequence a->row_seq[seq_start[s]] (row_seq == NULL: sequence s), so a SUBSET of an engine's rows can be prefilled. */
 int ssrhip_attn_prefill(const ssrhip_attn_args* a, const int32_t* seq_start, int32_t n_seq, int32_t max_len, float* out,
                         ssrhip_stream_t stream);
+/* ssrhip_attn_decode FOLLOWED BY ssrhip_gemv(PRO_ATTN_COMBINE, EPI_RESIDUAL) — attention (activation.py:634), out_proj (:637) and the
+ * residual add (transformer.py:328) of one decode layer — as ONE launch for <= 4 rows: every workgroup requests its slice of the
+ * out-projection weight first, the attention partials are computed by the first workgroups and handed to all of them INSIDE the launch
+ * (sharded arrival counters in `sync`, write-through stores, bounded spin), so the 17 MB weight stream and the K/V reads overlap instead
+ * of waiting for each other at a kernel boundary. Bit-identical to the two-call sequence. `a` / `g` are exactly the arguments of the two
+ * calls (g->x unused; g->part_o / part_ml / max_splits / row_len / kv must equal a's). `sync`: ssrhip_attn_outproj_sync_words() int32 of
+ * device memory, ZERO before the first launch that uses them: arrival counters and a pass counter, all back to zero when the launch ends
+ * (so consecutive launches on one stream share the block); the LAST word is set to 1 — and stays — if the bounded spin ever gave up
+ * (results then undefined).
+ * ssrhip_attn_outproj_supported() != 0 tells whether the shapes qualify (B in {1,2,4}, N == K == n_head * head_dim == 2048,
+ * head_dim in {64,128}, row-major operands, no row_seq); otherwise issue the two calls. */
+int ssrhip_attn_outproj_supported(const ssrhip_attn_args* a, const ssrhip_gemv_args* g);
+int ssrhip_attn_outproj_sync_words(void);
+int ssrhip_attn_outproj(const ssrhip_attn_args* a, const ssrhip_gemv_args* g, int32_t* sync, ssrhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Token embedding + sinusoidal position: replaces embed_y (models/ssr.py:191-198, :655-660, :757-761),
@@ -354,6 +368,8 @@ typedef struct ssrhip_lm_buffers {      /* caller-allocated device workspaces */
   ssrhip_kv kv;
   ssrhip_sampler_cfg* cfg; ssrhip_sampler_state* state;
   const float* noise; int32_t* generated; float* dbg_logits;
+  int32_t* sync;   /* optional (NULL = the two-launch path): ssrhip_attn_outproj_sync_words() int32, zero-initialised by the caller once —
+                      hand-off counters of the fused attention + out-projection launch, shared by all layers; last word != 0 = a spin gave up */
 } ssrhip_lm_buffers;
 
 typedef struct ssrhip_lm ssrhip_lm;     /* opaque host-side object (graph + launch descriptors) */
@@ -376,12 +392,12 @@ typedef struct ssrhip_prefill_args {
 int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ssrhip_stream_t stream);
 
 /* run `n_steps` eager decode steps with a hipEvent pair around EVERY kernel launch (bench.py roofline).
- * out_us[i] = average microseconds of launch slot i of a step, out_kind[i] = 0 gemv | 1 attention | 2 sampler;
+ * out_us[i] = average microseconds of launch slot i of a step, out_kind[i] = 0 gemv | 1 attention | 2 sampler | 3 fused attention + out-proj;
  * returns the number of slots (<= n_out) or a negative error. */
 int ssrhip_lm_time_steps(ssrhip_lm* lm, int32_t n_steps, ssrhip_stream_t stream, float* out_us, int32_t* out_kind, int32_t n_out);
 
 /* Launch duration of ONE kernel category inside a decode step, measured the way the product runs it: the launches of
- * `category` (0 gemv | 1 attention | 2 sampler) of one step are captured into a hipGraph (the others are left out), the
+ * `category` (0 gemv | 1 attention | 2 sampler | 3 fused attention + out-projection) of one step are captured into a hipGraph (the others are left out), the
  * graph is replayed `n_replays` times between one hipEvent pair on `stream`, and the elapsed time is divided by the number
  * of launches. No per-launch event overhead, so the figure agrees with rocprofv3's kernel durations (+ the ~0.1 us
  * in-graph gap). The decode state is NOT advanced and the hidden-state buffers are left with garbage: call

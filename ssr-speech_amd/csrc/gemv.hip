@@ -37,8 +37,11 @@ struct GemvK {
   int hd;         // head_dim (QKV epilogue / combine prologue)
   int seg_shift;  // segment kernel: log2(K / 1024)
   int rows_max;   // segment kernel: most rows a workgroup owns (sizes the LDS partials)
+  long long* prof;          // debug (ssrhip_debug_gemv_prof): 8 wall_clock64 stamps per workgroup, or NULL
+  int rows_per, rows_rem;   // segment / front kernels: N / groups_x and N % groups_x (workgroup b owns rows_per + (b < rows_rem) rows)
 };
 
+long long* g_gemv_prof = nullptr;   // debug: ssrhip_debug_gemv_prof
 constexpr int PRO_LN_REGS = 3;   // internal: LayerNorm with gamma/beta folded into W/bias, whole row per wave (no LDS)
 constexpr int MAXCH = 8;
 constexpr int MAX_IT = 8;   // max rows per wave-group when K is split (LDS partials)
@@ -470,16 +473,26 @@ constexpr int SEG = 1024;            // floats per unit
 constexpr int SEG_TH = 512, SEG_NW = 8;
 template <int B> struct SegCS { static constexpr int v = (B <= 2) ? 6 : 2; };   // pages prefetched by the combine prologue (register budget: 128)
 
-template <int B, int PRO>
+// TWO: every wave owns at most two units (rows_max * S <= 16: the out-projection at one workgroup per CU, head-MLP1): BOTH are requested at
+// kernel entry instead of the second one being re-requested in place after the first was used. For the out-projection the first use comes
+// only after the split-KV merge prologue (a dependent L2 round trip + exp + two barriers), so the in-place form started its second HBM
+// round trip ~2 us into the kernel (tools/fused_prof.py shows the same prologue inside the fused launch); with both in flight from the
+// start the whole 64 KB slice of the workgroup lands under the prologue. Same arithmetic per unit: bit-identical results.
+template <int B, int PRO, bool TWO>
 __global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#define GSTAMP(i) do { if (p.prof && threadIdx.x == 0) p.prof[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+  GSTAMP(0);
   constexpr int SEG_CS = SegCS<B>::v;
   const ssrhip_gemv_args& a = p.a;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int g = blockIdx.y, G = p.groups_x;
+  const int g = blockIdx.y;
   const int K = a.K, N = a.N, S = p.nslice;                        // S segments per row (power of two <= 8)
-  const int r0 = (int)(((long)N * blockIdx.x) / G), r1 = (int)(((long)N * (blockIdx.x + 1)) / G);
-  const int nrows = r1 - r0, nu = nrows * S;                       // host guarantees N >= G: nrows >= 1
+  // balanced contiguous split of the N rows over the grid, WITHOUT a division: floor(N * bid / G) is a 64-bit division, which gfx9 emulates
+  // with ~150 dependent scalar / vector instructions — twice, at the head of every wave, in front of the first weight request (seen in the
+  // ISA: 397 instructions before the first global_load; round 4). The host passes N / G and N % G instead.
+  const int r0 = (int)blockIdx.x * p.rows_per + min((int)blockIdx.x, p.rows_rem);
+  const int nrows = p.rows_per + ((int)blockIdx.x < p.rows_rem ? 1 : 0), nu = nrows * S;                       // host guarantees N >= G: nrows >= 1
   const int seg = wave & (S - 1), sh = p.seg_shift;                // sh = log2(S)
   float* part = smem;                                              // [rows_max][S][B]
   float* aux = smem + p.rows_max * S * B;                          // prologue scratch
@@ -515,12 +528,19 @@ __global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
   // ---- 2. the wave's first unit, unconditional (clamped to the workgroup's last unit). FOUR loads in flight per lane, 16 waves per
   // CU: 64 KB per CU cover the HBM latency-bandwidth product; `tools/overlap_bench orders`: 8 in flight cost +1.5 us per launch.
   float4 wa[4];
+  float4 wb[TWO ? 4 : 1];
   int ua = wave;
   {
     const int ca = min(ua, nu - 1) >> sh;                           // local row (the segment is the wave's own)
 #pragma unroll
     for (int i = 0; i < 4; ++i) wa[i] = ld_nt(Wg + (size_t)ca * K + i * 256);
+    if constexpr (TWO) {
+      const int cb = min(ua + SEG_NW, nu - 1) >> sh;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wb[i] = ld_nt(Wg + (size_t)cb * K + i * 256);
+    }
   }
+  GSTAMP(1);
   // ---- epilogue operands of the (row, b) this thread finalises
   RowEpi efin = {0.f, 0.f};
   const int bfin = t % B, rfin = min(t / B, nrows - 1), nfin = r0 + rfin;
@@ -623,6 +643,7 @@ __global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) xr[b][i] = *reinterpret_cast<const float4*>(xs + b * K + seg * SEG + (i * 64 + lane) * 4);
   }
+  GSTAMP(2);
   // ---- 4. stream the units: every 16-byte piece is re-requested for the next unit as soon as it has been used
   auto reduce_park = [&](float (&acc)[B][2], int u) {
     float mine = 0.f;
@@ -633,7 +654,20 @@ __global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
     }
     if (lane < B) part[u * B + lane] = mine;                       // u = local_row * S + seg
   };
-  if (ua < nu) {
+  if constexpr (TWO) {
+    auto unit = [&](const float4 (&w)[4], int u) {
+      float acc[B][2];
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[b][0] = acc[b][1] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[b][i & 1] = dot4(w[i], xr[b][i], acc[b][i & 1]);
+      reduce_park(acc, u);
+    };
+    if (ua < nu) unit(wa, ua);
+    if (ua + SEG_NW < nu) unit(reinterpret_cast<const float4 (&)[4]>(wb), ua + SEG_NW);
+  } else if (ua < nu) {
     while (ua + SEG_NW < nu) {                                      // not the wave's last unit: re-request in place, UNCONDITIONALLY
       const int un = ua + SEG_NW;                                   // (a conditional re-request makes hipcc drain the queue every unit)
       const float* wn = Wg + (size_t)(un >> sh) * K;
@@ -660,14 +694,21 @@ __global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
       for (int b = 0; b < B; ++b) acc[b][i & 1] = dot4(wa[i], xr[b][i], acc[b][i & 1]);
     reduce_park(acc, ua);
   }
+  GSTAMP(3);
   __syncthreads();
+  GSTAMP(4);
   if (t < nrows * B) {
     float v = 0.f;
     for (int s2 = 0; s2 < S; ++s2) v += part[(rfin * S + s2) * B + bfin];
     finalize(p, g, nfin, bfin, v, efin, kvb);
   }
+  GSTAMP(5);
+#undef GSTAMP
 }
 
+// Round 4 measured the opposite organisation too — ALL of a wave's units requested at kernel entry, one 8-wave workgroup per CU (256 VGPRs):
+// bit-identical results, 12.4 us per launch in the step against 10.5 here (profiles/r04_microbench/decode_ab.log; the lab form of the same
+// idea is tools/gemv_floor_lab.hip mode 4: 10.0 us against 9.2-9.5 for 1-4 units in flight). Removed again.
 int g_seg_mode = -1;   // SSRHIP_GEMV_SEG: 1 (default) = take the segment kernel where its conditions hold, 0 = never
 
 // true if the segment kernel was launched
@@ -694,6 +735,9 @@ bool try_seg(const ssrhip_gemv_args* a, int num_cu, hipStream_t s) {
   p.nch = 4;
   p.seg_shift = (S == 1) ? 0 : (S == 2) ? 1 : (S == 4) ? 2 : 3;
   p.rows_max = rows_max;
+  p.rows_per = a->N / G;
+  p.rows_rem = a->N % G;
+  p.prof = g_gemv_prof;
   p.groups_x = G;
   p.hd = (a->kv.head_dim > 0) ? a->kv.head_dim : 1;
   size_t smem = (size_t)rows_max * S * B * sizeof(float);
@@ -701,10 +745,22 @@ bool try_seg(const ssrhip_gemv_args* a, int num_cu, hipStream_t s) {
   if (a->pro == SSRHIP_PRO_ATTN_COMBINE) smem += ((size_t)B * a->K + (size_t)B * H * a->max_splits) * sizeof(float);
   smem = (smem + 15) / 16 * 16;
   dim3 grid(G, a->groups);
+  static int two_mode = -1;                                         // SSRHIP_GEMV_SEG_TWO=0: A/B knob (the in-place form for every shape)
+  if (two_mode < 0) { const char* e = getenv("SSRHIP_GEMV_SEG_TWO"); two_mode = (e && e[0] == '0') ? 0 : 1; }
+  const bool two = two_mode && rows_max * S <= 2 * SEG_NW && rows_max * S > SEG_NW;   // more than one and at most two units per wave
   switch (a->pro) {
-    case SSRHIP_PRO_LAYERNORM: hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_LAYERNORM>), grid, dim3(SEG_TH), smem, s, p); break;
-    case SSRHIP_PRO_ATTN_COMBINE: hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_ATTN_COMBINE>), grid, dim3(SEG_TH), smem, s, p); break;
-    default: hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_NONE>), grid, dim3(SEG_TH), smem, s, p); break;
+    case SSRHIP_PRO_LAYERNORM:
+      if (two) hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_LAYERNORM, true>), grid, dim3(SEG_TH), smem, s, p);
+      else hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_LAYERNORM, false>), grid, dim3(SEG_TH), smem, s, p);
+      break;
+    case SSRHIP_PRO_ATTN_COMBINE:
+      if (two) hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_ATTN_COMBINE, true>), grid, dim3(SEG_TH), smem, s, p);
+      else hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_ATTN_COMBINE, false>), grid, dim3(SEG_TH), smem, s, p);
+      break;
+    default:
+      if (two) hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_NONE, true>), grid, dim3(SEG_TH), smem, s, p);
+      else hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_NONE, false>), grid, dim3(SEG_TH), smem, s, p);
+      break;
   }
   return true;
 }
@@ -716,6 +772,9 @@ int g_blocks_per_cu = 3;   // A/B in the real (dependent-launch) decode step: 1 
 }  // namespace
 
 int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s);   // gemv_mfma.hip: 5..16 rows on the matrix core
+
+// debug hook (not part of the ABI; tools/gemv_prof.py): per-workgroup time stamps of every later gemv_seg_kernel launch
+extern "C" void ssrhip_debug_gemv_prof(void* dev_ptr) { g_gemv_prof = (long long*)dev_ptr; }
 
 extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->W && a->y, "ssrhip_gemv: null argument");
@@ -760,6 +819,8 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   p.a = *a;
   p.seg_shift = 0;
   p.rows_max = 0;
+  p.rows_per = p.rows_rem = 0;
+  p.prof = nullptr;
   p.nslice = a->K <= 2048 ? 1 : (a->K <= 4096 ? 2 : 4);
   p.slice_len = ((a->K + p.nslice - 1) / p.nslice + 3) / 4 * 4;
   p.nch = (p.slice_len + 255) / 256;
