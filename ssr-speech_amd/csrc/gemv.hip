@@ -478,8 +478,9 @@ template <int B> struct SegCS { static constexpr int v = (B <= 2) ? 6 : 2; };   
 // only after the split-KV merge prologue (a dependent L2 round trip + exp + two barriers), so the in-place form started its second HBM
 // round trip ~2 us into the kernel (tools/fused_prof.py shows the same prologue inside the fused launch); with both in flight from the
 // start the whole 64 KB slice of the workgroup lands under the prologue. Same arithmetic per unit: bit-identical results.
+// (the merge-prologue variant with two units at entry runs at ONE workgroup per CU — try_seg — so it may take up to 256 VGPRs: at 128 it spilled)
 template <int B, int PRO, bool TWO>
-__global__ __launch_bounds__(SEG_TH, 4) void gemv_seg_kernel(const GemvK p) {
+__global__ __launch_bounds__(SEG_TH, (TWO && PRO == SSRHIP_PRO_ATTN_COMBINE) ? 2 : 4) void gemv_seg_kernel(const GemvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #define GSTAMP(i) do { if (p.prof && threadIdx.x == 0) p.prof[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
   GSTAMP(0);
@@ -747,19 +748,20 @@ bool try_seg(const ssrhip_gemv_args* a, int num_cu, hipStream_t s) {
   dim3 grid(G, a->groups);
   static int two_mode = -1;                                         // SSRHIP_GEMV_SEG_TWO=0: A/B knob (the in-place form for every shape)
   if (two_mode < 0) { const char* e = getenv("SSRHIP_GEMV_SEG_TWO"); two_mode = (e && e[0] == '0') ? 0 : 1; }
-  const bool two = two_mode && rows_max * S <= 2 * SEG_NW && rows_max * S > SEG_NW;   // more than one and at most two units per wave
+  const bool two = B <= 2 && two_mode && rows_max * S <= 2 * SEG_NW && rows_max * S > SEG_NW &&   // more than one and at most two units per wave; 4 rows: no registers left
+                   (a->pro != SSRHIP_PRO_ATTN_COMBINE || G <= num_cu);                // (its merge variant is built for one workgroup per CU)
   switch (a->pro) {
     case SSRHIP_PRO_LAYERNORM:
-      if (two) hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_LAYERNORM, true>), grid, dim3(SEG_TH), smem, s, p);
-      else hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_LAYERNORM, false>), grid, dim3(SEG_TH), smem, s, p);
+      if constexpr (B <= 2) { if (two) { hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_LAYERNORM, true>), grid, dim3(SEG_TH), smem, s, p); break; } }
+      hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_LAYERNORM, false>), grid, dim3(SEG_TH), smem, s, p);
       break;
     case SSRHIP_PRO_ATTN_COMBINE:
-      if (two) hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_ATTN_COMBINE, true>), grid, dim3(SEG_TH), smem, s, p);
-      else hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_ATTN_COMBINE, false>), grid, dim3(SEG_TH), smem, s, p);
+      if constexpr (B <= 2) { if (two) { hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_ATTN_COMBINE, true>), grid, dim3(SEG_TH), smem, s, p); break; } }
+      hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_ATTN_COMBINE, false>), grid, dim3(SEG_TH), smem, s, p);
       break;
     default:
-      if (two) hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_NONE, true>), grid, dim3(SEG_TH), smem, s, p);
-      else hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_NONE, false>), grid, dim3(SEG_TH), smem, s, p);
+      if constexpr (B <= 2) { if (two) { hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_NONE, true>), grid, dim3(SEG_TH), smem, s, p); break; } }
+      hipLaunchKernelGGL((gemv_seg_kernel<B, SSRHIP_PRO_NONE, false>), grid, dim3(SEG_TH), smem, s, p);
       break;
   }
   return true;

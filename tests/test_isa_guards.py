@@ -52,14 +52,15 @@ def gemv_asm(tmp_path_factory):
 
 def test_segment_kernel_fits_128_vgprs_without_scratch(gemv_asm):
     meta = {k: v for k, v in _kernel_meta(gemv_asm).items() if "gemv_seg_kernel" in k}
-    assert len(meta) == 9, sorted(meta)                              # B in {1,2,4} x prologue in {none, LayerNorm, split-KV merge}
+    assert len(meta) == 15, sorted(meta)                             # B in {1,2,4} x prologue in {none, LayerNorm, split-KV merge}, + two units at entry for B <= 2
     for sym, (vgpr, scratch) in meta.items():
-        assert vgpr <= 128, (sym, vgpr)
+        one_per_cu = "Li2ELb1E" in sym                                # split-KV merge + two units at entry: launched at one workgroup per CU
+        assert vgpr <= (256 if one_per_cu else 128), (sym, vgpr)
         assert scratch == 0, (sym, scratch)
 
 
 def test_segment_kernel_loop_rerequests_in_place(gemv_asm):
-    for sym in (s for s in _kernel_meta(gemv_asm) if "gemv_seg_kernel" in s and "ILi2E" in s):
+    for sym in (s for s in _kernel_meta(gemv_asm) if "gemv_seg_kernel" in s and "ILi2E" in s and "Lb0E" in s):   # the in-place variants (TWO = false)
         body = _body(gemv_asm, sym)
         loops = [m.start() for m in re.finditer(r"=>This Inner Loop Header", body)]
         assert loops, sym
@@ -120,3 +121,31 @@ def test_split_gemm_kernels_use_the_bf16_matrix_core_and_do_not_spill(tmp_path_f
         assert vgpr <= 256 and scratch == 0, (sym, vgpr, scratch)
         body = _body(rb, sym)
         assert body.count("v_mfma_f32_32x32x16_bf16") >= 36 and "v_mfma_f32_32x32x2_f32" not in body, sym
+
+
+def test_segment_kernel_prologue_has_no_integer_division(gemv_asm):
+    """Round 4: the row partition floor(N * blockIdx / G) was a 64-bit division — ~330 emulation instructions at the head of every wave,
+    in front of the first weight request. The host passes N / G and N % G now; the first non-temporal load must come early."""
+    for sym in (s for s in _kernel_meta(gemv_asm) if "gemv_seg_kernel" in s and "ILi2E" in s and "Li2ELb" not in s):   # no-prologue and LayerNorm variants
+        lines = [l for l in _body(gemv_asm, sym).split("\n") if l.strip() and not l.strip().startswith(";") and not l.strip().endswith(":")]
+        first = next(i for i, l in enumerate(lines) if "global_load_dwordx4" in l and " nt" in l)
+        assert first < 120, (sym, first)
+        assert not any("v_rcp_iflag_f32" in l for l in lines[:first]), sym          # the signature of an emulated integer division
+
+
+def test_fused_attention_outproj_keeps_its_contract_in_the_isa(tmp_path_factory):
+    """csrc/attn_fused.hip: no scratch, <= 256 VGPRs (one 8-wave workgroup per CU), write-through (sc1) partial stores, an explicit
+    vmcnt(0) drain in front of the arrival atomic, and NO cache invalidate on the default path that is not behind the A/B flag branch."""
+    asm = _asm(tmp_path_factory, "attn_fused")
+    meta = {k: v for k, v in _kernel_meta(asm).items() if "attn_outproj_kernel" in k}
+    assert len(meta) == 6, sorted(meta)
+    for sym, (vgpr, scratch) in meta.items():
+        assert vgpr <= 256 and scratch == 0, (sym, vgpr, scratch)
+        body = _body(asm, sym)
+        assert re.search(r"global_store_dword [^\n]* sc1", body), sym
+        st = [m.end() for m in re.finditer(r"global_store_dword [^\n]* sc1", body)]
+        for k, pos in enumerate(st):                                  # every run of partial stores is drained before the next arrival atomic
+            if k + 1 < len(st) and st[k + 1] - pos < 400:
+                continue
+            i = body.index("global_atomic_add", pos)
+            assert "s_waitcnt vmcnt(0)" in body[pos:i], sym
