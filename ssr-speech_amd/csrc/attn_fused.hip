@@ -41,7 +41,7 @@ struct FusedK {
 
 constexpr int FSEG = 1024;       // floats per (row, segment) unit
 constexpr int F_TH = 512, F_NW = 8;
-constexpr int F_CS = 6;          // pages whose partial outputs are requested together (as gemv_seg_kernel's SegCS<2>)
+template <int B> struct FusedCS { static constexpr int v = (B <= 2) ? 6 : 2; };   // pages whose partial outputs are requested together (= gemv_seg_kernel's SegCS)
 constexpr int SPIN_LIMIT = 1 << 22;
 // Arrival counters: NREP replicas, one per 256-byte block of `sync` (different memory channels). Every arriving item adds 1 to ALL of
 // them (one 16-lane atomic instruction, no return); a waiting workgroup polls ONLY replica blockIdx % NREP. With a single counter line
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(F_TH, 2) void attn_outproj_kernel(const FusedK p) {
   constexpr int KPI = 64 / LPK;       // key rows per wave-instruction
   constexpr int NI = 32 / KPI;        // load instructions for a wave's 32 keys
   constexpr int S = 2, SH = 1;        // K == 2048: two segments per row
+  constexpr int F_CS = FusedCS<B>::v;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const ssrhip_attn_args& a = p.at;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
