@@ -63,7 +63,7 @@ __global__ __launch_bounds__(F_TH, 2) void attn_outproj_kernel(const FusedK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const ssrhip_attn_args& a = p.at;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int H = a.kv.n_head, K = p.K, N = p.N, G = gridDim.x, MS = a.max_splits;
+  const int H = a.kv.n_head, K = p.K, G = gridDim.x, MS = a.max_splits;
   const int r0 = (int)blockIdx.x * p.rows_per + min((int)blockIdx.x, p.rows_rem);     // no division in the prologue (see gemv.hip)
   const int nrows = p.rows_per + ((int)blockIdx.x < p.rows_rem ? 1 : 0), nu = nrows * S;
   const int rows_max = p.rows_per + (p.rows_rem ? 1 : 0);
@@ -269,7 +269,9 @@ __global__ __launch_bounds__(F_TH, 2) void attn_outproj_kernel(const FusedK p) {
       for (int s2 = 0; s2 < F_CS; ++s2) co[b][s2] = ld4(po + (size_t)min(s2, MS - 1) * HD);
     }
     if (t < B * H) {
-      const int n = ns[t / H];
+      int n = ns[0];                                            // ns[t / H] as a select chain: a dynamically indexed array lives in scratch
+#pragma unroll
+      for (int b = 1; b < B; ++b) n = (t / H == b) ? ns[b] : n;
       float M = -INFINITY;
 #pragma unroll
       for (int i = 0; i < F_CS; ++i)
