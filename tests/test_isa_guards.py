@@ -97,8 +97,8 @@ def test_split_gemm_kernels_use_the_bf16_matrix_core_and_do_not_spill(tmp_path_f
     meta = {k: v for k, v in _kernel_meta(asm).items() if "gemm_split_kernel" in k}
     assert len(meta) == 4, sorted(meta)                              # 128- / 64-row tiles x ELU on load or not
     for sym, (vgpr, scratch) in meta.items():
-        # (the 4-row, head_dim-128 variant keeps one 32-byte stack object — the per-row length arrays — and spills nothing)
-        assert vgpr <= 256 and scratch <= (32 if "ILi4ELi128E" in sym else 0), (sym, vgpr, scratch)
+        # (the 4-row variants keep one 32-byte stack object — the per-row length arrays — and spill nothing)
+        assert vgpr <= 256 and scratch <= (32 if "ILi4E" in sym else 0), (sym, vgpr, scratch)
         body = _body(asm, sym)
         n_mfma = body.count("v_mfma_f32_32x32x16_bf16")
         assert n_mfma >= 24 and n_mfma % 6 == 0, (sym, n_mfma)
@@ -141,8 +141,8 @@ def test_fused_attention_outproj_keeps_its_contract_in_the_isa(tmp_path_factory)
     meta = {k: v for k, v in _kernel_meta(asm).items() if "attn_outproj_kernel" in k}
     assert len(meta) == 6, sorted(meta)
     for sym, (vgpr, scratch) in meta.items():
-        # (the 4-row, head_dim-128 variant keeps one 32-byte stack object — the per-row length arrays — and spills nothing)
-        assert vgpr <= 256 and scratch <= (32 if "ILi4ELi128E" in sym else 0), (sym, vgpr, scratch)
+        # (the 4-row variants keep one 32-byte stack object — the per-row length arrays — and spill nothing)
+        assert vgpr <= 256 and scratch <= (32 if "ILi4E" in sym else 0), (sym, vgpr, scratch)
         body = _body(asm, sym)
         assert re.search(r"global_store_dword [^\n]* sc1", body), sym
         pos = re.search(r"global_store_dword [^\n]* sc1", body).end()  # the first item's partial stores ...
