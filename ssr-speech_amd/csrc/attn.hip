@@ -25,7 +25,7 @@ namespace {
 #endif
 __device__ __forceinline__ float4 ld_kv(const float* p) { return SSR_ATTN_NT ? ld_nt(p) : ld4(p); }
 
-template <int HD>
+template <int HD, bool SEQ>      // SEQ: rows carry an explicit sequence id (a.row_seq != NULL: the per-row prefill path); the decode step has none
 __global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args a) {
   constexpr int LPK = HD / 4;         // lanes per key row
   constexpr int KPI = 64 / LPK;       // key rows per wave-instruction
@@ -37,11 +37,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args
   const int c4 = (lane % LPK) * 4;    // this lane's 4 columns
   const int H = a.kv.n_head;
   // the row's length, its page id and q are requested TOGETHER, before the early exit (split < max_pages: the table entry exists and
-  // holds a valid page — the engine's spare page — also beyond the row's length): one scalar-memory round trip instead of two in a row
-  const int seq = a.row_seq ? a.row_seq[r] : r;
-  const int len = a.row_len[r];
-  const int page = a.kv.table[(size_t)seq * a.kv.max_pages + split];
+  // holds a valid page — the engine's spare page — also beyond the row's length): one scalar-memory round trip instead of two in a row.
+  // Round 4: the ISA showed FOUR serial scalar round trips in front of the first K/V request (kernel arguments fetched piecemeal, then
+  // row_seq, then the table entry): the arguments are pinned into ONE batch, and the decode step's common case (row_seq == NULL) reads
+  // table[r][split] without waiting for anything but the arguments. Constant address space: scalar loads (row_len / table / row_seq do
+  // not change during the launch).
+  typedef const int32_t __attribute__((address_space(4))) cint;
+  cint* c_len = (cint*)(uintptr_t)a.row_len;
+  cint* c_tab = (cint*)(uintptr_t)a.kv.table;
+  cint* c_seq = (cint*)(uintptr_t)a.row_seq;
+  asm volatile("; kernel arguments in one batch" :: "s"(a.q), "s"(a.kv.pool), "s"(a.kv.max_pages), "s"(a.kv.n_layer), "s"(a.layer), "s"(a.scale),
+               "s"(a.part_o), "s"(a.part_ml), "s"(a.max_splits), "s"(a.q_stride), "s"(H), "s"(c_len), "s"(c_tab), "s"(c_seq));
+  const int len = c_len[r];
+  const int page = SEQ ? c_tab[(size_t)c_seq[r] * a.kv.max_pages + split]      // rows mapped to another sequence: one more round trip
+                       : c_tab[(size_t)r * a.kv.max_pages + split];            // the row's own sequence (decode step): together with its length
   const float4 q = ld4(a.q + (size_t)r * (a.q_stride ? a.q_stride : H * HD) + h * HD + c4);
+  asm volatile("; row length and page id arrive together" :: "s"(len), "s"(page));
   const int base = split * SSRHIP_PAGE;
   if (base >= len) return;            // uniform per block
   const float* kp = a.kv.pool + ((((size_t)page * a.kv.n_layer + a.layer) * 2 + 0) * H + h) * SSRHIP_PAGE * HD;
@@ -493,8 +504,13 @@ extern "C" int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t str
     const int n = min(a->R - r0, (int)MAX_GRID_ROWS);
     const ssrhip_attn_args s = a->R <= MAX_GRID_ROWS ? *a : row_slice(*a, r0, n);
     dim3 grid(s.max_splits, s.kv.n_head, n);
-    if (s.kv.head_dim == 128) hipLaunchKernelGGL(attn_decode_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, s);
-    else hipLaunchKernelGGL(attn_decode_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, s);
+    if (s.kv.head_dim == 128) {
+      if (s.row_seq) hipLaunchKernelGGL((attn_decode_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, s);
+      else hipLaunchKernelGGL((attn_decode_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, s);
+    } else {
+      if (s.row_seq) hipLaunchKernelGGL((attn_decode_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, s);
+      else hipLaunchKernelGGL((attn_decode_kernel<64, false>), grid, dim3(256), 0, (hipStream_t)stream, s);
+    }
     SSR_LAUNCH_CHECK();
   }
   return 0;

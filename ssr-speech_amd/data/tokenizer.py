@@ -5,7 +5,6 @@ any callable `tokenizer([text]) -> [[phonemes]]` can be passed instead).
 """
 from __future__ import annotations
 
-import re
 import struct
 from typing import Any, List, Optional, Sequence, Tuple
 
@@ -204,36 +203,61 @@ def tokenize_audio(tokenizer: AudioTokenizer, audio_path: str, offset=-1, num_fr
     return encoded_frames, scale, emb
 
 
+def split_phonemized(phonemized: str, word_sep: str = "_", phone_sep: str = "|") -> List[str]:
+    """One phonemized utterance -> the symbol list the LM's phoneme table is indexed by (what the reference's tokenizer returns,
+    data/tokenizer.py:59-77): inside every word a maximal run of letters / digits / modifier letters is ONE symbol (a phone such as
+    `iː`), every other non-blank character a symbol of its own (punctuation), phone separators vanish, and the word separator itself
+    stands between two words as a symbol. A character scanner instead of a regular expression: no dependency on `re`'s Unicode tables
+    beyond `str.isalnum`, and usable (and tested, tests/test_host_surface.py) without espeak installed."""
+    symbols: List[str] = []
+    words = phonemized.split(word_sep)
+    for wi, word in enumerate(words):
+        run = ""
+        for ch in word:
+            if ch.isalnum() or ch == "_":                 # part of a phone
+                run += ch
+                continue
+            if run:
+                symbols.append(run)
+                run = ""
+            if not ch.isspace() and ch != phone_sep:      # a punctuation mark (the phone separator only delimits)
+                symbols.append(ch)
+        if run:
+            symbols.append(run)
+        if wi + 1 < len(words):
+            symbols.append(word_sep)
+    kept = sum(len(sym) for sym in symbols)
+    if kept != len(phonemized) - phonemized.count(phone_sep) - sum(ch.isspace() for ch in phonemized):
+        raise ValueError(f"phonemizer output does not round-trip: {phonemized!r}")
+    return symbols
+
+
 class TextTokenizer:
-    """Phonemize Text (data/tokenizer.py:31-80): thin wrapper over `phonemizer`'s espeak backend, which must be installed
-    (it is an external binary stack; not part of this package's scope)."""
+    """Text -> phoneme symbols through the external `phonemizer` / espeak-ng stack (reference data/tokenizer.py:31-80). Only the
+    backend call needs that stack; the symbol splitting is `split_phonemized` above. The CLI's `--phoneme_ids` bypasses this class."""
+
+    WORD_SEP, SYLLABLE_SEP, PHONE_SEP = "_", "-", "|"
 
     def __init__(self, language="en-us", backend="espeak", separator=None, preserve_punctuation=True, punctuation_marks=None,
                  with_stress=False, tie=False, language_switch="keep-flags", words_mismatch="ignore") -> None:
         try:
             from phonemizer.backend import EspeakBackend
-            from phonemizer.separator import Separator
             from phonemizer.punctuation import Punctuation
+            from phonemizer.separator import Separator
         except ImportError as e:
-            raise RuntimeError("TextTokenizer needs the `phonemizer` package and espeak-ng (reference data/tokenizer.py:8-10)") from e
-        self.separator = separator or Separator(word="_", syllable="-", phone="|")
-        self.backend = EspeakBackend(language, punctuation_marks=punctuation_marks or Punctuation.default_marks(),
-                                     preserve_punctuation=preserve_punctuation, with_stress=with_stress, tie=tie,
-                                     language_switch=language_switch, words_mismatch=words_mismatch)
-
-    def to_list(self, phonemized: str) -> List[str]:
-        fields = []
-        for word in phonemized.split(self.separator.word):
-            pp = re.findall(r"\w+|[^\w\s]", word, re.UNICODE)             # phones and punctuation marks (tokenizer.py:66)
-            fields.extend([p for p in pp if p != self.separator.phone] + [self.separator.word])
-        assert len("".join(fields[:-1])) == len(phonemized) - phonemized.count(self.separator.phone)
-        return fields[:-1]
+            raise RuntimeError("TextTokenizer needs the `phonemizer` package and espeak-ng (reference data/tokenizer.py:8-10); "
+                               "pass phoneme ids directly (--phoneme_ids) on a box without them") from e
+        if backend != "espeak":
+            raise ValueError("only the espeak backend is wired up (as in the reference)")
+        self.separator = separator if separator is not None else Separator(word=self.WORD_SEP, syllable=self.SYLLABLE_SEP, phone=self.PHONE_SEP)
+        marks = Punctuation.default_marks() if punctuation_marks is None else punctuation_marks
+        self.backend = EspeakBackend(language, punctuation_marks=marks, preserve_punctuation=preserve_punctuation, with_stress=with_stress,
+                                     tie=tie, language_switch=language_switch, words_mismatch=words_mismatch)
 
     def __call__(self, text, strip=True) -> List[List[str]]:
-        if isinstance(text, str):
-            text = [text]
-        phonemized = self.backend.phonemize(text, separator=self.separator, strip=strip, njobs=1)
-        return [self.to_list(p) for p in phonemized]
+        batch = [text] if isinstance(text, str) else list(text)
+        lines = self.backend.phonemize(batch, separator=self.separator, strip=strip, njobs=1)
+        return [split_phonemized(line, self.separator.word, self.separator.phone) for line in lines]
 
 
 def tokenize_text(tokenizer, text: str) -> List[str]:

@@ -90,3 +90,28 @@ def test_encode_driver_flags_and_txt_format(golden_dir, tmp_path):
     TK.write_wav(str(tmp_path / "c.wav"), torch.zeros(1, 1234), 16000)
     clip, dur = ENC.load_clip(str(tmp_path / "c.wav"), 16000)
     assert clip.shape == (1234,) and dur == 1234 / 16000 and round(dur * 50) == 4
+
+
+def test_split_phonemized_follows_the_reference_symbol_rule():
+    """The phonemizer's output line -> LM symbols (reference data/tokenizer.py:59-77 states the rule as the regular expression
+    `\\w+|[^\\w\\s]` per word, phone separators dropped, the word separator kept as a symbol). Needs no espeak: the scanner is plain Python."""
+    import random
+    import re
+    from ssr_speech_amd.data.tokenizer import split_phonemized
+
+    def rule(line, w="_", p="|"):
+        out = []
+        for word in line.split(w):
+            out += [tok for tok in re.findall(r"\w+|[^\w\s]", word, re.UNICODE) if tok != p] + [w]
+        return out[:-1]
+
+    line = "ɐ m|iː|n? ɹ|ɪ|z|ɜː|v; h|ɪ|z._ð|ə_k|w|ɪ|k,_b|ɹ|aʊ|n"
+    assert split_phonemized(line) == ['ɐ', 'm', 'iː', 'n', '?', 'ɹ', 'ɪ', 'z', 'ɜː', 'v', ';', 'h', 'ɪ', 'z', '.', '_', 'ð', 'ə', '_',
+                                      'k', 'w', 'ɪ', 'k', ',', '_', 'b', 'ɹ', 'aʊ', 'n']
+    assert split_phonemized("") == [] and split_phonemized("_") == ["_"] and split_phonemized("a|b") == ["a", "b"]
+    rng = random.Random(4)
+    alphabet = "abɐiːɪɜʊŋθðˈˌ|_ ,.;?!-'1"
+    for _ in range(3000):
+        line = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 24)))
+        assert split_phonemized(line) == rule(line), line
+    assert split_phonemized("a-b|c", word_sep="-", phone_sep="|") == ["a", "-", "b", "c"]
