@@ -229,26 +229,27 @@ def dp64_leg(model, args_lm, dev, world, rank, dist):
         utts.append({"x": torch.randint(0, 100, (1, 67), generator=gx), "y": torch.randint(0, 2048, (1, 150, 4), generator=gy),
                      "mask_interval": torch.LongTensor([[[150, 150]]])})
     kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, cfg_coef=1.5, cfg_stride=5, aug_text=True)
-    lo, hi = dp.shard_range(64, world, rank)
-    if hi > lo:        # untimed: the codec's kernels and allocator blocks for this shard's decode shape (the LM engine warmed up in the rtf leg / first pass)
-        tok.decode_batch([torch.zeros(1, 4, 520, dtype=torch.long, device=dev)] * (hi - lo))
+    n_mine = len(dp.balanced_shards([dp.utterance_cost(67, 150)] * 64, world)[rank])
+    if n_mine:         # untimed: the codec's kernels and allocator blocks for this shard's decode shape (the LM engine warmed up in the rtf leg / first pass)
+        tok.decode_batch([torch.zeros(1, 4, 520, dtype=torch.long, device=dev)] * n_mine)
     stats = {}
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    waves, (lo, hi), toks = dp.synthesize(model, tok, utts, seed=0, tts=True, stats=stats, device=dev, **kw)
+    waves, mine, toks = dp.synthesize(model, tok, utts, seed=0, tts=True, stats=stats, device=dev, **kw)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t1 = time.perf_counter()
     wall = t1 - t0
     if dist is not None:
-        tt = torch.tensor([wall, stats["decode_s"], stats["codec_s"]], device=dev, dtype=torch.float64)
+        tt = torch.tensor([wall, stats["decode_s"], stats["codec_s"], -stats["decode_s"]], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, dec, cod = float(tt[0]), float(tt[1]), float(tt[2])
+        wall, dec, cod, dec_min = float(tt[0]), float(tt[1]), float(tt[2]), -float(tt[3])
     else:
         dec, cod = stats["decode_s"], stats["codec_s"]
+        dec_min = dec
     n_new = sum(int(t.shape[1]) - 150 for t in toks)
     crc = 0
     for t in toks:
@@ -256,9 +257,9 @@ def dp64_leg(model, args_lm, dev, world, rank, dist):
     # waveforms stay on the rank that rendered them; their CRCs are combined in utterance order on rank 0 (a few bytes per utterance)
     wcrc = torch.zeros(64, dtype=torch.int64, device=dev)
     wlen = torch.zeros(64, dtype=torch.int64, device=dev)
-    for j, w in enumerate(waves):
-        wcrc[lo + j] = zlib.crc32(w.detach().cpu().numpy().astype("<f4").tobytes())
-        wlen[lo + j] = w.shape[-1]
+    for gi, w in zip(mine, waves):
+        wcrc[gi] = zlib.crc32(w.detach().cpu().numpy().astype("<f4").tobytes())
+        wlen[gi] = w.shape[-1]
     if dist is not None:
         dist.all_reduce(wcrc, op=dist.ReduceOp.SUM)
         dist.all_reduce(wlen, op=dist.ReduceOp.SUM)
@@ -267,7 +268,7 @@ def dp64_leg(model, args_lm, dev, world, rank, dist):
     return {"workload": "64 utterances, L=67, 150-frame prompts, greedy + CFG (stride 5), <= 8 utterances x 2 rows per engine pass; "
                         "tokens all-gathered, then every rank renders its own shard's waveforms (ragged wmencodec decode, prompt cut off)",
             "n_gpus": world, "utterances_per_gpu": (64 + world - 1) // world, "new_frames_total": n_new,
-            "wall_ms_with_codec": round(1000 * wall, 1), "decode_ms_max_rank": round(1000 * dec, 1), "allgather_ms": round(1000 * stats["allgather_s"], 3),
+            "wall_ms_with_codec": round(1000 * wall, 1), "decode_ms_max_rank": round(1000 * dec, 1), "decode_ms_min_rank": round(1000 * dec_min, 1), "allgather_ms": round(1000 * stats["allgather_s"], 3),
             "codec_ms_max_rank": round(1000 * cod, 1), "generated_audio_s": round(gen_s, 2), "rtf": round(wall / max(gen_s, 1e-9), 5),
             "codec_tokens_per_s_per_gpu": round(4 * n_new / dec / world, 1), "codec_tokens_per_s_total": round(4 * n_new / wall, 1),
             "tokens_crc32": f"{crc:08x}", "wav_crc32": f"{wav_crc:08x}",

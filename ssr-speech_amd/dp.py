@@ -18,6 +18,41 @@ def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
+def utterance_cost(text_len: int, prompt_frames: int, n_codebooks: int = 4) -> float:
+    """What an utterance is expected to cost its rank, in decode steps: the reference stops a span once the audio position passes
+    10 x the text length (models/ssr.py:739), so `10 L - T0` bounds — and for long texts tracks — the number of generated frames;
+    the prefill of its L + T0 positions is worth about one step per 32 positions (13 ms for ~500 positions x 2 rows against 0.83 ms
+    per step)."""
+    steps = max(10 * int(text_len) + 2 - int(prompt_frames), 1) + n_codebooks + 1
+    return float(steps) + (int(text_len) + int(prompt_frames)) / 32.0
+
+
+def balanced_shards(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Utterance -> rank by cost instead of by position ("length-sorted round-robin to balance steps"): longest processing
+    time first — utterances in order of decreasing cost, each to the rank with the smallest load so far (ties: fewer utterances, then
+    the lower rank). A rank runs its utterances through 8 slots with refill, so its time is ~ max(sum / 8, longest): both terms are
+    what LPT evens out. Pure function of (costs, world): every rank computes the same plan without communicating. Returns owners[r] =
+    the GLOBAL indices of rank r's utterances, ascending (utterance i keeps seed + i and its place in every result list)."""
+    owners: List[List[int]] = [[] for _ in range(world)]
+    load = [0.0] * world
+    for i in sorted(range(len(costs)), key=lambda j: (-float(costs[j]), j)):
+        r = min(range(world), key=lambda q: (load[q], len(owners[q]), q))
+        owners[r].append(i)
+        load[r] += float(costs[i])
+    return [sorted(o) for o in owners]
+
+
+def contiguous_shards(n_items: int, world: int) -> List[List[int]]:
+    return [list(range(*shard_range(n_items, world, r))) for r in range(world)]
+
+
+def plan_stats(costs: Sequence[float], owners: Sequence[Sequence[int]], slots: int = 8) -> dict:
+    """max / mean of the ranks' estimated times under a plan (a rank's time ~ max(sum of its costs / slots, its longest utterance))."""
+    t = [max(sum(costs[i] for i in o) / slots, max((costs[i] for i in o), default=0.0)) for o in owners]
+    mean = sum(t) / max(len(t), 1)
+    return {"rank_time": t, "max_over_mean": (max(t) / mean) if mean > 0 else 1.0}
+
+
 def utterance_seed(seed: int, global_index: int) -> int:
     """Per-utterance RNG seed: independent of the world size (same convention as `inference_v2.py:332`, seed+num)."""
     return int(seed) + int(global_index)
@@ -34,8 +69,9 @@ def _collective_device(hint=None) -> torch.device:
     return torch.device(hint) if hint is not None else torch.device("cpu")
 
 
-def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token: int, device=None, force_collective: bool = False) -> List[torch.Tensor]:
-    """local[i]: int tensor [K, T_i] of this rank's utterances (rank-contiguous shard of `n_total`).
+def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token: int, device=None, force_collective: bool = False,
+                  owners: Sequence[Sequence[int]] = None) -> List[torch.Tensor]:
+    """local[i]: int tensor [K, T_i] of this rank's utterances, in the order of owners[rank] (default: the rank-contiguous shard of `n_total`).
     Returns the list of all `n_total` token tensors on every rank. One all_gather of lengths (n ints per
     rank) and one all_gather of a padded [n_max, K, T_max] int32 block (a few KB..100 KB per rank). A world of one returns the
     local list without a collective unless `force_collective` (tests: a 1-rank nccl group then issues the very RCCL calls an
@@ -48,7 +84,11 @@ def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token
     world, rank = dist.get_world_size(), dist.get_rank()
     if device is None:
         device = _collective_device(local[0].device if len(local) else None)
-    n_max = (n_total + world - 1) // world
+    if owners is None:
+        owners = contiguous_shards(n_total, world)
+    assert len(owners) == world and sorted(i for o in owners for i in o) == list(range(n_total)), "owners must partition the utterances"
+    assert len(local) == len(owners[rank]), (len(local), len(owners[rank]))
+    n_max = max(max(len(o) for o in owners), 1)
     lens = torch.zeros(n_max, dtype=torch.int32, device=device)
     for i, t in enumerate(local):
         lens[i] = t.shape[1]
@@ -61,33 +101,44 @@ def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token
     out = torch.empty((world,) + tuple(block.shape), dtype=torch.int32, device=device)
     dist.all_gather_into_tensor(out.view(-1), block.view(-1))
     all_lens = all_lens.view(world, n_max)
-    res = []
+    res: List[torch.Tensor] = [None] * n_total
     for r in range(world):
-        s, e = shard_range(n_total, world, r)
-        for i in range(e - s):
-            res.append(out[r, i, :, : int(all_lens[r, i])].to(torch.int64).clone())
-    assert len(res) == n_total
+        for i, gi in enumerate(owners[r]):
+            res[gi] = out[r, i, :, : int(all_lens[r, i])].to(torch.int64).clone()
     return res
 
 
 def generate(model, utterances: Sequence[dict], seed: int = 0, pad_token: int = None, device=None, stats: dict = None,
-             force_collective: bool = False, **decode_kw):
+             force_collective: bool = False, costs: Sequence[float] = None, balance: bool = True, **decode_kw):
     """BASELINE config 4 in one call: shard `utterances` (dicts {x, y, mask_interval}, see `SSR_Speech.inference_batch`)
     over the ranks of the default process group, decode this rank's shard in lock-step (up to 8 utterances x CFG rows per
-    engine pass), and all-gather the generated codec tokens so that every rank holds all of them before codec decode.
-    Utterance i uses the RNG stream `seed + i` whatever the world size. Returns (tokens, local) where tokens[i] is the int64
-    [K, T_i'] result of utterance i (all utterances, every rank) and local = (lo, hi, the 4-tuples of this rank's shard)."""
+    engine pass, rows refilled as utterances finish), and all-gather the generated codec tokens so that every rank holds all of
+    them before codec decode. Utterance i uses the RNG stream `seed + i` whatever the world size and whichever rank runs it.
+
+    The shard of a rank is chosen by COST (`balanced_shards` over `utterance_cost(L_i, T0_i)`; `costs` overrides the estimate —
+    then only this rank's own utterances need their `y`, the others may be None; `balance=False`: contiguous blocks by position).
+    Returns (tokens, local): tokens[i] = the int64 [K, T_i'] result of utterance i (all utterances, on every rank);
+    local = (indices, outs): the ascending global indices of this rank's shard and their 4-tuples."""
     import torch.distributed as dist
     in_group = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size() if in_group else 1
     rank = dist.get_rank() if world > 1 else 0
     collective = world > 1 or (force_collective and in_group)
-    lo, hi = shard_range(len(utterances), world, rank)
+    n_total = len(utterances)
+    if not balance or world == 1:
+        owners = contiguous_shards(n_total, world)
+    else:
+        if costs is None:
+            K = int(model.args.n_codebooks)
+            costs = [utterance_cost(u["x"].shape[-1], u["y"].shape[1], K) for u in utterances]
+        assert len(costs) == n_total
+        owners = balanced_shards(costs, world)
+    mine = owners[rank]
     import time
     t0 = time.perf_counter()
     failure = None
     try:
-        outs = model.inference_batch(list(utterances[lo:hi]), seed=seed, first_index=lo, **decode_kw) if hi > lo else []
+        outs = model.inference_batch([utterances[i] for i in mine], seed=seed, indices=mine, **decode_kw) if mine else []
     except Exception as e:              # noqa: BLE001 — re-raised below, on EVERY rank
         failure, outs = e, []
     if stats is not None:           # wall time of this rank's lock-step decode (inference_batch ends on a device->host read)
@@ -107,10 +158,11 @@ def generate(model, utterances: Sequence[dict], seed: int = 0, pad_token: int = 
     if device is None:
         device = _collective_device(getattr(model, "device", None))
     t1 = time.perf_counter()
-    everyone = gather_tokens(toks, len(utterances), K, pad_token, device=device, force_collective=force_collective)
+    everyone = gather_tokens(toks, n_total, K, pad_token, device=device, force_collective=force_collective, owners=owners)
     if stats is not None:
         stats["allgather_s"] = time.perf_counter() - t1
-    return everyone, (lo, hi, outs)
+        stats["shard"] = list(mine)
+    return everyone, (list(mine), outs)
 
 
 def synthesize(model, audio_tokenizer, utterances: Sequence[dict], seed: int = 0, use_watermark: bool = False, tts: bool = True,
@@ -126,27 +178,28 @@ def synthesize(model, audio_tokenizer, utterances: Sequence[dict], seed: int = 0
     utterances[i]: {x, y, mask_interval} as for `generate`, plus `wav` ([1, n] original 16 kHz audio, or a path) when
     `use_watermark` (the watermark decoder's skip input, inference_scale.py:67-78).
     Replaces the reference's per-sample loop inference_v2.py:331-358 + inference_scale.py:63-86.
-    Returns (waves, (lo, hi), tokens): waves[j] = waveform [1, 1, n] of utterance lo + j; tokens = all utterances' codes."""
+    Returns (waves, indices, tokens): waves[j] = waveform [1, 1, n] of utterance indices[j] (this rank's shard, ascending global
+    indices — cost-balanced, see `generate`); tokens = all utterances' codes."""
     import time
     from .inference_scale import render_many
-    tokens, (lo, hi, outs) = generate(model, utterances, seed=seed, stats=stats, force_collective=force_collective, **decode_kw)
+    tokens, (mine, outs) = generate(model, utterances, seed=seed, stats=stats, force_collective=force_collective, **decode_kw)
     t0 = time.perf_counter()
     dev = getattr(model, "device", None)
     # the gathered tokens are the codec's input (what any rank could decode); marks / kept intervals are this rank's own
-    results = [(tokens[lo + j].unsqueeze(0).to(dev if dev is not None else tokens[lo + j].device), o[1], o[2], o[3]) for j, o in enumerate(outs)]
+    results = [(tokens[gi].unsqueeze(0).to(dev if dev is not None else tokens[gi].device), o[1], o[2], o[3]) for gi, o in zip(mine, outs)]
     waves = []
     if results:
-        audio = [u.get("wav") for u in utterances[lo:hi]] if use_watermark else None
+        audio = [utterances[gi].get("wav") for gi in mine] if use_watermark else None
         waves = render_many(audio_tokenizer, results, None, audio, bool(use_watermark), bool(tts))
     if output_dir is not None and waves:
         import os
         from .data.tokenizer import write_wav
         os.makedirs(output_dir, exist_ok=True)
-        for j, w in enumerate(waves):
-            name = names[lo + j] if names is not None else f"utt{lo + j:05d}"
+        for gi, w in zip(mine, waves):
+            name = names[gi] if names is not None else f"utt{gi:05d}"
             write_wav(os.path.join(output_dir, f"{name}.wav"), w[0].cpu(), sample_rate)
     if stats is not None:
         if waves and waves[0].is_cuda:
             torch.cuda.synchronize(waves[0].device)
         stats["codec_s"] = time.perf_counter() - t0
-    return waves, (lo, hi), tokens
+    return waves, list(mine), tokens

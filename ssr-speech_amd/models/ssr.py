@@ -12,7 +12,7 @@ import copy
 import logging
 import time
 from argparse import Namespace
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -255,14 +255,16 @@ class SSR_Speech(nn.Module):
     @torch.no_grad()
     def inference_batch(self, utterances, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0, stop_repetition: int = -1,
                         silence_tokens=(1388, 1898, 131), cfg_coef: float = 1.5, cfg_stride: int = 1, aug_text: bool = False,
-                        seed: int = 0, first_index: int = 0, group: Optional[int] = None, use_graph: bool = True, refill: bool = True):
+                        seed: int = 0, first_index: int = 0, group: Optional[int] = None, use_graph: bool = True, refill: bool = True,
+                        indices: Optional[Sequence[int]] = None):
         """Several independent utterances decoded in lock-step so that one pass over the weights serves all of them
         (the reference is strictly batch-1: `assert y.shape[0] == 1`, ssr.py:559, and loops `--sample_batch_size`
         sequentially, inference_v2.py:331-333).
 
         utterances: list of dicts {x: LongTensor[1,L], y: LongTensor[1,T,K], mask_interval: LongTensor[1,M,2]}.
         Parity contract: result i == `inference()` of utterance i alone after `torch.manual_seed(seed + first_index + i)`
-        (per-utterance RNG streams, independent of grouping and of the DP world size).
+        (per-utterance RNG streams, independent of grouping and of the DP world size); `indices[i]` replaces `first_index + i`
+        when the list is a cost-balanced (non-contiguous) shard of a larger job (`dp.generate`).
         `refill=False` (A/B knob, bench): fixed groups of `group` utterances, each decoded until its longest member ends (round 2).
         Returns a list of the same 4-tuples `inference` returns."""
         K = self.args.n_codebooks
@@ -278,7 +280,7 @@ class SSR_Speech(nn.Module):
         jobs, metas, page_need = [], [], []
         cap_max, seq_max = 1, 1
         for j, u in enumerate(utterances):
-            gi = first_index + j
+            gi = int(indices[j]) if indices is not None else first_index + j
             rng = torch.Generator().manual_seed(seed + gi)      # same stream as `torch.manual_seed(seed + gi)` + a batch-1 run
             x_np = u["x"].detach().cpu().numpy().astype(np.int64)
             L = x_np.shape[1]
