@@ -348,6 +348,10 @@ typedef struct ssrhip_lm_weights {      /* device pointers; per-layer arrays hav
    * Used by the decode steps of engines with more than 4 rows; the prefill GEMMs and the <= 4-row GEMV read the [N][K] copies. */
   const float* const* in_proj_wt; const float* const* out_proj_wt; const float* const* ffn1_wt; const float* const* ffn2_wt;
   const float* head1_wt; const float* head2_wt;
+  /* optional (all four or none; NULL = the fp32 FMA chain): the four matrices of every layer as three bf16 planes each (ssrhip_split_weights)
+   * for the PREFILL GEMMs (ssrhip_lm_prefill: tgt_len = prompt length): fp32 operands split exactly, six cross products on the bf16 matrix
+   * cores (ssrhip_gemm_args.W_split: error against fp64 no larger than the chain's, not bit-identical to it). The decode step never reads them. */
+  const uint16_t* const* in_proj_ws; const uint16_t* const* out_proj_ws; const uint16_t* const* ffn1_ws; const uint16_t* const* ffn2_ws;
 } ssrhip_lm_weights;
 
 typedef struct ssrhip_lm_dims {

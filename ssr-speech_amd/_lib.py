@@ -121,7 +121,8 @@ class LMWeights(C.Structure):
                 ("lnf_w", C.c_void_p), ("lnf_b", C.c_void_p),
                 ("head1_w", C.c_void_p), ("head1_b", C.c_void_p), ("head2_w", C.c_void_p), ("head2_b", C.c_void_p),
                 ("in_proj_wt", _PP), ("out_proj_wt", _PP), ("ffn1_wt", _PP), ("ffn2_wt", _PP),
-                ("head1_wt", C.c_void_p), ("head2_wt", C.c_void_p)]
+                ("head1_wt", C.c_void_p), ("head2_wt", C.c_void_p),
+                ("in_proj_ws", _PP), ("out_proj_ws", _PP), ("ffn1_ws", _PP), ("ffn2_ws", _PP)]
 
 
 class LMDims(C.Structure):

@@ -50,6 +50,8 @@ struct ssrhip_lm {
   ssrhip_lm_weights w;
   ssrhip_lm_buffers b;
   std::vector<const float*> ptrs[16];
+  std::vector<const uint16_t*> sptrs[4];
+  bool prefill_split = false;   // bf16 planes present and SSRHIP_PREFILL_SPLIT != 0
   hipStream_t cap_stream = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -255,6 +257,19 @@ extern "C" int ssrhip_lm_create(const ssrhip_lm_dims* d, const ssrhip_lm_weights
     }
   }
   if (!has_wt) lm->w.head1_wt = lm->w.head2_wt = nullptr;
+  // optional bf16 planes for the prefill GEMMs (all four or none)
+  const uint16_t* const** sp[4] = {&lm->w.in_proj_ws, &lm->w.out_proj_ws, &lm->w.ffn1_ws, &lm->w.ffn2_ws};
+  const bool has_ws = lm->w.in_proj_ws && lm->w.out_proj_ws && lm->w.ffn1_ws && lm->w.ffn2_ws;
+  for (int f = 0; f < 4; ++f) {
+    if (has_ws) {
+      const uint16_t* const* src = *sp[f];
+      lm->sptrs[f].assign(src, src + d->n_layer);
+      *sp[f] = lm->sptrs[f].data();
+    } else {
+      *sp[f] = nullptr;
+    }
+  }
+  { const char* e = getenv("SSRHIP_PREFILL_SPLIT"); lm->prefill_split = has_ws && !(e && e[0] == '0'); }
   *out = lm;
   return 0;
 }
@@ -369,6 +384,7 @@ extern "C" int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ss
     memset(&g, 0, sizeof(g));
     g.A = p->xn; g.W = w.in_proj_w[l]; g.bias = w.in_proj_b[l]; g.C = p->qkv;
     g.M = R; g.N = 3 * D; g.K = D; g.lda = D; g.ldc = 3 * D;
+    if (lm->prefill_split) g.W_split = w.in_proj_ws[l];
     if (int rc = ssrhip_gemm(&g, s)) return rc;
     if (int rc = ssrhip_kv_scatter(p->qkv, &lm->b.kv, l, p->row_seq, p->row_pos, R, s)) return rc;
 
@@ -389,16 +405,19 @@ extern "C" int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ss
     memset(&g, 0, sizeof(g));
     g.A = p->o; g.W = w.out_proj_w[l]; g.bias = w.out_proj_b[l]; g.C = p->x;
     g.M = R; g.N = D; g.K = D; g.lda = D; g.ldc = D; g.residual = 1;
+    if (lm->prefill_split) g.W_split = w.out_proj_ws[l];
     if (int rc = ssrhip_gemm(&g, s)) return rc;
 
     if (int rc = ssrhip_layernorm(p->x, w.ln2_w[l], w.ln2_b[l], 1e-5f, p->xn, R, D, s)) return rc;
     memset(&g, 0, sizeof(g));
     g.A = p->xn; g.W = w.ffn1_w[l]; g.bias = w.ffn1_b[l]; g.C = p->h;
     g.M = R; g.N = d.d_ffn; g.K = D; g.lda = D; g.ldc = d.d_ffn; g.act = SSRHIP_ACT_RELU;
+    if (lm->prefill_split) g.W_split = w.ffn1_ws[l];
     if (int rc = ssrhip_gemm(&g, s)) return rc;
     memset(&g, 0, sizeof(g));
     g.A = p->h; g.W = w.ffn2_w[l]; g.bias = w.ffn2_b[l]; g.C = p->x;
     g.M = R; g.N = D; g.K = d.d_ffn; g.lda = d.d_ffn; g.ldc = D; g.residual = 1;
+    if (lm->prefill_split) g.W_split = w.ffn2_ws[l];
     if (int rc = ssrhip_gemm(&g, s)) return rc;
   }
   // x of the first decode step: the rows' pending input tokens (the span-0 mask token, ssr.py:655-662)

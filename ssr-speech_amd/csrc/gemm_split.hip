@@ -317,7 +317,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   for (int k0 = 0; k0 < K; k0 += BK) {
     __syncthreads();                                                 // the previous tile is consumed (the A stage, W stage ^ 1)
     store_a();
-    __syncthreads();                                                 // A(k0) stored, W(k0) landed (the compiler waits for the DMA here)
+    // W(k0) was written into LDS by OTHER waves' DMA: every wave drains its own DMA before the barrier publishes the tile. hipcc happens to
+    // place a vmcnt(0) at the loop head today (it merges the prologue's issue order with its conservative LDS-DMA alias rule); a compiler that
+    // tracks the DMA more precisely could legally move that wait behind the barrier — stale W rows, no error. Explicit, and
+    // guarded in tests/test_isa_guards.py. Free: the wait is already there.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                 // A(k0) stored, W(k0) landed
     gload_a(k0 + BK);                                                // past K: zeros, never used
     dma_w(k0 + BK, stage ^ 1);
     __builtin_amdgcn_sched_barrier(0);                               // keep the loads HERE
@@ -353,8 +358,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 }  // namespace
 
 // true when the split kernel applies to this call (decided by ssrhip_gemm). It depends on the matrix (N, K) and on what the caller
-// supplied — never on M or the batch: an item's result must not change with the batch it is computed in (codec batch lanes,
-// decode_ragged == batch-1 decode).
+// supplied — not on M or the batch as long as they fit the launch grid (M <= 65535 x 64 rows = 4.19 M rows per item, batch <= 65535:
+// 87 s of 48 kHz audio per item at the codec's finest layer; beyond that the call takes the fp32 chain, which is NOT bit-identical):
+// an item's result must not change with the batch it is computed in (codec batch lanes, decode_ragged == batch-1 decode).
+// gfx950 only, like the whole library (the Makefile's ARCH): the DMA kernels use `buffer_load ... lds` with 16-byte pieces and 73,728 B
+// of LDS per workgroup at two workgroups per CU; ssrhip_gemm_split_launch raises the dynamic-LDS limit per device and returns an error
+// (never a silent fallback) when the runtime refuses it.
 bool ssrhip_gemm_split_eligible(const ssrhip_gemm_args* a) {
   if (!a->W_split || a->N <= 64 || a->K % 8 != 0 || a->lda % 4 != 0) return false;
   static const int off = getenv("SSRHIP_GEMM_SPLIT") && getenv("SSRHIP_GEMM_SPLIT")[0] == '0';   // A/B knob: always the exact fp32 chain

@@ -125,6 +125,23 @@ class LMWeightsArena:
         self.generation += 1
         return True
 
+    def ensure_split_planes(self) -> bool:
+        """The four matrices of every layer as three bf16 planes each ([3][N][K], `ssrhip_split_weights`) for the PREFILL GEMMs: fp32
+        operands split exactly, six cross products on the bf16 matrix cores (csrc/gemm_split.hip; +6 bytes per weight = +4.8 GB at 830M,
+        built once on first use). `SSRHIP_PREFILL_SPLIT=0` keeps the prefill on the fp32 FMA chain. Returns True when created now."""
+        if getattr(self, "_ws_ready", False) or os.environ.get("SSRHIP_PREFILL_SPLIT", "1") in ("0",):
+            return False
+        lib = _lib.lib()
+        for lay in self.layers:
+            for name in ("in_proj", "out_proj", "ffn1", "ffn2"):
+                Wm = lay[name + "_w"]
+                planes = torch.empty(3 * Wm.numel(), dtype=torch.int16, device=Wm.device)
+                _lib.check(lib.ssrhip_split_weights(Wm.data_ptr(), planes.data_ptr(), Wm.numel(), _lib.stream_ptr()), "ssrhip_split_weights")
+                lay[name + "_ws"] = planes
+        self._ws_ready = True
+        self.generation += 1
+        return True
+
     def ensure_positions(self, n: int) -> bool:
         """Grow the sinusoidal table so that positions [0, n) exist, like `SinePositionalEmbedding.extend_pe` does on demand
         (models/modules/embedding.py:66-92: no length limit in the reference). Returns True when the table was rebuilt
@@ -140,7 +157,7 @@ class LMWeightsArena:
         """Algorithmic weight bytes one decode step must stream."""
         n = 0
         for lay in self.layers:
-            n += sum(t.numel() for k, t in lay.items() if not k.endswith("_wt"))     # incl. the (now constant) LayerNorm vectors, as SURVEY §8d counts them
+            n += sum(t.numel() for k, t in lay.items() if not k.endswith("_wt") and not k.endswith("_ws"))     # incl. the (now constant) LayerNorm vectors, as SURVEY §8d counts them
         n += self.lnf_w.numel() + self.lnf_b.numel()
         n += self.head1_w.numel() + self.head1_b.numel() + self.head2_w.numel() + self.head2_b.numel()
         n += (self.K + 1) * self.D  # K embedding rows + one pe row
@@ -165,6 +182,11 @@ class LMWeightsArena:
                 self._arrays[name] = arr
                 setattr(w, name, C.cast(arr, C.POINTER(C.c_void_p)))
             w.head1_wt, w.head2_wt = self.head1_wt.data_ptr(), self.head2_wt.data_ptr()
+        if getattr(self, "_ws_ready", False):
+            for name in ("in_proj_ws", "out_proj_ws", "ffn1_ws", "ffn2_ws"):
+                arr = (C.c_void_p * self.L)(*[lay[name].data_ptr() for lay in self.layers])
+                self._arrays[name] = arr
+                setattr(w, name, C.cast(arr, C.POINTER(C.c_void_p)))
         return w
 
     def dims(self):
@@ -309,6 +331,7 @@ class DecodeEngine:
         arena.ensure_positions(self.max_seq)      # every text / audio position of a row is < its sequence capacity
         if self.B > 4:
             arena.ensure_streaming_copies()       # the matrix-core GEMV streams W in its own order
+        arena.ensure_split_planes()               # the prefill GEMMs run on the bf16 matrix cores with exactly split operands
         self.max_steps = max_steps
         D, H, L, K = arena.D, arena.H, arena.L, arena.K
         self.hd = D // H
@@ -750,9 +773,15 @@ class DecodeEngine:
             freed = []
             for u in live:
                 st, j = states[u], slot_job[u]
-                over = local[u] >= min(int(jobs[j]["cap"]), self.max_steps)
+                cap_j = min(int(jobs[j]["cap"]), self.max_steps)
+                over = local[u] >= cap_j
                 if st.done or over:
                     n = int(st.n_steps)
+                    if st.done and n > cap_j:
+                        # the flags are polled every `chunk` steps: an utterance may finish up to chunk - 1 steps past ITS OWN cap before the
+                        # poll sees it. The fixed-group path bounded every member by the group's cap; here the bound is per utterance, and a
+                        # result longer than its cap is the same failure as not finishing (the caller raises on done != 1).
+                        st.done = 2
                     gen = self.generated[u, :n].cpu().numpy().astype(np.int64)
                     snap = _lib.SamplerState.from_buffer_copy(bytes(st))
                     results[j] = (snap, gen)

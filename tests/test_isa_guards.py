@@ -148,3 +148,20 @@ def test_fused_attention_outproj_keeps_its_contract_in_the_isa(tmp_path_factory)
         pos = re.search(r"global_store_dword [^\n]* sc1", body).end()  # the first item's partial stores ...
         i = body.index("global_atomic_add", pos)                        # ... are drained before its arrival atomic
         assert "s_waitcnt vmcnt(0)" in body[pos:i], sym
+
+
+def test_split_gemm_drains_its_dma_before_the_tile_barrier(tmp_path_factory):
+    """gemm_split_dma_kernel: W tiles arrive in LDS by DMA issued by OTHER waves; the k-loop must wait for its own DMA (vmcnt(0)) before the
+    barrier that publishes the tile (until round 4 only the compiler's conservative wait placement guaranteed it)."""
+    asm = _asm(tmp_path_factory, "gemm_split")
+    syms = [k for k in _kernel_meta(asm) if "gemm_split_dma_kernel" in k]
+    assert len(syms) == 4, syms
+    for sym in syms:
+        body = _body(asm, sym)
+        lo = body.index("=>This Inner Loop Header")
+        loop = body[lo:]
+        first_mfma = loop.index("v_mfma_f32_32x32x16")
+        head = loop[:first_mfma]                                   # loop head .. first MFMA: store_a, the drain, the second barrier, the next loads
+        bars = [m.start() for m in re.finditer(r"s_barrier", head)]
+        assert len(bars) >= 2, sym
+        assert "s_waitcnt vmcnt(0)" in head[bars[0]:bars[1]], sym
