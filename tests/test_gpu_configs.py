@@ -181,6 +181,40 @@ def test_config5_codec_256_clips_of_30s_on_one_gpu():
         np.testing.assert_allclose(dec[b:b + 1].cpu().numpy(), o_dec.numpy(), rtol=0, atol=2e-4)
 
 
+def test_config5_wmdecode_256_clips_of_30s_checked_where_it_is_timed():
+    """`bench.py` times `wmdecode` at 256 x 30 s in 4 batch lanes (marks = second half ones), but the largest comparison
+    with the oracle was 20 clips x ~12 frames. Here the SAME call (the `--use_watermark` product path, wmencodec.py:358-375 /
+    seanet.py:555-600: skip encoder with four taps, three stacked LSTMs over 1,500 steps, label-conditioned projections, detector):
+    shapes and finiteness for all 256 clips, and three clips — the first of lane 0, one in the middle lane, the last of the last lane —
+    wav and detector output against oracle/codec.py within 2e-4."""
+    from ssr_speech_amd.codec.wmencodec import WMEncodecModel
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    cfg = W.codec_config_full()
+    sd = W.codec_state_dict(cfg, seed=0)
+    m = WMEncodecModel(cfg, sd, "cuda")
+    m.lanes = 4
+    B, n = 256, 480000
+    T = n // cfg.hop
+    g = torch.Generator().manual_seed(5)
+    wav = torch.randn(B, 1, n, generator=g) * 0.1
+    codes = torch.randint(0, cfg.bins, (B, cfg.n_q, T), generator=g)
+    marks = torch.zeros(B, T, dtype=torch.long)
+    marks[:, T // 2:] = 1
+    marks[B - 1, : T // 4] = 1                                     # the last clip carries its own label pattern
+    wav_gpu, codes_gpu, marks_gpu = wav.cuda(), codes.cuda(), marks.cuda()
+    out, mk = m.wmdecode(codes_gpu, marks_gpu, wav_gpu, with_mark=True)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (B, 1, n) and tuple(mk.shape) == (B, T, 2)
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(mk).all())
+    out_nomark, none = m.wmdecode(codes_gpu, marks_gpu, wav_gpu, with_mark=False)      # the CLI's call (the detector output is discarded there)
+    assert none is None and torch.equal(out_nomark, out)
+    del out_nomark
+    for b in (0, 131, B - 1):
+        o_wav, o_mk = OC.wmdecode(sd, codes[b:b + 1], marks[b:b + 1], wav[b:b + 1], cfg)
+        np.testing.assert_allclose(out[b:b + 1].cpu().numpy(), o_wav.numpy(), rtol=0, atol=2e-4)
+        np.testing.assert_allclose(mk[b:b + 1].cpu().numpy(), o_mk.numpy(), rtol=0, atol=2e-4)
+
+
 def test_config3_edit_of_the_reference_demo_wav_end_to_end():
     """BASELINE config 3 on the file it names (the chain wav -> codes -> edit -> wav had only been run on random codes).
     (a) the demo wav tokenises to 397 frames; the 830M LM's first 8 greedy CFG steps of the span [150, 250) edit on THOSE codes equal
