@@ -317,6 +317,12 @@ typedef struct ssrhip_resblock_args {
   int32_t B, T, C;
   int64_t x_bstride, y_bstride;   /* elements between items */
   int32_t out_act;                /* SSRHIP_ACT_ELU: y = ELU(block(x)): the block's only consumer is `ELU -> conv` */
+  /* optional (both or none; C in {64, 128}): the two weight matrices as three bf16 planes each (ssrhip_split_weights) — the block then runs
+   * on the bf16 matrix cores with exactly split fp32 operands, weights streamed global -> LDS by DMA (csrc/resblock_split.hip).
+   *   w3_split: planes of w3 as it is, [3][C/2][3*C];
+   *   w1_split: planes of w1 with its COLUMNS permuted into the order the kernel's stage-1 accumulator hands the hidden channels on:
+   *             column k' = 16 j + 8 g + i (j = k'/16, g = (k'/8) % 2, i = k' % 8) holds hidden channel h = 16 j + (i % 4) + 8 (i / 4) + 4 g. */
+  const uint16_t* w3_split; const uint16_t* w1_split;
 } ssrhip_resblock_args;
 int ssrhip_resblock(const ssrhip_resblock_args* a, ssrhip_stream_t stream);
 

@@ -109,7 +109,7 @@ _PP = C.POINTER(C.c_void_p)
 class ResblockArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("w3", C.c_void_p), ("b3", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
                 ("B", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("x_bstride", C.c_int64), ("y_bstride", C.c_int64),
-                ("out_act", C.c_int32)]
+                ("out_act", C.c_int32), ("w3_split", C.c_void_p), ("w1_split", C.c_void_p)]
 
 
 class LMWeights(C.Structure):

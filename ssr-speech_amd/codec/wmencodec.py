@@ -251,6 +251,8 @@ class WMEncodecModel:
                 elif kind == "res":
                     self._planes(obj[0].W)
                     self._planes(obj[1].W)
+                    if obj[0].Cin in self.fuse_channels:
+                        self._resblock_planes(obj[0], obj[1])
                 elif kind == "lstm":
                     for wih, _, _ in obj.layers:
                         self._planes(wih)
@@ -274,6 +276,30 @@ class WMEncodecModel:
         if hit is None:
             hit = torch.empty(3, W.shape[0], W.shape[1], dtype=torch.int16, device=W.device)
             _lib.check(self.lib.ssrhip_split_weights(W.data_ptr(), hit.data_ptr(), W.numel(), self._s()), "ssrhip_split_weights")
+            self._plane_cache[key] = hit
+        return hit
+
+    def _resblock_planes(self, c3, c1):
+        """bf16 planes of a residual block's two matrices for csrc/resblock_split.hip (C in {64, 128}): W3 [C/2][3C] as it is, W1 [C][C/2]
+        with its columns in the order the kernel's stage-1 accumulator hands the hidden channels on (include/ssrhip.h w1_split).
+        Made once per block on the device; None when the split path is off."""
+        if not self.split_gemm or c3.Cin not in (64, 128):
+            return None
+        key = ("res", c3.W.data_ptr(), c1.W.data_ptr())
+        hit = self._plane_cache.get(key)
+        if hit is None:
+            Hh = c3.Cout
+            kp = torch.arange(Hh, device=c1.W.device)
+            j, g, i = kp // 16, (kp // 8) % 2, kp % 8
+            perm = 16 * j + (i % 4) + 8 * (i // 4) + 4 * g
+            w1p = c1.W.reshape(c1.Cout, Hh)[:, perm].contiguous()
+            w3 = c3.W.reshape(Hh, -1).contiguous()
+            p3 = torch.empty(3, w3.shape[0], w3.shape[1], dtype=torch.int16, device=w3.device)
+            p1 = torch.empty(3, w1p.shape[0], w1p.shape[1], dtype=torch.int16, device=w3.device)
+            _lib.check(self.lib.ssrhip_split_weights(w3.data_ptr(), p3.data_ptr(), w3.numel(), self._s()), "ssrhip_split_weights")
+            _lib.check(self.lib.ssrhip_split_weights(w1p.data_ptr(), p1.data_ptr(), w1p.numel(), self._s()), "ssrhip_split_weights")
+            torch.cuda.current_stream(w3.device).synchronize()       # w1p / w3 temporaries may be freed after this call
+            hit = (p3, p1)
             self._plane_cache[key] = hit
         return hit
 
@@ -378,6 +404,9 @@ class WMEncodecModel:
             a.B, a.T, a.C = x.B, x.T, c3.Cin
             a.x_bstride, a.y_bstride = x.bstride, out.bstride
             a.out_act = _lib.ACT_ELU if post_elu else 0
+            planes = self._resblock_planes(c3, c1)
+            if planes is not None:
+                a.w3_split, a.w1_split = planes[0].data_ptr(), planes[1].data_ptr()
             _lib.check(self.lib.ssrhip_resblock(C.byref(a), self._s()), "ssrhip_resblock")
             out.elu = post_elu
             self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))

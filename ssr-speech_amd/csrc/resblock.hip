@@ -474,9 +474,17 @@ int launch_resblock_chain(const ssrhip_resblock_args* a, hipStream_t s) {
 
 }  // namespace
 
+int ssrhip_resblock_split_launch(const ssrhip_resblock_args* a, hipStream_t s);   // resblock_split.hip
+
 extern "C" int ssrhip_resblock(const ssrhip_resblock_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->x && a->y && a->w3 && a->b3 && a->w1 && a->b1, "ssrhip_resblock: null argument");
   SSR_REQUIRE(a->B > 0 && a->B <= 65535 && a->T > 0, "ssrhip_resblock: bad B / T");
+  SSR_REQUIRE(!a->w3_split == !a->w1_split, "ssrhip_resblock: w3_split and w1_split come together");
+  if (a->w3_split && (a->C == 64 || a->C == 128)) {                // the caller prepared the bf16 planes: the DMA kernel (round 4)
+    static const bool split_off2 = (getenv("SSRHIP_GEMM_SPLIT") && getenv("SSRHIP_GEMM_SPLIT")[0] == '0') ||
+                                   (getenv("SSRHIP_RESBLOCK_DMA") && getenv("SSRHIP_RESBLOCK_DMA")[0] == '0');   // A/B knobs
+    if (!split_off2) return ssrhip_resblock_split_launch(a, (hipStream_t)stream);
+  }
   if (a->C == 128 || a->C == 256 || a->C == 512) {
     static const int big = getenv("SSRHIP_RESCHAIN_BIG") ? atoi(getenv("SSRHIP_RESCHAIN_BIG")) : 0;   // tuning knob: the larger row block
     hipStream_t s = (hipStream_t)stream;

@@ -1,0 +1,258 @@
+// resblock_split.hip — SEANetResnetBlock (audiocraft/modules/seanet.py:16-60; true_skip, dilation 1, kernels 3 and 1) for C = 64 and
+// C = 128 channels as ONE kernel on the bf16 matrix cores with exactly split fp32 operands (round 4).
+//
+//     y[t] = x[t] + b1 + W1 . ELU( b3 + W3 . ELU( x[t-1 : t+2] ) )          W3: [C/2][3][C], W1: [C][C/2]
+//
+// The arithmetic is csrc/gemm_split.hip's: every fp32 operand is the exact sum of three bf16 pieces, the six largest cross products are
+// accumulated in fp32 (error against fp64 no larger than the fp32 FMA chain's). What round 3's resblock_chain_split_kernel<128> left on
+// the table (55.6 ms per call at 256 clips x 30 s against 9.6 ms of matrix time and 12.6 ms of HBM time) and what is done
+// about it here:
+//   * W3 / W1 were split from fp32 again by every workgroup at every k-step: the host splits them ONCE (ssrhip_resblock_args.w3_split /
+//     w1_split, three bf16 planes each) and the kernel brings the tiles global -> LDS by DMA, one step ahead, no registers, no ds_write;
+//   * the x window was loaded, ELU'd and split once PER TAP (three times per element): a tile of ELU(x) — 130 rows x 32 channels, three
+//     bf16 planes, XOR-swizzled 64-byte rows — is built once per channel tile and the three taps read it at row offsets 0 / 1 / 2;
+//   * the C/2-channel intermediate made a round trip through LDS (fp32, split again by every reading wave): stage 1 runs TRANSPOSED
+//     (H^T[h][t] = W3 . ELU(x)^T, the time steps as the N dimension), so that a lane's accumulator registers are 16 hidden channels of
+//     ITS time step — exactly the A operand stage 2 wants (row = time step, k = hidden channel) once W1's k order follows the
+//     accumulator's row order (the host permutes W1's columns; resblock64_kernel's trick, carried over to the bf16 pipe). A wave owns
+//     32 time steps through both stages; waves exchange nothing but the shared weight / input tiles;
+//   * two barriers per 16-wide k-step with 12 MFMAs between them: one barrier per 32-wide step with 24 MFMAs per wave between them
+//     (two at the four channel-tile boundaries), 4 waves per workgroup, ~50 KB of LDS: three workgroups per CU.
+// Replaces the two strided-view GEMMs (or the round-3 fused kernels) for `SEANetResnetBlock` at C in {64, 128}; results are NOT
+// bit-identical to them (same class of error; tests: G7 per-module fixtures and the end-to-end codec fixtures, 2e-4 / 2e-5).
+#include <stdlib.h>
+#include <algorithm>
+using std::min;
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bfx2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ float elu_r(float v) {          // the codec's ELU (same function as gemm.hip / resblock.hip)
+  const float p = v * (1.0f + v * (0.5f + v * (0.16666667f + v * (0.041666668f + v * (0.0083333338f + v * 0.0013888889f)))));
+  const float e = __expf(v) - 1.0f;
+  const float neg = v > -0.25f ? p : e;
+  return v > 0.f ? v : neg;
+}
+
+// exact three-way split of 4 consecutive values: piece p of element e in out[p][e]   (gemm_split.hip)
+__device__ __forceinline__ void split4r(const float4 v, bf16x4 (&out)[3]) {
+  f32x2 r[2] = {{v.x, v.y}, {v.z, v.w}};
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bfx2 b = __builtin_convertvector(r[h], bfx2);
+      const unsigned bits = __builtin_bit_cast(unsigned, b);
+      out[p][2 * h] = (short)(bits & 0xFFFFu);
+      out[p][2 * h + 1] = (short)(bits >> 16);
+      if (p < 2) {
+        const f32x2 back = {__builtin_bit_cast(float, bits << 16), __builtin_bit_cast(float, bits & 0xFFFF0000u)};
+        r[h] = r[h] - back;
+      }
+    }
+  }
+}
+
+constexpr int RB_BM = 128, RB_TH = 256, RB_NW = 4;        // time steps per workgroup, threads, waves
+constexpr int RB_ER = RB_BM + 2 + 2;                      // rows of the ELU(x) tile (130 used; padded to a multiple of 4 for the swizzle period)
+constexpr int RB_EP = RB_ER * 64;                         // bytes per bf16 plane of the tile (64-byte rows = 32 channels)
+constexpr int rb_wtile(int CC) { return 96 * CC; }        // bytes of one weight tile: W3 [3][C/2][32 k] = W1 [3][C][16 k] = 96 C
+constexpr int rb_lds(int CC) { return 3 * RB_EP + 2 * rb_wtile(CC); }
+
+template <int CC>
+__global__ __launch_bounds__(RB_TH, 3) void resblock_split_dma_kernel(const ssrhip_resblock_args a) {
+  constexpr int HH = CC / 2, NHB = HH / 32, NCT = CC / 32, NNB = CC / 32, NJ = HH / 16;
+  constexpr int NS1 = NCT * 3;                             // weight tiles: NS1 of W3 (channel tile, tap), then NJ of W1
+  constexpr int WT = rb_wtile(CC), NIT = 3 * HH / 16;      // DMA instructions per tile (1 KiB each): 3 planes x HH/16 (= 3 x CC/32)
+  constexpr int K3 = 3 * CC;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // a2b0, a0b2, a1b1, a1b0, a0b1, a0b0 (smallest first)
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  char* const Es = lds;                                    // [3][RB_ER][64 B]
+  char* const Wb = lds + 3 * RB_EP;                        // [2][WT]
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int T = a.T, m0 = blockIdx.x * RB_BM;
+  const float* xin = a.x + (size_t)blockIdx.y * a.x_bstride;      // row 0 = the halo row in front of t = 0; T + 2 rows per item
+  float* yout = a.y + (size_t)blockIdx.y * a.y_bstride;
+  const short* w3p = reinterpret_cast<const short*>(a.w3_split);  // [3][HH][3 CC]
+  const short* w1p = reinterpret_cast<const short*>(a.w1_split);  // [3][CC][HH], k in accumulator order (include/ssrhip.h)
+  const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(w3p), 0, 3 * HH * K3 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(w1p), 0, 3 * CC * HH * 2, 0x00020000);
+
+  // ---- weight tile u -> Wb[u & 1] by DMA (wave-level instruction = one lane-linear KiB)
+  auto dma_tile = [&](int u) {
+    char* dst = Wb + (u & 1) * WT;
+    if (u < NS1) {
+      // W3 tile (channel tile ct, tap): rows h, 32 k = 64 B per row and plane. KiB = 16 rows; lane l lands in (row 16g + l/4, slot l%4),
+      // which has to hold chunk (l%4) ^ ((row >> 2) & 3)
+      const int ct = u / 3, tap = u % 3;
+      for (int it = wave; it < NIT; it += RB_NW) {
+        const int q = it / (HH / 16), g = it % (HH / 16);
+        const int row = 16 * g + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
+        const unsigned off = (unsigned)((((size_t)q * HH + row) * K3 + tap * CC + ct * 32 + chunk * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs3, (lds_ptr_t)(dst + q * HH * 64 + g * 1024), 16, off, 0, 0, 0);
+      }
+    } else {
+      // W1 tile j: rows n, 16 k' = 32 B per row and plane, dense. KiB = 32 rows; lane l lands in (row 32g + l/2, half l%2)
+      const int j = u - NS1;
+      for (int it = wave; it < NIT; it += RB_NW) {
+        const int q = it / (CC / 32), g = it % (CC / 32);
+        const int row = 32 * g + (lane >> 1);
+        const unsigned off = (unsigned)((((size_t)q * CC + row) * HH + j * 16 + (lane & 1) * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(dst + q * CC * 32 + g * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+  // ---- ELU(x) tile of channel tile ct: 130 rows (times m0 - 1 .. m0 + 128) x 32 channels; 1040 float4 over 256 threads
+  constexpr int NEL = (130 * 8 + RB_TH - 1) / RB_TH;       // 5
+  float4 er[NEL];
+  auto e_load = [&](int ct) {
+#pragma unroll
+    for (int i = 0; i < NEL; ++i) {
+      const int idx = min(t + RB_TH * i, 130 * 8 - 1);      // the surplus threads of the last pass repeat the last piece (same value, same slot)
+      const int row = idx >> 3, c4 = idx & 7;
+      const int prow = min(m0 + row, T + 1);               // padded row; tiles that run past the item: clamped (those outputs are not stored)
+      er[i] = ld4(xin + (size_t)prow * CC + ct * 32 + c4 * 4);
+    }
+  };
+  auto e_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NEL; ++i) {
+      const int idx = min(t + RB_TH * i, 130 * 8 - 1);
+      const int row = idx >> 3, c4 = idx & 7;
+      const float4 v = make_float4(elu_r(er[i].x), elu_r(er[i].y), elu_r(er[i].z), elu_r(er[i].w));
+      bf16x4 p[3];
+      split4r(v, p);
+      const int off = row * 64 + (((c4 >> 1) ^ ((row >> 2) & 3)) << 4) + (c4 & 1) * 8;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(Es + q * RB_EP + off) = p[q];
+    }
+  };
+
+  f32x16 acc1[NHB];
+#pragma unroll
+  for (int hb = 0; hb < NHB; ++hb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[hb][r] = 0.f;
+  f32x16 acc2[NNB];
+  bf16x8 hf[3][NJ];                                        // stage-2 A operand: ELU(H + b3) of this lane's time step, split, in k' order
+
+  e_load(0);
+  dma_tile(0);
+  // ---- stage 1, transposed: acc1[hb][h][m] += W3[h][k] . E[m + tap][k]; a runtime loop over the channel tiles (a fully unrolled
+  // 16-step loop was refused by the compiler and left the register arrays in scratch), the three taps of a tile unrolled
+  for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+      const int u = ct * 3 + tap;
+      if (tap == 0) {
+        if (ct > 0) __syncthreads();                       // every wave has finished reading the previous channel tile
+        e_store();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile u has landed (and the x prefetch, a whole step old)
+      __syncthreads();                                     // tile u (and a new ELU(x) tile) visible; everyone is done with tile u - 1
+      dma_tile(u + 1);                                     // u + 1 <= NS1: the last one is W1's first tile
+      if (tap == 0 && ct + 1 < NCT) e_load(ct + 1);
+      __builtin_amdgcn_sched_barrier(0);                   // keep the requests HERE, in front of the MFMA block
+      const char* Wt = Wb + (u & 1) * WT;
+      const int erow = 32 * wave + li + tap;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 32; kk += 16) {
+        const int cidx = (kk >> 3) + lh;
+        bf16x8 fb[3], fa[3][NHB];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          fb[q] = *reinterpret_cast<const bf16x8*>(Es + q * RB_EP + erow * 64 + ((cidx ^ ((erow >> 2) & 3)) << 4));
+#pragma unroll
+          for (int hb = 0; hb < NHB; ++hb) {
+            const int hrow = hb * 32 + li;
+            fa[q][hb] = *reinterpret_cast<const bf16x8*>(Wt + q * HH * 64 + hrow * 64 + ((cidx ^ ((hrow >> 2) & 3)) << 4));
+          }
+        }
+#pragma unroll
+        for (int pq = 0; pq < 6; ++pq)
+#pragma unroll
+          for (int hb = 0; hb < NHB; ++hb) acc1[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pq]][hb], fb[PB[pq]], acc1[hb], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  // ---- between the stages, in registers: accumulator register r of block hb = hidden channel hb*32 + (r&3) + 8(r>>2) + 4lh of time
+  // step 32 wave + li; ELU(. + b3), exact three-way split, packed as the A operand of stage 2: k16-step j = 2 hb + (r >> 3), element r & 7
+#pragma unroll
+  for (int hb = 0; hb < NHB; ++hb)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = half * 8 + i;
+        v[i] = elu_r(acc1[hb][r] + a.b3[hb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh]);
+      }
+      bf16x4 p0[3], p1[3];
+      split4r(make_float4(v[0], v[1], v[2], v[3]), p0);
+      split4r(make_float4(v[4], v[5], v[6], v[7]), p1);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) hf[q][2 * hb + half] = __builtin_shufflevector(p0[q], p1[q], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+#pragma unroll
+  for (int nb = 0; nb < NNB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+  // ---- stage 2: acc2[nb][m][n] += H[m][k'] . W1[n][k'] for the 16 hidden channels of step j (unrolled: hf[.][j] stays in registers)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int u = NS1 + j;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (j + 1 < NJ) dma_tile(u + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const char* Wt = Wb + (u & 1) * WT;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) {                       // one output block at a time: 12 operand registers instead of 12 x NNB
+      bf16x8 fb[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) fb[q] = *reinterpret_cast<const bf16x8*>(Wt + q * CC * 32 + (nb * 32 + li) * 32 + lh * 16);
+#pragma unroll
+      for (int pq = 0; pq < 6; ++pq) acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[PA[pq]][j], fb[PB[pq]], acc2[nb], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  // ---- epilogue: + b1 + x (raw: the centre tap's row), 128-byte runs per accumulator row
+#pragma unroll
+  for (int nb = 0; nb < NNB; ++nb) {
+    const int n = nb * 32 + li;
+    const float b1 = a.b1[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < T) {
+        float o = xin[(size_t)(m + 1) * CC + n] + (acc2[nb][r] + b1);
+        if (a.out_act == SSRHIP_ACT_ELU) o = elu_r(o);
+        yout[(size_t)m * CC + n] = o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// launched by ssrhip_resblock (resblock.hip) when the caller supplied the weight planes
+int ssrhip_resblock_split_launch(const ssrhip_resblock_args* a, hipStream_t s) {
+  SSR_REQUIRE(a->C == 64 || a->C == 128, "ssrhip_resblock (split planes): C=%d not in {64, 128}", a->C);
+  SSR_REQUIRE((size_t)(a->T + 2) * a->C * 4 < 0x7FFFFFF0ull, "ssrhip_resblock (split planes): item too long");
+  dim3 grid((a->T + RB_BM - 1) / RB_BM, a->B);
+  if (a->C == 128) hipLaunchKernelGGL(resblock_split_dma_kernel<128>, grid, dim3(RB_TH), rb_lds(128), s, *a);
+  else hipLaunchKernelGGL(resblock_split_dma_kernel<64>, grid, dim3(RB_TH), rb_lds(64), s, *a);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}

@@ -1004,3 +1004,50 @@ def test_gemm_split_result_of_an_item_does_not_depend_on_the_batch(L):
 
     alone, many = run(1), run(B)
     assert torch.equal(alone[0], many[0])
+
+
+@pytest.mark.parametrize("Cc", [64, 128])
+@pytest.mark.parametrize("T", [1, 127, 128, 129, 1000])
+@pytest.mark.parametrize("out_act", [0, _lib.ACT_ELU])
+def test_resblock_split_dma_kernel_matches_fp64(L, Cc, T, out_act):
+    """csrc/resblock_split.hip (round 4: SEANetResnetBlock at C = 64 / 128 on the bf16 matrix cores, fp32 operands split exactly, weights by
+    DMA, the intermediate handed from stage 1 to stage 2 in registers through a column permutation of W1) against an fp64 evaluation of
+    y = x + b1 + W1 . ELU(b3 + W3 . ELU(x[t-1:t+2])) (modules/seanet.py:16-60): tiles that end inside a 128-step block, a single time step,
+    three items with their own halos, with and without the ELU-on-store epilogue. Error no larger than the fp32 paths' (2e-5 on O(1) data);
+    and the plane-less call (round-3 kernels) agrees to the same tolerance."""
+    g = torch.Generator().manual_seed(1000 * Cc + T)
+    Hh, B = Cc // 2, 3
+    x = torch.randn(B, T + 2, Cc, generator=g)                         # rows 0 and T + 1: the halo (any values: a reflect / zero pad)
+    w3 = torch.randn(Hh, 3, Cc, generator=g) / math.sqrt(3 * Cc)
+    w1 = torch.randn(Cc, Hh, generator=g) / math.sqrt(Hh)
+    b3, b1 = torch.randn(Hh, generator=g) * 0.1, torch.randn(Cc, generator=g) * 0.1
+    xd = x.double()
+    win = torch.cat([xd[:, 0:T], xd[:, 1:T + 1], xd[:, 2:T + 2]], dim=2)          # [B][T][3C]: taps t-1, t, t+1
+    hmid = F.elu(F.elu(win) @ w3.reshape(Hh, 3 * Cc).double().t() + b3.double())
+    want = xd[:, 1:T + 1] + hmid @ w1.double().t() + b1.double()
+    if out_act:
+        want = F.elu(want)
+    dx, dw3, dw1, db3, db1 = dev(x), dev(w3.reshape(Hh, 3 * Cc).contiguous()), dev(w1), dev(b3), dev(b1)
+    kp = torch.arange(Hh)
+    perm = 16 * (kp // 16) + (kp % 8) % 4 + 8 * ((kp % 8) // 4) + 4 * ((kp // 8) % 2)
+    assert sorted(perm.tolist()) == list(range(Hh))
+    dw1p = dev(w1[:, perm].contiguous())
+    p3 = torch.empty(3, Hh, 3 * Cc, dtype=torch.int16, device="cuda")
+    p1 = torch.empty(3, Cc, Hh, dtype=torch.int16, device="cuda")
+    _lib.check(L.ssrhip_split_weights(dw3.data_ptr(), p3.data_ptr(), dw3.numel(), _lib.stream_ptr()))
+    _lib.check(L.ssrhip_split_weights(dw1p.data_ptr(), p1.data_ptr(), dw1p.numel(), _lib.stream_ptr()))
+    outs = []
+    for planes in (True, False):
+        y = torch.full((B, T, Cc), float("nan"), device="cuda")
+        a = _lib.ResblockArgs()
+        a.x, a.y, a.w3, a.b3, a.w1, a.b1 = dx.data_ptr(), y.data_ptr(), dw3.data_ptr(), db3.data_ptr(), dw1.data_ptr(), db1.data_ptr()
+        a.B, a.T, a.C, a.x_bstride, a.y_bstride, a.out_act = B, T, Cc, (T + 2) * Cc, T * Cc, out_act
+        if planes:
+            a.w3_split, a.w1_split = p3.data_ptr(), p1.data_ptr()
+        _lib.check(L.ssrhip_resblock(C.byref(a), _lib.stream_ptr()))
+        sync()
+        outs.append(y.cpu())
+        torch.testing.assert_close(y.cpu().double(), want, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(outs[0], outs[1], rtol=2e-5, atol=2e-5)
+    a.w3_split, a.w1_split = p3.data_ptr(), 0
+    assert L.ssrhip_resblock(C.byref(a), _lib.stream_ptr()) != 0                           # the two plane pointers come together
