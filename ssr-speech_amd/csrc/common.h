@@ -39,6 +39,18 @@ struct ssr_once_per_device {
   }
 };
 
+// profiling aid (tools/prof_summary.py --gemm-log): one line per GEMM launch — M N K batch, the launch grid, split (1) or fp32 chain (0) —
+// so that a kernel trace's GEMM rows get their problem size and a TFLOP/s column. Off unless SSRHIP_GEMM_LOG names a file.
+#include <stdio.h>
+#include <stdlib.h>
+static inline void ssr_gemm_log(const ssrhip_gemm_args* a, unsigned gx, unsigned gy, unsigned gz, int split) {
+  static FILE* glog = getenv("SSRHIP_GEMM_LOG") ? fopen(getenv("SSRHIP_GEMM_LOG"), "a") : nullptr;
+  if (glog) {
+    fprintf(glog, "%d %d %d %d %u %u %u %d\n", a->M, a->N, a->K, a->batch > 1 ? a->batch : 1, gx, gy, gz, split);
+    fflush(glog);
+  }
+}
+
 #define SSR_LAUNCH_CHECK()                                                    \
   do {                                                                        \
     hipError_t _e = hipGetLastError();                                        \
@@ -145,14 +157,15 @@ __device__ __forceinline__ float4 ld_nt(const float* p) {
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-// nn.ELU(alpha=1) on operand load. libm's expm1f costs ~40 VALU ops and the convolution views re-load every input element
-// k (taps) x N-tiles times — it made the narrow SEANet layers VALU-bound. exp(v)-1 for v <= 0 as: degree-6 Taylor for
-// v > -0.25 (truncation 1.2e-8), else v_exp_f32 - 1 (abs error <= 1.2e-7 on a result >= 0.22 in magnitude).
+// nn.ELU(alpha = 1): v > 0 ? v : exp(v) - 1 with the hardware exponential (v_exp_f32). Absolute error <= 1.2e-7 everywhere (for |v| below
+// 6e-8 the result is 0 instead of v). Rounds 1-3 switched to a degree-6 Taylor polynomial above -0.25 for RELATIVE accuracy near zero;
+// round 4's counters showed what that costs — the fused residual block was VALU-bound, half of its 4,230 VALU instructions per wave and
+// tile were ELUs at ~13 instructions each (profiles/r04_microbench/resblock_pmc.log) — and nothing downstream needs it: every consumer is a
+// convolution whose result is compared in absolute terms (5e-5 per layer, 2e-5 end to end against the reference fixtures). ONE definition
+// for every codec kernel, so ELU-on-store stays bit-identical to ELU-on-load (tests/test_gpu_codec.py).
 __device__ __forceinline__ float elu1(float v) {
-  const float p = v * (1.0f + v * (0.5f + v * (0.16666667f + v * (0.041666668f + v * (0.0083333338f + v * 0.0013888889f)))));
   const float e = __expf(v) - 1.0f;
-  const float neg = v > -0.25f ? p : e;
-  return v > 0.f ? v : neg;
+  return v > 0.f ? v : e;
 }
 
 // address of element (pos, d) of head h, k(0)/v(1), layer, in sequence `seq`'s paged cache

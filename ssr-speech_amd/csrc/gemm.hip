@@ -9,6 +9,7 @@
 // LDS rows are padded to 20 floats: a lane's ds_read_b128 (4 consecutive k of one row) then hits 16
 // distinct 16-byte slots per 16-lane group -> conflict-free. The k-pairs fed to one MFMA are (t, t+4):
 // any permutation of k is legal as long as A and W use the same one.
+#include <stdio.h>
 #include <stdlib.h>
 #include "common.h"
 
@@ -232,6 +233,7 @@ extern "C" int ssrhip_gemm(const ssrhip_gemm_args* a, ssrhip_stream_t stream) {
   if (small_grid) bn = 64;
   SSR_REQUIRE(a->batch <= 65535 && (a->M + bm - 1) / bm <= 65535, "ssrhip_gemm: grid too large (M=%d batch=%d)", a->M, a->batch);
   dim3 grid((a->N + bn - 1) / bn, (a->M + bm - 1) / bm, a->batch > 1 ? a->batch : 1);
+  ssr_gemm_log(a, grid.x, grid.y, grid.z, 0);
   // Experiment knob (off): 128 x 128 tiles (each wave 64 x 64: twice the FLOPs per operand byte staged through LDS). Measured
   // SLOWER on the codec (32 clips x 30 s: encode 86.6 -> 96.7 ms, decode 88.5 -> 98.2 ms): one workgroup per CU no longer
   // hides the two barriers per k-tile.

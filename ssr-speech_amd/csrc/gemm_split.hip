@@ -393,6 +393,7 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
   }
   if (tiles128 >= 384 && !half_empty) {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 127) / 128, (unsigned)nb);
+    ssr_gemm_log(a, grid.x, grid.y, grid.z, 1);
     if (dma) {
       if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<128, true>), grid, dim3(512), dma_lds(128), s, *a);
       else hipLaunchKernelGGL((gemm_split_dma_kernel<128, false>), grid, dim3(512), dma_lds(128), s, *a);
@@ -400,6 +401,7 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_split_kernel<128, false>), grid, dim3(256), 0, s, *a);
   } else {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 63) / 64, (unsigned)nb);
+    ssr_gemm_log(a, grid.x, grid.y, grid.z, 1);
     if (dma) {
       if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<64, true>), grid, dim3(512), dma_lds(64), s, *a);
       else hipLaunchKernelGGL((gemm_split_dma_kernel<64, false>), grid, dim3(512), dma_lds(64), s, *a);

@@ -25,12 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int C = 64, H = 32, K3 = 3 * C, XS = C + 4;     // XS: padded LDS row stride (floats)
 
-__device__ __forceinline__ float elu_fast(float v) {       // same function as gemm.hip's ELU-on-load
-  const float p = v * (1.0f + v * (0.5f + v * (0.16666667f + v * (0.041666668f + v * (0.0083333338f + v * 0.0013888889f)))));
-  const float e = __expf(v) - 1.0f;
-  const float neg = v > -0.25f ? p : e;
-  return v > 0.f ? v : neg;
-}
+__device__ __forceinline__ float elu_fast(float v) { return elu1(v); }      // the codec's one ELU (common.h)
 
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 

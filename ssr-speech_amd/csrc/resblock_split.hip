@@ -17,7 +17,10 @@
 //     accumulator's row order (the host permutes W1's columns; resblock64_kernel's trick, carried over to the bf16 pipe). A wave owns
 //     32 time steps through both stages; waves exchange nothing but the shared weight / input tiles;
 //   * two barriers per 16-wide k-step with 12 MFMAs between them: one barrier per 32-wide step with 24 MFMAs per wave between them
-//     (two at the four channel-tile boundaries), 4 waves per workgroup, ~50 KB of LDS: three workgroups per CU.
+//     (two at the channel-tile boundaries), 4 waves per workgroup;
+//   * a 32-wide step is ~0.3 us of MFMAs, an L2 -> LDS DMA ~1 us: the weight tiles go through a ring of FOUR LDS slots, three steps ahead
+//     of their use (first version: one ahead, 36.6 ms per call at C = 128 — every step waited for its tile). The DMA is issued as inline
+//     asm and counted by hand (vmcnt): through the builtin hipcc makes every ds_read wait for every LDS-DMA issued before it.
 // Replaces the two strided-view GEMMs (or the round-3 fused kernels) for `SEANetResnetBlock` at C in {64, 128}; results are NOT
 // bit-identical to them (same class of error; tests: G7 per-module fixtures and the end-to-end codec fixtures, 2e-4 / 2e-5).
 #include <stdlib.h>
@@ -34,12 +37,7 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bfx2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-__device__ __forceinline__ float elu_r(float v) {          // the codec's ELU (same function as gemm.hip / resblock.hip)
-  const float p = v * (1.0f + v * (0.5f + v * (0.16666667f + v * (0.041666668f + v * (0.0083333338f + v * 0.0013888889f)))));
-  const float e = __expf(v) - 1.0f;
-  const float neg = v > -0.25f ? p : e;
-  return v > 0.f ? v : neg;
-}
+__device__ __forceinline__ float elu_r(float v) { return elu1(v); }         // the codec's one ELU (common.h: hardware exponential, |error| <= 1.2e-7)
 
 // exact three-way split of 4 consecutive values: piece p of element e in out[p][e]   (gemm_split.hip)
 __device__ __forceinline__ void split4r(const float4 v, bf16x4 (&out)[3]) {
@@ -64,18 +62,50 @@ constexpr int RB_BM = 128, RB_TH = 256, RB_NW = 4;        // time steps per work
 constexpr int RB_ER = RB_BM + 2 + 2;                      // rows of the ELU(x) tile (130 used; padded to a multiple of 4 for the swizzle period)
 constexpr int RB_EP = RB_ER * 64;                         // bytes per bf16 plane of the tile (64-byte rows = 32 channels)
 constexpr int rb_wtile(int CC) { return 96 * CC; }        // bytes of one weight tile: W3 [3][C/2][32 k] = W1 [3][C][16 k] = 96 C
-constexpr int rb_lds(int CC) { return 3 * RB_EP + 2 * rb_wtile(CC); }
+constexpr int NS1X(int CC) { return 3 * (CC / 32); }
+// weight tiles in LDS = RING: the one in use + RING - 1 in flight (a 32-wide step is ~0.3 us of MFMAs, an L2 -> LDS DMA ~1 us)
+constexpr int rb_lds(int CC, int RING) { return 3 * RB_EP + RING * rb_wtile(CC); }
+typedef int i32x4r __attribute__((ext_vector_type(4)));
 
-template <int CC>
-__global__ __launch_bounds__(RB_TH, 3) void resblock_split_dma_kernel(const ssrhip_resblock_args a) {
+// LDS-DMA as inline asm: with the builtin hipcc applies its conservative alias rule — every ds_read behind an LDS-DMA first waits for
+// the DMA (seen in the ISA: s_waitcnt vmcnt right behind the request), which makes a prefetch distance impossible. The asm form is
+// invisible to that pass; its completion is counted by hand (wait_vm below). M0 = LDS byte address of the wave's KiB, restored afterwards.
+__device__ __forceinline__ void dma_kib(const i32x4r rsrc, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
+}
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;   // n >= 12: a stricter wait is always correct
+  }
+}
+
+template <int CC, int RB_RING>
+__global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrhip_resblock_args a) {
   constexpr int HH = CC / 2, NHB = HH / 32, NCT = CC / 32, NNB = CC / 32, NJ = HH / 16;
   constexpr int NS1 = NCT * 3;                             // weight tiles: NS1 of W3 (channel tile, tap), then NJ of W1
   constexpr int WT = rb_wtile(CC), NIT = 3 * HH / 16;      // DMA instructions per tile (1 KiB each): 3 planes x HH/16 (= 3 x CC/32)
+  constexpr int CNT = (NIT + RB_NW - 1) / RB_NW;           // ... per wave (C = 64: 6 over 4 waves -> 2 each, the surplus repeats the last KiB)
+  constexpr int NU = NS1X(CC) + HH / 16;                   // weight tiles in all
   constexpr int K3 = 3 * CC;
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // a2b0, a0b2, a1b1, a1b0, a0b1, a0b0 (smallest first)
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* const Es = lds;                                    // [3][RB_ER][64 B]
-  char* const Wb = lds + 3 * RB_EP;                        // [2][WT]
+  char* const Wb = lds + 3 * RB_EP;                        // [RB_RING][WT]
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int T = a.T, m0 = blockIdx.x * RB_BM;
@@ -83,33 +113,51 @@ __global__ __launch_bounds__(RB_TH, 3) void resblock_split_dma_kernel(const ssrh
   float* yout = a.y + (size_t)blockIdx.y * a.y_bstride;
   const short* w3p = reinterpret_cast<const short*>(a.w3_split);  // [3][HH][3 CC]
   const short* w1p = reinterpret_cast<const short*>(a.w1_split);  // [3][CC][HH], k in accumulator order (include/ssrhip.h)
-  const __amdgpu_buffer_rsrc_t rs3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(w3p), 0, 3 * HH * K3 * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(w1p), 0, 3 * CC * HH * 2, 0x00020000);
+  auto make_rsrc = [](const void* p, int bytes) {          // raw buffer descriptor: base, stride 0, extent, the flags make_buffer_rsrc uses
+    const unsigned long long ad = (unsigned long long)(uintptr_t)p;
+    i32x4r r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)ad);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((ad >> 32) & 0xFFFFu));
+    r[2] = bytes;
+    r[3] = 0x00020000;
+    return r;
+  };
+  const i32x4r rs3 = make_rsrc(w3p, 3 * HH * K3 * 2), rs1 = make_rsrc(w1p, 3 * CC * HH * 2);
+  const unsigned wb_addr = (unsigned)(uintptr_t)(lds_ptr_t)Wb;          // LDS byte address of the ring
 
-  // ---- weight tile u -> Wb[u & 1] by DMA (wave-level instruction = one lane-linear KiB)
+  // ---- weight tile u -> ring slot u % RB_RING by DMA (a wave-level instruction = one lane-linear KiB; CNT per wave and tile)
   auto dma_tile = [&](int u) {
-    char* dst = Wb + (u & 1) * WT;
+    const unsigned dst = wb_addr + (unsigned)(u % RB_RING) * WT;
     if (u < NS1) {
       // W3 tile (channel tile ct, tap): rows h, 32 k = 64 B per row and plane. KiB = 16 rows; lane l lands in (row 16g + l/4, slot l%4),
       // which has to hold chunk (l%4) ^ ((row >> 2) & 3)
       const int ct = u / 3, tap = u % 3;
-      for (int it = wave; it < NIT; it += RB_NW) {
+#pragma unroll
+      for (int i = 0; i < CNT; ++i) {
+        const int it = min(wave + RB_NW * i, NIT - 1);
         const int q = it / (HH / 16), g = it % (HH / 16);
         const int row = 16 * g + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
         const unsigned off = (unsigned)((((size_t)q * HH + row) * K3 + tap * CC + ct * 32 + chunk * 8) * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs3, (lds_ptr_t)(dst + q * HH * 64 + g * 1024), 16, off, 0, 0, 0);
+        dma_kib(rs3, off, __builtin_amdgcn_readfirstlane(dst + q * HH * 64 + g * 1024));
       }
     } else {
-      // W1 tile j: rows n, 16 k' = 32 B per row and plane, dense. KiB = 32 rows; lane l lands in (row 32g + l/2, half l%2)
+      // W1 tile j: rows n, 16 k' = 32 B per row and plane. KiB = 32 rows; lane l lands in (row 32g + l/2, slot l%2)
       const int j = u - NS1;
-      for (int it = wave; it < NIT; it += RB_NW) {
+#pragma unroll
+      for (int i = 0; i < CNT; ++i) {
+        const int it = min(wave + RB_NW * i, NIT - 1);
         const int q = it / (CC / 32), g = it % (CC / 32);
         const int row = 32 * g + (lane >> 1);
-        const unsigned off = (unsigned)((((size_t)q * CC + row) * HH + j * 16 + (lane & 1) * 8) * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr_t)(dst + q * CC * 32 + g * 1024), 16, off, 0, 0, 0);
+        const int half = (lane & 1) ^ ((row >> 3) & 1);        // 32-byte rows: the two halves swap places every 8 rows (dense rows read 2-way)
+        const unsigned off = (unsigned)((((size_t)q * CC + row) * HH + j * 16 + half * 8) * 2);
+        dma_kib(rs1, off, __builtin_amdgcn_readfirstlane(dst + q * CC * 32 + g * 1024));
       }
     }
   };
+  // tile u is complete when at most `younger` of this wave's vector-memory operations are still outstanding: the DMA of the tiles
+  // requested after it (CNT each) and — while they are in flight — the NEL loads of the next ELU(x) tile, which were issued behind
+  // DMA(v + 3) of their step v = 3 ct
+  auto tiles_after = [&](int u) { return min(u + RB_RING - 2, NU - 1) - u; };        // tiles u+1 .. u+RING-2 that exist (u + RING - 1 is requested after the wait)
   // ---- ELU(x) tile of channel tile ct: 130 rows (times m0 - 1 .. m0 + 128) x 32 channels; 1040 float4 over 256 threads
   constexpr int NEL = (130 * 8 + RB_TH - 1) / RB_TH;       // 5
   float4 er[NEL];
@@ -145,7 +193,15 @@ __global__ __launch_bounds__(RB_TH, 3) void resblock_split_dma_kernel(const ssrh
   bf16x8 hf[3][NJ];                                        // stage-2 A operand: ELU(H + b3) of this lane's time step, split, in k' order
 
   e_load(0);
-  dma_tile(0);
+  // b3 of the hidden channels this lane's accumulator registers hold, requested NOW: a load between the stages would make the compiler
+  // wait with vmcnt(0) there — it cannot see the DMA in flight — and drain the ring once per tile
+  float b3r[NHB][16];
+#pragma unroll
+  for (int hb = 0; hb < NHB; ++hb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b3r[hb][r] = a.b3[hb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+  for (int u0 = 0; u0 < RB_RING - 1; ++u0) dma_tile(u0);
   // ---- stage 1, transposed: acc1[hb][h][m] += W3[h][k] . E[m + tap][k]; a runtime loop over the channel tiles (a fully unrolled
   // 16-step loop was refused by the compiler and left the register arrays in scratch), the three taps of a tile unrolled
   for (int ct = 0; ct < NCT; ++ct) {
@@ -154,14 +210,16 @@ __global__ __launch_bounds__(RB_TH, 3) void resblock_split_dma_kernel(const ssrh
       const int u = ct * 3 + tap;
       if (tap == 0) {
         if (ct > 0) __syncthreads();                       // every wave has finished reading the previous channel tile
-        e_store();
+        e_store();                                         // (the compiler waits for the x loads here; it cannot see the DMA: vmcnt(0))
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile u has landed (and the x prefetch, a whole step old)
+      // x loads of the next channel tile are in flight behind DMA(3 ct + 3) during the steps of tap 1 and 2
+      // (they are YOUNGER than tile u — and count — only while u <= 3 ct + RING - 1)
+      wait_vm(CNT * tiles_after(u) + ((tap != 0 && tap <= RB_RING - 1 && ct + 1 < NCT) ? NEL : 0));
       __syncthreads();                                     // tile u (and a new ELU(x) tile) visible; everyone is done with tile u - 1
-      dma_tile(u + 1);                                     // u + 1 <= NS1: the last one is W1's first tile
+      if (u + RB_RING - 1 < NU) dma_tile(u + RB_RING - 1); // into the slot tile u - 1 has just left
       if (tap == 0 && ct + 1 < NCT) e_load(ct + 1);
       __builtin_amdgcn_sched_barrier(0);                   // keep the requests HERE, in front of the MFMA block
-      const char* Wt = Wb + (u & 1) * WT;
+      const char* Wt = Wb + (u % RB_RING) * WT;
       const int erow = 32 * wave + li + tap;
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -195,7 +253,7 @@ __global__ __launch_bounds__(RB_TH, 3) void resblock_split_dma_kernel(const ssrh
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int r = half * 8 + i;
-        v[i] = elu_r(acc1[hb][r] + a.b3[hb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh]);
+        v[i] = elu_r(acc1[hb][r] + b3r[hb][r]);
       }
       bf16x4 p0[3], p1[3];
       split4r(make_float4(v[0], v[1], v[2], v[3]), p0);
@@ -211,34 +269,36 @@ __global__ __launch_bounds__(RB_TH, 3) void resblock_split_dma_kernel(const ssrh
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int u = NS1 + j;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vm(CNT * tiles_after(u));
     __syncthreads();
-    if (j + 1 < NJ) dma_tile(u + 1);
+    if (u + RB_RING - 1 < NU) dma_tile(u + RB_RING - 1);
     __builtin_amdgcn_sched_barrier(0);
-    const char* Wt = Wb + (u & 1) * WT;
+    const char* Wt = Wb + (u % RB_RING) * WT;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int nb = 0; nb < NNB; ++nb) {                       // one output block at a time: 12 operand registers instead of 12 x NNB
       bf16x8 fb[3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) fb[q] = *reinterpret_cast<const bf16x8*>(Wt + q * CC * 32 + (nb * 32 + li) * 32 + lh * 16);
+      for (int q = 0; q < 3; ++q) fb[q] = *reinterpret_cast<const bf16x8*>(Wt + q * CC * 32 + (nb * 32 + li) * 32 + ((lh ^ ((li >> 3) & 1)) << 4));
 #pragma unroll
       for (int pq = 0; pq < 6; ++pq) acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[PA[pq]][j], fb[PB[pq]], acc2[nb], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
   }
-  // ---- epilogue: + b1 + x (raw: the centre tap's row), 128-byte runs per accumulator row
+  // ---- epilogue: + b1 + x (raw: the centre tap's row), 128-byte runs per accumulator row; tiles inside the item skip the row checks
+  const bool whole = m0 + RB_BM <= T;                      // uniform
 #pragma unroll
   for (int nb = 0; nb < NNB; ++nb) {
     const int n = nb * 32 + li;
     const float b1 = a.b1[n];
+    const size_t base = (size_t)(m0 + 32 * wave + 4 * lh) * CC + n;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m < T) {
-        float o = xin[(size_t)(m + 1) * CC + n] + (acc2[nb][r] + b1);
-        if (a.out_act == SSRHIP_ACT_ELU) o = elu_r(o);
-        yout[(size_t)m * CC + n] = o;
+      const int dm = (r & 3) + 8 * (r >> 2);
+      if (whole || m0 + 32 * wave + 4 * lh + dm < T) {
+        float o = xin[base + (size_t)(dm + 1) * CC] + (acc2[nb][r] + b1);
+        if (a.out_act == SSRHIP_ACT_ELU) o = elu1(o);        // what a consumer would compute on load (common.h): ELU-on-store stays bit-identical to ELU-on-load
+        yout[base + (size_t)dm * CC] = o;
       }
     }
   }
@@ -251,8 +311,19 @@ int ssrhip_resblock_split_launch(const ssrhip_resblock_args* a, hipStream_t s) {
   SSR_REQUIRE(a->C == 64 || a->C == 128, "ssrhip_resblock (split planes): C=%d not in {64, 128}", a->C);
   SSR_REQUIRE((size_t)(a->T + 2) * a->C * 4 < 0x7FFFFFF0ull, "ssrhip_resblock (split planes): item too long");
   dim3 grid((a->T + RB_BM - 1) / RB_BM, a->B);
-  if (a->C == 128) hipLaunchKernelGGL(resblock_split_dma_kernel<128>, grid, dim3(RB_TH), rb_lds(128), s, *a);
-  else hipLaunchKernelGGL(resblock_split_dma_kernel<64>, grid, dim3(RB_TH), rb_lds(64), s, *a);
+  // ring of 2 (one tile ahead, three workgroups per CU) measured FASTER than a ring of 4 (three ahead, two workgroups per CU): 4.76 vs 5.46 ms
+  // at 32 clips, C = 128 (profiles/r04_microbench/resblock_pmc.log): a third workgroup hides more than the deeper prefetch does
+  static const int ring = getenv("SSRHIP_RESBLOCK_RING") ? atoi(getenv("SSRHIP_RESBLOCK_RING")) : 2;      // A/B knob
+  if (ring == 2) {
+    if (a->C == 128) hipLaunchKernelGGL((resblock_split_dma_kernel<128, 2>), grid, dim3(RB_TH), rb_lds(128, 2), s, *a);
+    else hipLaunchKernelGGL((resblock_split_dma_kernel<64, 2>), grid, dim3(RB_TH), rb_lds(64, 2), s, *a);
+  } else if (a->C == 128) {
+    static ssr_once_per_device once;
+    if (once.need()) SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_split_dma_kernel<128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, rb_lds(128, 4)));
+    hipLaunchKernelGGL((resblock_split_dma_kernel<128, 4>), grid, dim3(RB_TH), rb_lds(128, 4), s, *a);
+  } else {
+    hipLaunchKernelGGL((resblock_split_dma_kernel<64, 4>), grid, dim3(RB_TH), rb_lds(64, 4), s, *a);
+  }
   SSR_LAUNCH_CHECK();
   return 0;
 }
