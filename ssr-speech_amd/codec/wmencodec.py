@@ -454,6 +454,12 @@ class WMEncodecModel:
         if nl == 2 and T > self.LSTM_CHUNK:
             main = torch.cuda.current_stream(dev)
             side = self._side_stream()
+            # every tensor the side stream touches was allocated on `main`: tell the caching allocator (a block freed while the side
+            # stream still has work queued on it must not be handed to a new allocation of `main`). The event chain below already orders
+            # every access (main waits for `fin` before anything is freed); record_stream makes that independent of who frees what when.
+            if os.environ.get("SSRHIP_NO_RECORD_STREAM", "0") in ("", "0"):        # (the knob exists for the experiment in DESIGN.md §4b)
+                for tns in gins + hbufs + cbufs + [o.data for o in outs] + [x.data]:
+                    tns.record_stream(side)
             in_gemm(0, 0, T)
             for t0 in range(0, T, self.LSTM_CHUNK):
                 t1 = min(t0 + self.LSTM_CHUNK, T)
