@@ -316,7 +316,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(const ssrhip_sam
   const int k = wave / WPC, sub = wave % WPC;
   const int K = a.K, card = a.card;
   const bool active = k < K;
-  const int rows = c.use_cfg ? 2 : 1;
+  const int rows = c.use_cfg ? 2 : 1;     // (read again below as c_usecfg: same value)
   const int row0 = u * rows;
   // snapshot of the state (every wave reads it before thread 0 mutates it, after the barriers below)
   const int num_gen = st.num_gen, num_eog = st.num_eog, cfg_tag = st.num_cfg_tag;
@@ -328,16 +328,26 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(const ssrhip_sam
   const float c_topp = c.top_p, c_temp = c.temperature, c_coef = c.cfg_coef, c_om = c.cfg_one_minus;
   const int c_maxsteps = c.max_steps, c_nsil = c.n_silence;
   const uint32_t c_seedlo = c.seed_lo, c_seedhi = c.seed_hi;
+  // everything the single-thread state machine at the end reads, fetched NOW with the other loads (round 4: it re-read these from
+  // memory one dependent load after the other — the compiler cannot keep them across the stores to `st` / `generated` — ~8 serial
+  // L1 / L2 round trips on the tail of the step's last kernel)
+  const int c_usecfg = c.use_cfg, c_stride = c.cfg_stride, c_textlen = c.text_len, c_nspans = c.n_spans;
+  const int st_audio_pos = st.audio_pos, st_span = st.span;
+  int c_sil[SSRHIP_MAX_SILENCE];
+#pragma unroll
+  for (int j = 0; j < SSRHIP_MAX_SILENCE; ++j) c_sil[j] = c.silence[j];
   STAMP(0);
 
   // ---- CFG combine (:690-696) + edits (:699-730); element e of this lane is index e*256 + sub*64 + lane
   const int kc = active ? k : 0;
   const float* lc = a.logits + ((size_t)row0 * K + kc) * card;
   const float* lu = lc + (size_t)K * card;
-  const bool guided = c.use_cfg && (cfg_tag == c.cfg_stride);
+  const bool guided = c_usecfg && (cfg_tag == c_stride);
   bool penal = false;     // silence-repetition penalty applies to logits[0][prev_token] (:726-730)
-  if (k == 0 && num_eog == 0 && c_stoprep > 0 && consec > c_stoprep)
-    for (int s = 0; s < c_nsil; ++s) penal |= (c.silence[s] == prev_token);
+  if (k == 0 && num_eog == 0 && c_stoprep > 0 && consec > c_stoprep) {
+#pragma unroll
+    for (int s = 0; s < SSRHIP_MAX_SILENCE; ++s) penal |= (s < c_nsil) && (c_sil[s] == prev_token);
+  }
   const float npen = (float)(consec - (c_stoprep - 1));
   const bool force_empty = (num_gen < K - 1) && (k > num_gen);     // :705-707
   const bool cut_eog_empty = (num_eog > 0) && (k > num_eog);       // :710-712
@@ -506,26 +516,27 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(const ssrhip_sam
   __syncthreads();
   STAMP(6);
   if (threadIdx.x == 0) {
-    // ---- state machine (:709-761), single thread
+    // ---- state machine (:709-761), single thread; reads only registers and LDS
     int s[SSRHIP_MAX_CODEBOOKS];
     for (int j = 0; j < K; ++j) s[j] = sh_sample[j];
     int ne_og = num_eog, cs = consec, pt = prev_token;
     if (num_eog > 0) {
-      for (int j = 0; j < num_eog; ++j) s[j] = c.empty_token;
-      s[num_eog] = c.eog;
+      for (int j = 0; j < num_eog; ++j) s[j] = c_empty;
+      s[num_eog] = c_eog;
       ne_og = num_eog + 1;
     } else {
-      if (s[0] == c.eog || sh_argmax0 == c.eog || (st.audio_pos + 1) > c.text_len * 10) {
-        s[0] = c.eog;
+      if (s[0] == c_eog || sh_argmax0 == c_eog || (st_audio_pos + 1) > c_textlen * 10) {
+        s[0] = c_eog;
         ne_og = 1;
       }
       bool sil = false;
-      for (int j = 0; j < c.n_silence; ++j) sil |= (c.silence[j] == s[0]);
+#pragma unroll
+      for (int j = 0; j < SSRHIP_MAX_SILENCE; ++j) sil |= (j < c_nsil) && (c_sil[j] == s[0]);
       cs = (sil && s[0] == pt) ? cs + 1 : 0;
       pt = s[0];
     }
-    if (c.use_cfg) st.num_cfg_tag = (cfg_tag == c.cfg_stride) ? 1 : cfg_tag + 1;
-    int* gen = a.generated + ((size_t)u * c.max_steps + step) * K;
+    if (c_usecfg) st.num_cfg_tag = (cfg_tag == c_stride) ? 1 : cfg_tag + 1;
+    int* gen = a.generated + ((size_t)u * c_maxsteps + step) * K;
     for (int j = 0; j < K; ++j) gen[j] = s[j];
     st.n_steps = step + 1;
     st.num_gen = num_gen + 1;
@@ -533,27 +544,31 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_kernel(const ssrhip_sam
     st.consec_silence = cs;
     st.prev_token = pt;
     bool done = false;
+    int span = st_span;
     if (ne_og == K) {                 // span finished (:753): the all-eog sample is NOT fed back
-      st.span_end[st.span] = step + 1;
-      st.span += 1;
-      if (st.span >= c.n_spans) { st.done = 1; done = true; }
+      st.span_end[span] = step + 1;
+      span += 1;
+      st.span = span;
+      if (span >= c_nspans) { st.done = 1; done = true; }
       else {
         st.num_gen = 0; st.num_eog = 0; st.num_cfg_tag = 1; st.prev_token = -1; st.consec_silence = 0;
-        for (int j = 0; j < K; ++j) s[j] = c.mts + st.span;   // next span starts from its mask token (:655)
+        for (int j = 0; j < K; ++j) s[j] = c_mts + span;   // next span starts from its mask token (:655)
       }
     }
-    if (!done && step + 1 >= c.max_steps) { st.done = 2; done = true; }
+    if (!done && step + 1 >= c_maxsteps) { st.done = 2; done = true; }
     sh_next[SSRHIP_MAX_CODEBOOKS + 1] = done ? 0 : 1;
     if (!done) {
-      st.audio_pos += 1;
-      sh_next[SSRHIP_MAX_CODEBOOKS] = st.audio_pos;
+      const int apos = st_audio_pos + 1;
+      st.audio_pos = apos;
+      sh_next[SSRHIP_MAX_CODEBOOKS] = apos;
       for (int j = 0; j < SSRHIP_MAX_CODEBOOKS; ++j) sh_next[j] = (j < K) ? s[j] : 0;
       for (int rr = 0; rr < rows; ++rr) {
         const int b = row0 + rr;
         for (int j = 0; j < SSRHIP_MAX_CODEBOOKS; ++j) a.next_tok[b * SSRHIP_MAX_CODEBOOKS + j] = (j < K) ? s[j] : 0;
-        a.next_pos[b] = st.audio_pos;
-        a.kv_pos[b] += 1;
-        a.row_len[b] = a.kv_pos[b] + 1;
+        a.next_pos[b] = apos;
+        const int kp = a.kv_pos[b] + 1;
+        a.kv_pos[b] = kp;
+        a.row_len[b] = kp + 1;
       }
     }
   }
