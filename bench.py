@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 #   2 rows : (65.93 x17 + 58.30 x33 + 17.83 x16) / 66 = 50.5 MB read + 0.05 MB written (round 3 passes; the three segment-kernel variants)
 #   16 rows: (59.30 x33 + 71.66 x16 + 18.17 x16 + 36.04) / 66 = 52.0 MB read + 0.3 MB written (x re-read through L2 by the streamed-x kernel)
 TRAFFIC_BYTES_PER_GEMV_LAUNCH = {2: 50.5e6, 16: 52.3e6}
-TRAFFIC_SOURCE = {2: "profiles/r03_pmc_fetch_size.md + profiles/r03_pmc_write_size.md (same kernels and bytes as round 2)", 16: "profiles/r02_pmc_fetch_size_16rows.md + profiles/r02_pmc_write_size_16rows.md"}
+TRAFFIC_SOURCE = {2: "profiles/r04_pmc_fetch_size.md + profiles/r04_pmc_write_size.md (50.4 MB read + 0.05 MB written per GEMV launch)", 16: "profiles/r02_pmc_fetch_size_16rows.md + profiles/r02_pmc_write_size_16rows.md"}
 
 
 def synth_inputs(args_lm, rank, L=130, N=160):
@@ -375,8 +375,8 @@ def codec256_leg(dev, world, rank, dist, all_ok=lambda ok: ok):
                 res = e_ex[b].t().clone()                              # [T, D] latent of the exact pass
                 for q in range(cfg.n_q):
                     E = sdc[f"quantizer.vq.layers.{q}._codebook.embed"].to(dev)
-                    dist = -(res.pow(2).sum(1, keepdim=True) - 2 * res @ E.t() + E.t().pow(2).sum(0, keepdim=True))
-                    top2 = dist.topk(2, dim=-1).values
+                    score = -(res.pow(2).sum(1, keepdim=True) - 2 * res @ E.t() + E.t().pow(2).sum(0, keepdim=True))
+                    top2 = score.topk(2, dim=-1).values
                     fq = first[b, q]
                     if bool(fq.any()):
                         worst = max(worst, float((top2[:, 0] - top2[:, 1])[fq].max()))
@@ -583,7 +583,7 @@ def main():
             "decode_rtf_10s": round((500 * ms_per_step / 1000) / 10.0, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r03_pmc_*.md), gfx950 x2 correction
+                         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r04_pmc_*.md), gfx950 x2 correction
                          # for wide reads applied: 50.5 MB read + 0.1 MB written per GEMV launch vs 49.85 MB algorithmic
                          "traffic": TRAFFIC_BYTES_PER_GEMV_LAUNCH.get(2 * U) if (arena.D == 2048 and arena.L == 16) else None,
                          "traffic_source": TRAFFIC_SOURCE.get(2 * U, "not measured for this row count") + " (rocprofv3 --pmc passes of this command, gfx950 x2 FETCH_SIZE correction)",
