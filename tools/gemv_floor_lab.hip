@@ -10,6 +10,8 @@
 //   mode 5  mode 4 with at most 4 units (16 loads per lane) in flight: the rest requested as the first ones are consumed
 //   mode 6  mode 4 with 2 units in flight
 //   mode 10 mode 6 at two workgroups per CU (= the segment kernel's geometry: 1 unit in flight per wave, 16 waves per CU) [uses 1 unit]
+//   mode 7 / 11  modes 5 / 10 with x fetched ONCE per workgroup (512 threads x 2 float4 = the 16 KB both rows need) into LDS and read from
+//           there by every wave, instead of every wave fetching its 8 KB slice from L2 (64 KB of L1 traffic per workgroup for 16 KB of data)
 // Build: hipcc -O3 --offload-arch=gfx950 -I ssr-speech_amd/csrc -I include tools/gemv_floor_lab.hip -o tools/bin/gemv_floor_lab
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -43,9 +45,15 @@ __global__ __launch_bounds__(TH, (MODE >= 10) ? 4 : 2) void k(const float* __res
     const int seg = wave & 1;
     const float* Wg = W + (size_t)blockIdx.x * R * K + seg * 1024 + lane * 4;
     constexpr int NUW = (MODE >= 10) ? 3 : 6;    // units per wave at N = 6144 (QKV): 48 units / 8 waves; two workgroups per CU: 24 / 8
-    constexpr int DEPTH = (MODE == 3 || MODE == 4) ? NUW : (MODE == 5 ? 4 : (MODE == 6 ? 2 : 1));
+    constexpr int DEPTH = (MODE == 3 || MODE == 4) ? NUW : ((MODE == 5 || MODE == 7) ? 4 : (MODE == 6 ? 2 : 1));
+    constexpr bool XLDS = (MODE == 7 || MODE == 11);
+    __shared__ __attribute__((aligned(16))) float xs[XLDS ? 2 * K : 4];
     float4 xr[2][4];
-    if constexpr (MODE >= 4) {
+    float4 xg[2];
+    if constexpr (XLDS) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) xg[b] = ld4(x + b * K + t * 4);         // 512 threads x 4 floats = one row of x per pass
+    } else if constexpr (MODE >= 4) {
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -56,6 +64,15 @@ __global__ __launch_bounds__(TH, (MODE >= 10) ? 4 : 2) void k(const float* __res
     for (int j = 0; j < DEPTH; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(Wg + (size_t)(min(wave + 8 * j, nu - 1) >> 1) * K + i * 256);
+    if constexpr (XLDS) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) *reinterpret_cast<float4*>(xs + b * K + t * 4) = xg[b];
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[b][i] = *reinterpret_cast<const float4*>(xs + b * K + seg * 1024 + (i * 64 + lane) * 4);
+    }
     float tot = 0.f;
 #pragma unroll
     for (int j = 0; j < NUW; ++j) {
@@ -247,7 +264,9 @@ int main() {
   printf("mode 4  + GEMV arithmetic, all 6 units upfront %6.2f\n", run<4>(W, x, y, N, 256, wstride));
   printf("mode 5  4 units in flight                     %6.2f\n", run<5>(W, x, y, N, 256, wstride));
   printf("mode 6  2 units in flight                     %6.2f\n", run<6>(W, x, y, N, 256, wstride));
+  printf("mode 7  4 units in flight, x via LDS          %6.2f\n", run<7>(W, x, y, N, 256, wstride));
   printf("mode 10 two workgroups per CU, 1 unit in flight %6.2f\n", run<10>(W, x, y, N, 512, wstride));
+  printf("mode 11 same, x via LDS                       %6.2f\n", run<11>(W, x, y, N, 512, wstride));
   printf("mode 10z same on zeros                        %6.2f\n", run<10>(Wz, x, y, N, 512, wstride));
   printf("k16 static,  1 unit in flight (16 waves/CU)    %6.2f\n", run16<false, 1>(W, x, y, N, 256, wstride));
   printf("k16 dynamic, 1 unit in flight                  %6.2f\n", run16<true, 1>(W, x, y, N, 256, wstride));
