@@ -371,6 +371,8 @@ class DecodeEngine:
         self.noise = torch.empty(n_utt, max_steps, K, arena.card, **f32)
         self._pinned = None
         self._copy_stream = None
+        self._admit_pinned = self._admit_dev = self._admit_sent = None      # one-copy staging of an admission's integer arrays
+        self._prefill_ws = None
         self._arena_gen = arena.generation
         self.dbg_logits = torch.zeros(n_utt, K, arena.card, **f32) if debug_logits else None
         self._w = arena.c_struct()
@@ -482,13 +484,42 @@ class DecodeEngine:
             self._admit_step[u] = self._steps_enqueued
             self.n_admitted += 1
         self._grow_pages(0)                      # pages for the prompts (+ the first decoded position) of the new rows
-        tok = torch.from_numpy(np.concatenate(toks)).to(dev)
-        pos = torch.from_numpy(np.concatenate(poss)).to(dev)
-        kind = torch.from_numpy(np.concatenate(kinds)).to(dev)
-        seq = torch.from_numpy(np.concatenate(seqs)).to(dev)
-        rpos = torch.from_numpy(np.concatenate(rposs)).to(dev)
-        rlen = (rpos + 1).contiguous()
-        R = tok.shape[0]
+        # Every integer array of this admission goes to the device in ONE copy: packed into a pinned staging buffer, sent asynchronously
+        # into a persistent int32 workspace, addressed by views (ten small synchronous pageable copies per admit stalled the
+        # rows that were still decoding). Layout (int32): tok[R][4] | pos[R] | kind[R] | seq[R] | rpos[R] | rlen[R] | seq_start[n+1] |
+        # next_tok[rows][4] | t0[rows] | kv0[rows] | row index[rows].
+        tok_h = np.concatenate(toks)
+        R = tok_h.shape[0]
+        nrow = len(rows_b)
+        nt_h = np.zeros((nrow, MAX_CODEBOOKS), dtype=np.int32)
+        nt_h[:, :K] = int(a.args.mts)
+        t0_h = np.asarray([int(np.asarray(audio_cols[i // rpu]).shape[1]) for i in range(nrow)], dtype=np.int32)
+        kv0_h = np.asarray(lens, dtype=np.int32)
+        starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        rpos_h = np.concatenate(rposs)
+        parts = [tok_h.reshape(-1), np.concatenate(poss), np.concatenate(kinds), np.concatenate(seqs), rpos_h, rpos_h + 1, starts,
+                 nt_h.reshape(-1), t0_h, kv0_h, np.asarray(rows_b, dtype=np.int32)]
+        total = sum(int(p_.size) for p_ in parts)
+        if self._admit_pinned is None or self._admit_pinned.numel() < total:
+            cap_n = max(total, 2 * (self._admit_pinned.numel() if self._admit_pinned is not None else 0), 4096)
+            self._admit_pinned = torch.empty(cap_n, dtype=torch.int32).pin_memory()
+            self._admit_dev = torch.empty(cap_n, dtype=torch.int32, device=dev)
+            self._admit_sent = None
+        if self._admit_sent is not None:
+            self._admit_sent.synchronize()       # the previous admission's copy has left the staging buffer (admissions are >= 16 steps apart)
+        stage_np = self._admit_pinned.numpy()
+        offs, o = [], 0
+        for p_ in parts:
+            stage_np[o:o + p_.size] = p_.astype(np.int32, copy=False).reshape(-1)
+            offs.append(o)
+            o += int(p_.size)
+        self._admit_dev[:total].copy_(self._admit_pinned[:total], non_blocking=True)
+        self._admit_sent = torch.cuda.Event()
+        self._admit_sent.record(torch.cuda.current_stream(dev))
+        view = lambda i, n: self._admit_dev[offs[i]: offs[i] + n]
+        tok, pos, kind, seq, rpos, rlen = view(0, 4 * R).view(R, MAX_CODEBOOKS), view(1, R), view(2, R), view(3, R), view(4, R), view(5, R)
+        seq_start = view(6, len(lens) + 1)
+        nt_d, t0s, kv0, rows_d = view(7, 4 * nrow).view(nrow, MAX_CODEBOOKS), view(8, nrow), view(9, nrow), view(10, nrow)
 
         # sampler configuration / state of the slots
         args = a.args
@@ -529,27 +560,30 @@ class DecodeEngine:
             self._create_ctx()
 
         # first decode input of the new rows: the span-0 mask token at audio position T0 (ssr.py:655-662)
-        idx = torch.tensor(rows_b, dtype=torch.long, device=dev)
-        nt = np.zeros((len(rows_b), MAX_CODEBOOKS), dtype=np.int32)
-        nt[:, :K] = int(args.mts)
-        t0s = torch.tensor([int(np.asarray(audio_cols[i // rpu]).shape[1]) for i in range(len(rows_b))], dtype=torch.int32, device=dev)
-        kv0 = torch.tensor(lens, dtype=torch.int32, device=dev)
-        self.next_tok.index_copy_(0, idx, torch.from_numpy(nt).to(dev))
-        self.next_pos.index_copy_(0, idx, t0s)
-        self.kv_pos.index_copy_(0, idx, kv0)
-        self.row_len.index_copy_(0, idx, kv0 + 1)
+        idx = rows_d.long() if rows_b != list(range(self.B)) else None
+        if idx is None:                          # every row (the first fill): plain copies, no index tensor
+            self.next_tok.copy_(nt_d)
+            self.next_pos.copy_(t0s)
+            self.kv_pos.copy_(kv0)
+            self.row_len.copy_(kv0 + 1)
+        else:
+            self.next_tok.index_copy_(0, idx, nt_d)
+            self.next_pos.index_copy_(0, idx, t0s)
+            self.kv_pos.index_copy_(0, idx, kv0)
+            self.row_len.index_copy_(0, idx, kv0 + 1)
 
-        # prefill workspaces
+        # prefill workspaces: kept across admissions, grown when a larger prompt arrives
         f32 = dict(dtype=torch.float32, device=dev)
         D, F, H = a.D, a.F, a.H
         ms = (max(lens) + PAGE - 1) // PAGE
-        ws = dict(x=torch.empty(R, D, **f32), xn=torch.empty(R, D, **f32), qkv=torch.empty(R, 3 * D, **f32),
-                  o=torch.empty(R, D, **f32), h=torch.empty(R, F, **f32))
+        if self._prefill_ws is None or self._prefill_ws["x"].shape[0] < R:
+            Rc = max(R, int(1.25 * (self._prefill_ws["x"].shape[0] if self._prefill_ws is not None else 0)))
+            self._prefill_ws = dict(x=torch.empty(Rc, D, **f32), xn=torch.empty(Rc, D, **f32), qkv=torch.empty(Rc, 3 * D, **f32),
+                                    o=torch.empty(Rc, D, **f32), h=torch.empty(Rc, F, **f32))
+        ws = dict(self._prefill_ws)
         if os.environ.get("SSRHIP_PREFILL_ATTN_ROWWISE", "0") not in ("", "0"):      # A/B knob: the round-1 per-row attention needs its partials
             ws.update(part_o=torch.empty(R * H * ms * self.hd, **f32), part_ml=torch.empty(R * H * ms * 2, **f32))
-        # rows of one sequence are contiguous and in position order: the tiled prefill attention needs only where each starts
-        starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-        seq_start = torch.from_numpy(starts).to(dev)
+        # rows of one sequence are contiguous and in position order: the tiled prefill attention needs only where each starts (seq_start above)
         p = _lib.PrefillArgs()
         p.tok, p.pos, p.kind = tok.data_ptr(), pos.data_ptr(), kind.data_ptr()
         p.row_seq, p.row_pos, p.row_len = seq.data_ptr(), rpos.data_ptr(), rlen.data_ptr()
@@ -560,7 +594,7 @@ class DecodeEngine:
         # (the prefill ends by embedding the pending input token of EVERY row into x: for rows in mid-decode that re-writes the
         # very values the sampler's fused embedding left there — same function, same inputs)
         _lib.check(self.lib.ssrhip_lm_prefill(self._ctx, C.byref(p), _lib.stream_ptr()), "ssrhip_lm_prefill")
-        self._keep = (tok, pos, kind, seq, rpos, rlen, ws, seq_start, idx, t0s, kv0)   # alive until the stream has consumed them
+        self._keep = (ws, idx)                   # alive until the stream has consumed them (the integer arrays live in the engine's workspace)
         return R
 
     # ------------------------------------------------------------------ KV page bookkeeping
