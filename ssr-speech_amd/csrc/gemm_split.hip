@@ -333,6 +333,40 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   const int n = n0 + wn * 32 + li;
   if (n >= N) return;
   const float bias = a.bias ? a.bias[n] : 0.f;
+  // Whole tiles without a time mask or class bias, with at most ONE operand added behind the activation (C itself or R: a residual block's
+  // second convolution): its 16 values per accumulator block are requested together and the 16 stores follow together. The general loop
+  // below (load -> add -> store per element under a row predicate) compiles to one dependent HBM round trip per output — 32 per lane, the
+  // reason `60000 x 256 x 128 + R` ran at 56 TFLOP/s next to 185 for its neighbours (profiles/r04_codec_b256_kernel_trace_summary.md;
+  // found with tools/resblock_lab.hip on the residual-block kernel, which had the same epilogue). Same arithmetic per element.
+  if (m0 + BM <= M && a.tm_c <= 0 && !a.rbias && !(a.residual && a.R) && a.ldc < (1 << 24) && a.ldr < (1 << 24)) {      // uniform
+    const float* ap = a.residual ? a.C : a.R;
+    const unsigned ald = (unsigned)(a.residual ? a.ldc : a.ldr), cld = (unsigned)a.ldc;
+    const bool elu_out = a.act_out == SSRHIP_ACT_ELU;
+    const int nu = n0 + wn * 32;
+    auto blocks = [&](const int act) __attribute__((always_inline)) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int mu = m0 + (wm * MT + mt) * 32;
+        float av[16];
+        if (ap) {
+          const float* src = ap + ((size_t)mu * ald + nu);                                                               // wave-uniform base
+#pragma unroll
+          for (int r = 0; r < 16; ++r) av[r] = src[(unsigned)((r & 3) + 8 * (r >> 2) + 4 * lh) * ald + (unsigned)li];
+        }
+        float* dst = a.C + ((size_t)mu * cld + nu);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = act_fn(acc[mt][r] + bias, act);
+          if (ap) v += av[r];
+          if (elu_out) v = elu1(v);
+          dst[(unsigned)((r & 3) + 8 * (r >> 2) + 4 * lh) * cld + (unsigned)li] = v;
+        }
+      }
+    };
+    if (a.act == SSRHIP_ACT_NONE) blocks(SSRHIP_ACT_NONE);             // the codec's case: no per-element dispatch
+    else blocks(a.act);
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll

@@ -94,7 +94,14 @@ __device__ __forceinline__ void wait_vm(int n) {
   }
 }
 
-template <int CC, int RB_RING>
+// Cost attribution hooks for tools/resblock_lab.hip (KO = 0 in the product: every `if constexpr` below folds away): knock one component
+// out and time the rest, or (RB_PROF) leave 100 MHz timestamps of wave 0's phases in LDS and dump them for a sample of the workgroups.
+enum { RB_KO_WAIT = 1, RB_KO_ESTORE = 2, RB_KO_RESID = 4, RB_KO_MFMA = 8, RB_KO_DMA = 16, RB_KO_ELOAD = 32, RB_KO_STORE = 64, RB_PROF = 128 };
+constexpr int RB_NSTAMP = 64;
+constexpr int RB_RDEPTH = 1;                             // residual blocks (16 registers each) requested ahead of the one being stored
+__device__ unsigned* g_rb_prof = nullptr;                 // [sampled workgroup][RB_NSTAMP]
+
+template <int CC, int RB_RING, int KO = 0>
 __global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrhip_resblock_args a) {
   constexpr int HH = CC / 2, NHB = HH / 32, NCT = CC / 32, NNB = CC / 32, NJ = HH / 16;
   constexpr int NS1 = NCT * 3;                             // weight tiles: NS1 of W3 (channel tile, tap), then NJ of W1
@@ -106,6 +113,13 @@ __global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrh
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* const Es = lds;                                    // [3][RB_ER][64 B]
   char* const Wb = lds + 3 * RB_EP;                        // [RB_RING][WT]
+  unsigned* const stamps = reinterpret_cast<unsigned*>(lds + rb_lds(CC, RB_RING));      // RB_PROF only (the lab adds the bytes)
+  auto stamp = [&](int i) {
+    if constexpr ((KO & RB_PROF) != 0) {
+      if (threadIdx.x == 0) stamps[i] = (unsigned)wall_clock64();
+    }
+  };
+  stamp(0);
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int T = a.T, m0 = blockIdx.x * RB_BM;
@@ -127,6 +141,7 @@ __global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrh
 
   // ---- weight tile u -> ring slot u % RB_RING by DMA (a wave-level instruction = one lane-linear KiB; CNT per wave and tile)
   auto dma_tile = [&](int u) {
+    if constexpr ((KO & RB_KO_DMA) != 0) return;
     const unsigned dst = wb_addr + (unsigned)(u % RB_RING) * WT;
     if (u < NS1) {
       // W3 tile (channel tile ct, tap): rows h, 32 k = 64 B per row and plane. KiB = 16 rows; lane l lands in (row 16g + l/4, slot l%4),
@@ -167,10 +182,12 @@ __global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrh
       const int idx = min(t + RB_TH * i, 130 * 8 - 1);      // the surplus threads of the last pass repeat the last piece (same value, same slot)
       const int row = idx >> 3, c4 = idx & 7;
       const int prow = min(m0 + row, T + 1);               // padded row; tiles that run past the item: clamped (those outputs are not stored)
-      er[i] = ld4(xin + (size_t)prow * CC + ct * 32 + c4 * 4);
+      if constexpr ((KO & RB_KO_ELOAD) != 0) er[i] = make_float4(a.T * 1e-9f, 0.1f, -0.2f, 0.3f);
+      else er[i] = ld4(xin + (size_t)prow * CC + ct * 32 + c4 * 4);
     }
   };
   auto e_store = [&]() {
+    if constexpr ((KO & RB_KO_ESTORE) != 0) return;
 #pragma unroll
     for (int i = 0; i < NEL; ++i) {
       const int idx = min(t + RB_TH * i, 130 * 8 - 1);
@@ -214,8 +231,10 @@ __global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrh
       }
       // x loads of the next channel tile are in flight behind DMA(3 ct + 3) during the steps of tap 1 and 2
       // (they are YOUNGER than tile u — and count — only while u <= 3 ct + RING - 1)
-      wait_vm(CNT * tiles_after(u) + ((tap != 0 && tap <= RB_RING - 1 && ct + 1 < NCT) ? NEL : 0));
+      if (tap == 0) stamp(40 + ct);
+      if constexpr ((KO & (RB_KO_WAIT | RB_KO_DMA)) == 0) wait_vm(CNT * tiles_after(u) + ((tap != 0 && tap <= RB_RING - 1 && ct + 1 < NCT) ? NEL : 0));
       __syncthreads();                                     // tile u (and a new ELU(x) tile) visible; everyone is done with tile u - 1
+      stamp(2 + 2 * u);
       if (u + RB_RING - 1 < NU) dma_tile(u + RB_RING - 1); // into the slot tile u - 1 has just left
       if (tap == 0 && ct + 1 < NCT) e_load(ct + 1);
       __builtin_amdgcn_sched_barrier(0);                   // keep the requests HERE, in front of the MFMA block
@@ -238,9 +257,11 @@ __global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrh
 #pragma unroll
         for (int pq = 0; pq < 6; ++pq)
 #pragma unroll
-          for (int hb = 0; hb < NHB; ++hb) acc1[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pq]][hb], fb[PB[pq]], acc1[hb], 0, 0, 0);
+          for (int hb = 0; hb < NHB; ++hb)
+            if constexpr ((KO & RB_KO_MFMA) == 0) acc1[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pq]][hb], fb[PB[pq]], acc1[hb], 0, 0, 0);
       }
       __builtin_amdgcn_s_setprio(0);
+      stamp(3 + 2 * u);
     }
   }
   // ---- between the stages, in registers: accumulator register r of block hb = hidden channel hb*32 + (r&3) + 8(r>>2) + 4lh of time
@@ -265,13 +286,37 @@ __global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrh
   for (int nb = 0; nb < NNB; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+  // ---- the residual: x at the accumulator's own (time step, channel) positions, 16 values per lane and output block. Requested two
+  // blocks ahead of their use and ALL 16 at once: the first form of this epilogue (load -> add -> store per output, under a per-row
+  // predicate) compiled to 64 dependent HBM round trips per lane, 30 of the workgroup's 49 us (tools/resblock_lab.hip,
+  // profiles/r04_microbench/resblock_lab.log). Rows past the end of the item are clamped (their outputs are not stored).
+  const bool whole = m0 + RB_BM <= T;                      // uniform; the one ragged tile of an item takes the plain loop at the end
+  const int mrow = m0 + 32 * wave + 4 * lh;
+  const unsigned lane_el = (unsigned)(4 * lh * CC + li);   // lane part of the element index; the rest is wave-uniform (scalar base + immediate)
+  auto res_load = [&](int nb, float (&xr)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float* src = xin + ((size_t)(m0 + 32 * wave + 8 * g + 1) * CC + nb * 32);      // + 1: the centre tap's row
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr ((KO & RB_KO_RESID) != 0) xr[4 * g + i] = 0.25f;
+        else xr[4 * g + i] = src[lane_el + (unsigned)(i * CC)];
+      }
+    }
+  };
+  float xr[2][16];
   // ---- stage 2: acc2[nb][m][n] += H[m][k'] . W1[n][k'] for the 16 hidden channels of step j (unrolled: hf[.][j] stays in registers)
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int u = NS1 + j;
-    wait_vm(CNT * tiles_after(u));
+    if constexpr ((KO & (RB_KO_WAIT | RB_KO_DMA)) == 0) wait_vm(CNT * tiles_after(u));
     __syncthreads();
+    stamp(2 + 2 * u);
     if (u + RB_RING - 1 < NU) dma_tile(u + RB_RING - 1);
+    if (j == NJ - 1 && whole) {                              // behind the last DMA wait: from here on the compiler's own vmcnt bookkeeping is complete
+      res_load(0, xr[0]);
+      if constexpr (RB_RDEPTH > 1) res_load(1, xr[1]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     const char* Wt = Wb + (u % RB_RING) * WT;
     __builtin_amdgcn_s_setprio(1);
@@ -281,25 +326,58 @@ __global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrh
 #pragma unroll
       for (int q = 0; q < 3; ++q) fb[q] = *reinterpret_cast<const bf16x8*>(Wt + q * CC * 32 + (nb * 32 + li) * 32 + ((lh ^ ((li >> 3) & 1)) << 4));
 #pragma unroll
-      for (int pq = 0; pq < 6; ++pq) acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[PA[pq]][j], fb[PB[pq]], acc2[nb], 0, 0, 0);
+      for (int pq = 0; pq < 6; ++pq)
+        if constexpr ((KO & RB_KO_MFMA) == 0) acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf[PA[pq]][j], fb[PB[pq]], acc2[nb], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
+    stamp(3 + 2 * u);
   }
-  // ---- epilogue: + b1 + x (raw: the centre tap's row), 128-byte runs per accumulator row; tiles inside the item skip the row checks
-  const bool whole = m0 + RB_BM <= T;                      // uniform
+  // ---- epilogue: + b1 + x, 128-byte runs per accumulator row; the loads of the next block(s) go out before this one is stored
+  float b1r[NNB];
 #pragma unroll
-  for (int nb = 0; nb < NNB; ++nb) {
-    const int n = nb * 32 + li;
-    const float b1 = a.b1[n];
-    const size_t base = (size_t)(m0 + 32 * wave + 4 * lh) * CC + n;
+  for (int nb = 0; nb < NNB; ++nb) b1r[nb] = a.b1[nb * 32 + li];
+  const bool act = a.out_act == SSRHIP_ACT_ELU;
+  if (whole) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dm = (r & 3) + 8 * (r >> 2);
-      if (whole || m0 + 32 * wave + 4 * lh + dm < T) {
-        float o = xin[base + (size_t)(dm + 1) * CC] + (acc2[nb][r] + b1);
-        if (a.out_act == SSRHIP_ACT_ELU) o = elu1(o);        // what a consumer would compute on load (common.h): ELU-on-store stays bit-identical to ELU-on-load
-        yout[base + (size_t)dm * CC] = o;
+    for (int nb = 0; nb < NNB; ++nb) {
+      if constexpr (RB_RDEPTH == 1) { if (nb + 1 < NNB) res_load(nb + 1, xr[(nb + 1) & 1]); }
+      float o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = xr[nb & 1][r] + (acc2[nb][r] + b1r[nb]);
+        o[r] = act ? elu1(v) : v;                            // what a consumer would compute on load (common.h): ELU-on-store stays bit-identical to ELU-on-load
       }
+      if constexpr (RB_RDEPTH > 1) { if (nb + 2 < NNB) res_load(nb + 2, xr[nb & 1]); }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float* dst = yout + ((size_t)(m0 + 32 * wave + 8 * g) * CC + nb * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if ((KO & RB_KO_STORE) == 0 || o[4 * g + i] == 1.2345e-33f) dst[lane_el + (unsigned)(i * CC)] = o[4 * g + i];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) {
+      const size_t base = (size_t)mrow * CC + nb * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dm = (r & 3) + 8 * (r >> 2);
+        if (mrow + dm < T) {
+          float o = xin[base + (size_t)(dm + 1) * CC] + (acc2[nb][r] + b1r[nb]);
+          if (a.out_act == SSRHIP_ACT_ELU) o = elu1(o);
+          yout[base + (size_t)dm * CC] = o;
+        }
+      }
+    }
+  }
+  if constexpr ((KO & RB_PROF) != 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(2 + 2 * NU);
+    __syncthreads();
+    if (blockIdx.x % 61 == 7 && blockIdx.y % 8 == 3 && threadIdx.x < RB_NSTAMP) {
+      const int slot = (blockIdx.y / 8) * ((gridDim.x + 53) / 61) + blockIdx.x / 61;
+      g_rb_prof[(size_t)slot * RB_NSTAMP + threadIdx.x] = stamps[threadIdx.x];
     }
   }
 }
