@@ -222,7 +222,7 @@ constexpr int dma_lds(int bm) { return 3 * bm * 64 + 6 * DMA_PLANE; }  // A 3 pl
 // BM = 128: waves 2 x 4 of 64 x 32; BM = 64 (grids that 128-row tiles would not fill, half-empty tiles): waves 2 x 4 of 32 x 32. Same
 // arithmetic per output element in both (and in the 4-wave kernels above).
 template <int BM, bool ELU>
-__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_split_dma_kernel(const ssrhip_gemm_args a0) {
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_split_dma_kernel(const ssrhip_gemm_args a0, const int wide) {
   constexpr int MT = BM / 64, LA = BM / 64, APL = BM * 64;           // accumulators per wave, A loader passes, bytes per A plane
   extern __shared__ __attribute__((aligned(1024))) char ldsb[];
   char* const As = ldsb;                                             // [3][BM][64 B]
@@ -330,6 +330,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     stage ^= 1;
   }
   // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  if (wide) {                                                        // the 16-byte epilogue below turns blocks through the tiles' LDS:
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the last step's W DMA (zeros past K) has landed,
+    __syncthreads();                                                 // and every wave has read its last tile
+  }
   const int n = n0 + wn * 32 + li;
   if (n >= N) return;
   const float bias = a.bias ? a.bias[n] : 0.f;
@@ -343,6 +347,46 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const unsigned ald = (unsigned)(a.residual ? a.ldc : a.ldr), cld = (unsigned)a.ldc;
     const bool elu_out = a.act_out == SSRHIP_ACT_ELU;
     const int nu = n0 + wn * 32;
+    // 16-byte form (default; SSRHIP_EPILOGUE_WIDE=0 = the dword form below): an accumulator block (lane = one column, 16 rows) goes through
+    // a wave-private 4 KB of LDS and comes back as rows — lane l holds columns 4 (l % 8) .. + 3 of rows l / 8 + 8 p — so that the added
+    // operand is read and C is written as dwordx4, 128-byte row pieces per 8 lanes: 4 + 4 vector-memory instructions per block instead of
+    // 16 + 16 (the stores of a dword epilogue are issue-bound, MI355X_MICROARCH.md `epilogue store tail`). Same arithmetic per element.
+    if (wide && n0 + wn * 32 + 32 <= N && ((ald | cld) & 3u) == 0 && (((uintptr_t)a.C | (uintptr_t)ap) & 15) == 0) {
+      float* const tr = reinterpret_cast<float*>(ldsb) + wave * 1024;
+      const int trow = lane >> 3, tc4 = (lane & 7) * 4;
+      auto wblocks = [&](const int act) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int mu = m0 + (wm * MT + mt) * 32;
+          float4 av[4];
+          if (ap) {
+            const float* src = ap + ((size_t)mu * ald + nu);                                                             // wave-uniform base
+#pragma unroll
+            for (int p = 0; p < 4; ++p) av[p] = *reinterpret_cast<const float4*>(src + (unsigned)(trow + 8 * p) * ald + (unsigned)tc4);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = act_fn(acc[mt][r] + bias, act);
+          __builtin_amdgcn_wave_barrier();                           // a wave's own LDS accesses complete in order; this pins the compiler's order
+          float4 o[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            o[p] = *reinterpret_cast<const float4*>(tr + (trow + 8 * p) * 32 + tc4);
+            if (ap) o[p] = make_float4(o[p].x + av[p].x, o[p].y + av[p].y, o[p].z + av[p].z, o[p].w + av[p].w);
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (elu_out) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) o[p] = make_float4(elu1(o[p].x), elu1(o[p].y), elu1(o[p].z), elu1(o[p].w));
+          }
+          float* dst = a.C + ((size_t)mu * cld + nu);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(dst + (unsigned)(trow + 8 * p) * cld + (unsigned)tc4) = o[p];
+        }
+      };
+      if (a.act == SSRHIP_ACT_NONE) wblocks(SSRHIP_ACT_NONE);
+      else wblocks(a.act);
+      return;
+    }
     auto blocks = [&](const int act) __attribute__((always_inline)) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -416,6 +460,7 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
   // the DMA kernels address a tile through 32-bit buffer offsets: 128 rows of A (and of a W plane) have to stay below 2 GiB
   static const bool dma_off = getenv("SSRHIP_GEMM_SPLIT_DMA") && getenv("SSRHIP_GEMM_SPLIT_DMA")[0] == '0';   // A/B knob: the 4-wave kernels
   const bool dma = !dma_off && ((size_t)127 * a->lda + a->K) * 4 < 0x7FFFFFF0ull && (size_t)128 * a->K * 2 < 0x7FFFFFF0ull;
+  static const int wide = !(getenv("SSRHIP_EPILOGUE_WIDE") && getenv("SSRHIP_EPILOGUE_WIDE")[0] == '0');      // A/B knob: 0 = dword epilogue
   if (dma) {
     static ssr_once_per_device once;
     if (once.need()) {
@@ -429,16 +474,16 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 127) / 128, (unsigned)nb);
     ssr_gemm_log(a, grid.x, grid.y, grid.z, 1);
     if (dma) {
-      if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<128, true>), grid, dim3(512), dma_lds(128), s, *a);
-      else hipLaunchKernelGGL((gemm_split_dma_kernel<128, false>), grid, dim3(512), dma_lds(128), s, *a);
+      if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<128, true>), grid, dim3(512), dma_lds(128), s, *a, wide);
+      else hipLaunchKernelGGL((gemm_split_dma_kernel<128, false>), grid, dim3(512), dma_lds(128), s, *a, wide);
     } else if (elu) hipLaunchKernelGGL((gemm_split_kernel<128, true>), grid, dim3(256), 0, s, *a);
     else hipLaunchKernelGGL((gemm_split_kernel<128, false>), grid, dim3(256), 0, s, *a);
   } else {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 63) / 64, (unsigned)nb);
     ssr_gemm_log(a, grid.x, grid.y, grid.z, 1);
     if (dma) {
-      if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<64, true>), grid, dim3(512), dma_lds(64), s, *a);
-      else hipLaunchKernelGGL((gemm_split_dma_kernel<64, false>), grid, dim3(512), dma_lds(64), s, *a);
+      if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<64, true>), grid, dim3(512), dma_lds(64), s, *a, wide);
+      else hipLaunchKernelGGL((gemm_split_dma_kernel<64, false>), grid, dim3(512), dma_lds(64), s, *a, wide);
     } else if (elu) hipLaunchKernelGGL((gemm_split_kernel<64, true>), grid, dim3(256), 0, s, *a);
     else hipLaunchKernelGGL((gemm_split_kernel<64, false>), grid, dim3(256), 0, s, *a);
   }

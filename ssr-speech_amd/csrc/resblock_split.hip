@@ -102,7 +102,7 @@ constexpr int RB_RDEPTH = 1;                             // residual blocks (16 
 __device__ unsigned* g_rb_prof = nullptr;                 // [sampled workgroup][RB_NSTAMP]
 
 template <int CC, int RB_RING, int KO = 0>
-__global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrhip_resblock_args a) {
+__global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrhip_resblock_args a, const int wide) {
   constexpr int HH = CC / 2, NHB = HH / 32, NCT = CC / 32, NNB = CC / 32, NJ = HH / 16;
   constexpr int NS1 = NCT * 3;                             // weight tiles: NS1 of W3 (channel tile, tap), then NJ of W1
   constexpr int WT = rb_wtile(CC), NIT = 3 * HH / 16;      // DMA instructions per tile (1 KiB each): 3 planes x HH/16 (= 3 x CC/32)
@@ -292,11 +292,28 @@ __global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrh
   // profiles/r04_microbench/resblock_lab.log). Rows past the end of the item are clamped (their outputs are not stored).
   const bool whole = m0 + RB_BM <= T;                      // uniform; the one ragged tile of an item takes the plain loop at the end
   const int mrow = m0 + 32 * wave + 4 * lh;
-  const unsigned lane_el = (unsigned)(4 * lh * CC + li);   // lane part of the element index; the rest is wave-uniform (scalar base + immediate)
+  // The epilogue works on 16-byte pieces: an accumulator block (lane = one channel, 16 time steps) is turned through a wave-private
+  // 4 KB of the (by then dead) ELU(x) tile into rows — lane l holds channels 4 (l % 8) .. + 3 of time steps l / 8 + 8 p, p = 0..3 — so
+  // that the residual comes in and the result goes out as dwordx4 (128-byte row pieces per 8 lanes, the x tile's own pattern) instead
+  // of 16 + 16 dword instructions per block (store-issue-bound: the guide's `attention epilogue store tail` row). 32-dword rows are
+  // conflict-free for both the ds_write_b32 (32 lanes = one row) and the ds_read_b128 lane groups.
+  const int trow = lane >> 3, tc4 = lane & 7;
+  const unsigned lane_el4 = (unsigned)(trow * CC + tc4 * 4);   // lane part of the element index; the rest is wave-uniform (scalar base + immediate)
+  auto res_load4 = [&](int nb, float4 (&xr)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float* src = xin + ((size_t)(m0 + 32 * wave + 8 * p + 1) * CC + nb * 32);      // + 1: the centre tap's row
+      if constexpr ((KO & RB_KO_RESID) != 0) xr[p] = make_float4(0.25f, 0.25f, 0.25f, 0.25f);
+      else xr[p] = ld4(src + lane_el4);
+    }
+  };
+  float4 xr4[2][4];
+  // the dword form (SSRHIP_EPILOGUE_WIDE=0): the accumulator's own positions, 16 values per lane and block
+  const unsigned lane_el = (unsigned)(4 * lh * CC + li);
   auto res_load = [&](int nb, float (&xr)[16]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float* src = xin + ((size_t)(m0 + 32 * wave + 8 * g + 1) * CC + nb * 32);      // + 1: the centre tap's row
+      const float* src = xin + ((size_t)(m0 + 32 * wave + 8 * g + 1) * CC + nb * 32);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if constexpr ((KO & RB_KO_RESID) != 0) xr[4 * g + i] = 0.25f;
@@ -314,8 +331,13 @@ __global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrh
     stamp(2 + 2 * u);
     if (u + RB_RING - 1 < NU) dma_tile(u + RB_RING - 1);
     if (j == NJ - 1 && whole) {                              // behind the last DMA wait: from here on the compiler's own vmcnt bookkeeping is complete
-      res_load(0, xr[0]);
-      if constexpr (RB_RDEPTH > 1) res_load(1, xr[1]);
+      if (wide) {
+        res_load4(0, xr4[0]);
+        if constexpr (RB_RDEPTH > 1) res_load4(1, xr4[1]);
+      } else {
+        res_load(0, xr[0]);
+        if constexpr (RB_RDEPTH > 1) res_load(1, xr[1]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     const char* Wt = Wb + (u % RB_RING) * WT;
@@ -337,7 +359,34 @@ __global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrh
 #pragma unroll
   for (int nb = 0; nb < NNB; ++nb) b1r[nb] = a.b1[nb * 32 + li];
   const bool act = a.out_act == SSRHIP_ACT_ELU;
-  if (whole) {
+  if (whole && wide) {
+    float* const tr = reinterpret_cast<float*>(Es) + wave * (32 * 32);
+#pragma unroll
+    for (int nb = 0; nb < NNB; ++nb) {
+      if constexpr (RB_RDEPTH == 1) { if (nb + 1 < NNB) res_load4(nb + 1, xr4[(nb + 1) & 1]); }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc2[nb][r] + b1r[nb];
+      __builtin_amdgcn_wave_barrier();                       // the wave's own LDS accesses complete in order; this keeps the compiler from moving them
+      float4 o[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float4 v = *reinterpret_cast<const float4*>(tr + (trow + 8 * p) * 32 + tc4 * 4);
+        const float4 x4 = xr4[nb & 1][p];
+        o[p] = make_float4(x4.x + v.x, x4.y + v.y, x4.z + v.z, x4.w + v.w);
+      }
+      if (act) {                                             // what a consumer would compute on load (common.h): ELU-on-store stays bit-identical to ELU-on-load
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o[p] = make_float4(elu1(o[p].x), elu1(o[p].y), elu1(o[p].z), elu1(o[p].w));
+      }
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (RB_RDEPTH > 1) { if (nb + 2 < NNB) res_load4(nb + 2, xr4[nb & 1]); }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float* dst = yout + ((size_t)(m0 + 32 * wave + 8 * p) * CC + nb * 32);
+        if ((KO & RB_KO_STORE) == 0 || o[p].x == 1.2345e-33f) *reinterpret_cast<float4*>(dst + lane_el4) = o[p];
+      }
+    }
+  } else if (whole) {
 #pragma unroll
     for (int nb = 0; nb < NNB; ++nb) {
       if constexpr (RB_RDEPTH == 1) { if (nb + 1 < NNB) res_load(nb + 1, xr[(nb + 1) & 1]); }
@@ -345,7 +394,7 @@ __global__ __launch_bounds__(RB_TH, 2) void resblock_split_dma_kernel(const ssrh
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = xr[nb & 1][r] + (acc2[nb][r] + b1r[nb]);
-        o[r] = act ? elu1(v) : v;                            // what a consumer would compute on load (common.h): ELU-on-store stays bit-identical to ELU-on-load
+        o[r] = act ? elu1(v) : v;
       }
       if constexpr (RB_RDEPTH > 1) { if (nb + 2 < NNB) res_load(nb + 2, xr[nb & 1]); }
 #pragma unroll
@@ -392,15 +441,19 @@ int ssrhip_resblock_split_launch(const ssrhip_resblock_args* a, hipStream_t s) {
   // ring of 2 (one tile ahead, three workgroups per CU) measured FASTER than a ring of 4 (three ahead, two workgroups per CU): 4.76 vs 5.46 ms
   // at 32 clips, C = 128 (profiles/r04_microbench/resblock_pmc.log): a third workgroup hides more than the deeper prefetch does
   static const int ring = getenv("SSRHIP_RESBLOCK_RING") ? atoi(getenv("SSRHIP_RESBLOCK_RING")) : 2;      // A/B knob
+  // the 16-byte epilogue (accumulator blocks turned through LDS) measured 1-3 % SLOWER here than the dword form (3.29 vs 3.21 ms at C = 128,
+  // 2.33 vs 2.29 at C = 64, 32 clips, alternating runs, bit-identical outputs: profiles/r04_microbench/resblock_lab_ab.log) — unlike in the GEMM,
+  // whose default it is; kept behind the same knob for A/B runs
+  static const int wide = getenv("SSRHIP_EPILOGUE_WIDE") ? getenv("SSRHIP_EPILOGUE_WIDE")[0] != '0' : 0;
   if (ring == 2) {
-    if (a->C == 128) hipLaunchKernelGGL((resblock_split_dma_kernel<128, 2>), grid, dim3(RB_TH), rb_lds(128, 2), s, *a);
-    else hipLaunchKernelGGL((resblock_split_dma_kernel<64, 2>), grid, dim3(RB_TH), rb_lds(64, 2), s, *a);
+    if (a->C == 128) hipLaunchKernelGGL((resblock_split_dma_kernel<128, 2>), grid, dim3(RB_TH), rb_lds(128, 2), s, *a, wide);
+    else hipLaunchKernelGGL((resblock_split_dma_kernel<64, 2>), grid, dim3(RB_TH), rb_lds(64, 2), s, *a, wide);
   } else if (a->C == 128) {
     static ssr_once_per_device once;
     if (once.need()) SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_split_dma_kernel<128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, rb_lds(128, 4)));
-    hipLaunchKernelGGL((resblock_split_dma_kernel<128, 4>), grid, dim3(RB_TH), rb_lds(128, 4), s, *a);
+    hipLaunchKernelGGL((resblock_split_dma_kernel<128, 4>), grid, dim3(RB_TH), rb_lds(128, 4), s, *a, wide);
   } else {
-    hipLaunchKernelGGL((resblock_split_dma_kernel<64, 4>), grid, dim3(RB_TH), rb_lds(64, 4), s, *a);
+    hipLaunchKernelGGL((resblock_split_dma_kernel<64, 4>), grid, dim3(RB_TH), rb_lds(64, 4), s, *a, wide);
   }
   SSR_LAUNCH_CHECK();
   return 0;

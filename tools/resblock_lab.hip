@@ -23,22 +23,28 @@ void ssrhip_set_error(const char* fmt, ...) {
 static unsigned lcg(unsigned& s) { s = s * 1664525u + 1013904223u; return s; }
 
 template <int CC, int RING, int KO>
-static float run(const ssrhip_resblock_args& a, int reps) {
+static float run(const ssrhip_resblock_args& a, int reps, int wide = 1) {
   const int lds = rb_lds(CC, RING) + ((KO & RB_PROF) ? RB_NSTAMP * 4 : 0);
   auto kern = resblock_split_dma_kernel<CC, RING, KO>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   dim3 grid((a.T + RB_BM - 1) / RB_BM, a.B);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(kern, grid, dim3(RB_TH), lds, 0, a);      // warm
+  hipLaunchKernelGGL(kern, grid, dim3(RB_TH), lds, 0, a, wide);      // warm
   CK(hipEventRecord(e0, 0));
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, grid, dim3(RB_TH), lds, 0, a);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, grid, dim3(RB_TH), lds, 0, a, wide);
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   CK(hipGetLastError());
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
   return ms / reps;
+}
+
+__global__ void count_diff(const unsigned* a, const unsigned* b, size_t n, unsigned long long* out) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += a[i] != b[i];
+  if (c) atomicAdd(out, c);
 }
 
 template <int CC>
@@ -67,8 +73,15 @@ static void lab(int B, int T, int reps) {
   a.w3_split = w3s; a.w1_split = w1s;
   const double gb = (nx + ny) * 4 / 1e9;
   printf("== C = %d, B = %d, T = %d: %.2f GB in + out once, %d x %d workgroups\n", CC, B, T, gb, (T + RB_BM - 1) / RB_BM, B);
-  const float base = run<CC, 2, 0>(a, reps);
-  printf("  %-44s %8.3f ms   (%.2f TB/s of in + out once)\n", "shipped kernel (ring 2)", base, gb / base);
+  run<CC, 2, 0>(a, reps);                                   // settle clocks and the allocator's pages before anything is compared
+  float base = 0.f, dw = 0.f;
+  for (int k = 0; k < 3; ++k) {                              // alternate the two epilogue forms: order effects cancel
+    const float tw = run<CC, 2, 0>(a, reps, 1), td = run<CC, 2, 0>(a, reps, 0);
+    printf("  round %d: 16-byte epilogue %8.3f ms, dword epilogue %8.3f ms\n", k, tw, td);
+    base += tw / 3; dw += td / 3;
+  }
+  printf("  %-44s %8.3f ms   (%.2f TB/s of in + out once)\n", "shipped kernel (ring 2, 16-byte epilogue)", base, gb / base);
+  printf("  %-44s %8.3f ms   %+7.3f\n", "dword epilogue (SSRHIP_EPILOGUE_WIDE=0)", dw, dw - base);
 #define KOLINE(ko, what) { const float t_ = run<CC, 2, ko>(a, reps); printf("  %-44s %8.3f ms   %+7.3f\n", what, t_, t_ - base); }
   KOLINE(RB_KO_WAIT, "without the DMA waits");
   KOLINE(RB_KO_DMA, "without the weight DMA (and its waits)");
@@ -80,6 +93,19 @@ static void lab(int B, int T, int reps) {
   KOLINE(RB_KO_RESID | RB_KO_STORE | RB_KO_ELOAD, "without any HBM traffic");
   KOLINE(RB_KO_MFMA | RB_KO_ESTORE, "memory only (no MFMA, no tile build)");
   KOLINE(RB_KO_RESID | RB_KO_STORE | RB_KO_ELOAD | RB_KO_DMA | RB_KO_ESTORE, "MFMAs + LDS reads + barriers only");
+  {   // the two epilogue forms do the same arithmetic per element: their outputs have to be bit-identical
+    float* y2;
+    unsigned long long *d, h = 0;
+    CK(hipMalloc(&y2, ny * 4)); CK(hipMalloc(&d, 8)); CK(hipMemset(d, 0, 8));
+    run<CC, 2, 0>(a, 1, 1);
+    ssrhip_resblock_args a2 = a;
+    a2.y = y2;
+    run<CC, 2, 0>(a2, 1, 0);
+    hipLaunchKernelGGL(count_diff, dim3(4096), dim3(256), 0, 0, (const unsigned*)y, (const unsigned*)y2, ny, d);
+    CK(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost));
+    printf("  16-byte vs dword epilogue: %llu of %zu outputs differ\n", h, ny);
+    CK(hipFree(y2)); CK(hipFree(d));
+  }
   // timestamps
   const int gx = (T + RB_BM - 1) / RB_BM, nsx = (gx + 53) / 61, nslot = ((B + 7) / 8) * nsx;
   unsigned* prof;
