@@ -165,3 +165,62 @@ def test_split_gemm_drains_its_dma_before_the_tile_barrier(tmp_path_factory):
         bars = [m.start() for m in re.finditer(r"s_barrier", head)]
         assert len(bars) >= 2, sym
         assert "s_waitcnt vmcnt(0)" in head[bars[0]:bars[1]], sym
+
+
+def _serialized_loads(body):
+    """loads that are waited for (`vmcnt(0)`) within four instructions of their issue = dependent memory round trips (tools/isa_scan.py)"""
+    n, last = 0, -99
+    lines = [ln.strip() for ln in body.split("\n")]
+    lines = [t for t in lines if t and not t.startswith(";") and not t.startswith(".")]
+    for i, t in enumerate(lines):
+        if (t.startswith("global_load") or t.startswith("buffer_load")) and " lds" not in t:
+            last = i
+        elif t.startswith("s_waitcnt") and "vmcnt(0)" in t and i - last <= 4:
+            n, last = n + 1, -99
+    return n
+
+
+def _whole_body(asm, symbol):
+    """the kernel's whole text (a kernel with several exits has several s_endpgm: `_body` stops at the first)"""
+    start = asm.index("\n" + symbol + ":")
+    return asm[start:asm.index(".Lfunc_end", start)]
+
+
+def _longest_run(body, prefix):
+    """most `prefix` instructions issued with no `s_waitcnt vmcnt` and no branch between them"""
+    best = run = 0
+    for ln in body.split("\n"):
+        t = ln.strip()
+        if t.startswith(prefix + " "):
+            run += 1
+            best = max(best, run)
+        elif t.startswith("s_waitcnt") and "vmcnt" in t or t.startswith("s_cbranch"):
+            run = 0
+    return best
+
+
+def test_codec_epilogues_request_the_added_operand_a_block_at_a_time(tmp_path_factory):
+    """The residual-block kernel and the split DMA GEMM add an operand behind the accumulators (x, or R of a residual block's second
+    convolution). Written as `load -> add -> store` per output under a row predicate this compiles to ONE dependent HBM round trip per
+    output — 64 per lane, 30 of a workgroup's 49 us in the residual block, found late in round 4 with tools/resblock_lab.hip. The whole-tile
+    paths must issue a block's loads together (16 dword loads, or 4 dwordx4 in the 16-byte form); the only serialized loads left are
+    those of the general / ragged-tile loops (one per output there: the count is exact, so a regression of the fast paths shows)."""
+    asm = _asm(tmp_path_factory, "resblock_split")
+    syms = [k for k in _kernel_meta(asm) if "resblock_split_dma_kernel" in k]
+    assert len(syms) == 4, syms
+    for sym in syms:
+        body = _whole_body(asm, sym)
+        per_lane = 64 if "ILi128E" in sym else 32
+        assert _longest_run(body, "global_load_dword") >= 16, sym                 # dword form: a block's 16 residual values at once
+        assert _longest_run(body, "global_load_dwordx4") >= 4, sym                # 16-byte form (and the x tile loads)
+        assert _serialized_loads(body) == per_lane, (sym, _serialized_loads(body))   # the ragged last tile's plain loop, nothing else
+    asm = _asm(tmp_path_factory, "gemm_split")
+    syms = [k for k in _kernel_meta(asm) if "gemm_split_dma_kernel" in k]
+    assert len(syms) == 4, syms
+    for sym in syms:
+        body = _whole_body(asm, sym)
+        mt = 2 if "ILi128E" in sym else 1
+        assert _longest_run(body, "global_load_dword") >= 16, sym
+        assert body.count("global_store_dwordx4 ") >= 4 * mt, sym                  # the 16-byte form's stores
+        # general loop: up to 4 loads per output (C, R, class id -> class bias), 16 outputs per block; + a handful in the prologue
+        assert _serialized_loads(body) <= 4 * 16 * mt + 4, (sym, _serialized_loads(body))
