@@ -221,12 +221,39 @@ constexpr int dma_lds(int bm) { return 3 * bm * 64 + 6 * DMA_PLANE; }  // A 3 pl
 
 // BM = 128: waves 2 x 4 of 64 x 32; BM = 64 (grids that 128-row tiles would not fill, half-empty tiles): waves 2 x 4 of 32 x 32. Same
 // arithmetic per output element in both (and in the 4-wave kernels above).
-template <int BM, bool ELU>
+// Cost attribution hooks for tools/gemm_dma_lab.hip (KO = 0 in the library: every `if constexpr` below folds away): knock one component out and
+// time the rest, or (GD_PROF) leave 100 MHz time stamps of wave 0's first k-steps in LDS and dump them for a sample of the workgroups.
+enum { GD_KO_MFMA = 1, GD_KO_ALOAD = 2, GD_KO_ASTORE = 4, GD_KO_DMA = 8, GD_KO_STORE = 16, GD_PROF = 32 };
+constexpr int GD_NSTAMP = 128, GD_STEPS = 40;              // stamps 3 s + {0, 1, 2} of step s < GD_STEPS: loop top, tile ready, MFMA block issued; 124 / 125: entry / end
+__device__ unsigned* g_gd_prof = nullptr;                  // [sampled workgroup][GD_NSTAMP]
+
+template <int BM, bool ELU, int KO = 0>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_split_dma_kernel(const ssrhip_gemm_args a0, const int wide) {
   constexpr int MT = BM / 64, LA = BM / 64, APL = BM * 64;           // accumulators per wave, A loader passes, bytes per A plane
   extern __shared__ __attribute__((aligned(1024))) char ldsb[];
   char* const As = ldsb;                                             // [3][BM][64 B]
   char* const Wsb = ldsb + 3 * APL;                                  // [2][3][128][64 B]
+  unsigned* const stamps = reinterpret_cast<unsigned*>(ldsb + dma_lds(BM));   // GD_PROF only (the lab adds the bytes)
+  auto stamp = [&](int i) {
+    if constexpr ((KO & GD_PROF) != 0) {
+      if (threadIdx.x == 0 && i < GD_NSTAMP) stamps[i] = (unsigned)wall_clock64();
+    }
+  };
+  stamp(124);
+  // lab only (GD_PROF): at every exit of the kernel — N a multiple of 128 in the lab, so no lane leaves early — wave 0 marks the end of
+  // its epilogue and a sample of the workgroups copies the stamps out
+  struct Dump {
+    unsigned* st;
+    __device__ ~Dump() {
+      if constexpr ((KO & GD_PROF) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) st[125] = (unsigned)wall_clock64();
+        __syncthreads();
+        if (blockIdx.x == 0 && blockIdx.y % 37 == 5 && blockIdx.z % 8 == 3 && threadIdx.x < GD_NSTAMP)
+          g_gd_prof[((size_t)(blockIdx.z / 8) * ((gridDim.y + 31) / 37) + blockIdx.y / 37) * GD_NSTAMP + threadIdx.x] = st[threadIdx.x];
+      }
+    }
+  } dump{stamps};
   ssrhip_gemm_args a = a0;
   {   // batched problems: grid.z
     const size_t z = blockIdx.z;
@@ -269,9 +296,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   auto gload_a = [&](int k0) {
     const bool kin = (k0 + lc) < K;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, kin ? offA[i] + (unsigned)k0 * 4 : OOB, 0, 0));
+    for (int i = 0; i < LA; ++i) {
+      if constexpr ((KO & GD_KO_ALOAD) != 0) ra[i] = make_float4(a.M * 1e-9f, 0.25f, -0.5f, 0.125f);
+      else ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, kin ? offA[i] + (unsigned)k0 * 4 : OOB, 0, 0));
+    }
   };
   auto dma_w = [&](int k0, int stage) {
+    if constexpr ((KO & GD_KO_DMA) != 0) return;
     const bool kin = (k0 + wchunk * 8) < K;                          // K % 8 == 0 (checked by the host)
     const unsigned off = kin ? offW + (unsigned)k0 * 2 : OOB;
 #pragma unroll
@@ -280,6 +311,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   };
   const int aswz = (((lc >> 3) ^ ((lr >> 2) & 3)) << 4) + ((lc >> 2) & 1) * 8;   // rows lr and lr + 64 share (row >> 2) & 3
   auto store_a = [&]() {
+    if constexpr ((KO & GD_KO_ASTORE) != 0) return;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       float4 v = ra[i];
@@ -307,7 +339,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
       for (int pq = 0; pq < 6; ++pq)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pq]][i], fb[PB[pq]], acc[i], 0, 0, 0);
+        for (int i = 0; i < MT; ++i)
+          if constexpr ((KO & GD_KO_MFMA) == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pq]][i], fb[PB[pq]], acc[i], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -315,6 +348,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   dma_w(0, 0);
   int stage = 0;
   for (int k0 = 0; k0 < K; k0 += BK) {
+    if constexpr ((KO & GD_PROF) != 0) { if (k0 < GD_STEPS * BK) stamp(3 * (k0 / BK)); }
     __syncthreads();                                                 // the previous tile is consumed (the A stage, W stage ^ 1)
     store_a();
     // W(k0) was written into LDS by OTHER waves' DMA: every wave drains its own DMA before the barrier publishes the tile. hipcc happens to
@@ -323,12 +357,15 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     // guarded in tests/test_isa_guards.py. Free: the wait is already there.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                 // A(k0) stored, W(k0) landed
+    if constexpr ((KO & GD_PROF) != 0) { if (k0 < GD_STEPS * BK) stamp(3 * (k0 / BK) + 1); }
     gload_a(k0 + BK);                                                // past K: zeros, never used
     dma_w(k0 + BK, stage ^ 1);
     __builtin_amdgcn_sched_barrier(0);                               // keep the loads HERE
     mma_tile(stage);
+    if constexpr ((KO & GD_PROF) != 0) { if (k0 < GD_STEPS * BK) stamp(3 * (k0 / BK) + 2); }
     stage ^= 1;
   }
+  stamp(123);
   // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   if (wide) {                                                        // the 16-byte epilogue below turns blocks through the tiles' LDS:
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the last step's W DMA (zeros past K) has landed,
@@ -380,7 +417,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
           }
           float* dst = a.C + ((size_t)mu * cld + nu);
 #pragma unroll
-          for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(dst + (unsigned)(trow + 8 * p) * cld + (unsigned)tc4) = o[p];
+          for (int p = 0; p < 4; ++p)
+            if ((KO & GD_KO_STORE) == 0 || o[p].x == 1.2345e-33f) *reinterpret_cast<float4*>(dst + (unsigned)(trow + 8 * p) * cld + (unsigned)tc4) = o[p];
         }
       };
       if (a.act == SSRHIP_ACT_NONE) wblocks(SSRHIP_ACT_NONE);

@@ -1,0 +1,6 @@
+# round 5, first GPU session: the two labs on the shipped codec kernels (built in-tree: tools/bin travels with the snapshot)
+#   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I ssr-speech_amd/csrc -I include tools/gemm_dma_lab.hip -o tools/bin/gemm_dma_lab
+#   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I ssr-speech_amd/csrc -I include tools/resblock_lab.hip -o tools/bin/resblock_lab
+O=gpurun_out/r5a; mkdir -p $O
+timeout 150 tools/bin/gemm_dma_lab 32 3 > $O/gemm_dma_lab.log 2>&1; cat $O/gemm_dma_lab.log
+timeout 60 tools/bin/resblock_lab 32 5 > $O/resblock_lab.log 2>&1; grep -v "tile \|ELU(x)" $O/resblock_lab.log
