@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSRHIP_VERSION 101
+#define SSRHIP_VERSION 102
 #define SSRHIP_PAGE 128          /* KV-cache page = 128 positions */
 #define SSRHIP_MAX_CODEBOOKS 4
 #define SSRHIP_MAX_SILENCE 8
@@ -298,6 +298,13 @@ typedef struct ssrhip_lstm_args {
    * hidden unit 4j + r / 4), so that one wave-level load is one contiguous KiB instead of 64 pieces of 16 rows */
   int32_t w_packed;
   int32_t out_act;   /* SSRHIP_ACT_ELU: out = ELU(h_t (+ skip)) (the layer's only consumer is `ELU -> conv`: seanet.py:147-150, 226-236) */
+  /* optional (both or none; used when C % 128 == 0 and B >= 32): the recurrent product on the bf16 matrix cores with exactly split fp32
+   * operands (csrc/lstm_split.hip), both operands in MFMA fragment order — KS = C/64 k-steps of 16 per wave, a block = 64 lanes x 8 bf16:
+   *   w_split [C/16][4][KS][2][3][64][8]: lane l (li = l % 32, lh = l / 32), element e of block (ub, w, s, mb, q) = piece q
+   *            (ssrhip_split_weights) of w_hh[g C + 16 ub + u][w C/4 + 16 s + 8 lh + e] with 32 mb + li = 16 g + u;
+   *   hsplit  workspace, 2 x ceil(B/64) x 64 x C x 3 bf16 (two buffers by step parity): h_t in the same order, written and zeroed by
+   *            the library. `hbuf` is not used on this path (it still has to be a valid pointer). */
+  const uint16_t* w_split; uint16_t* hsplit;
 } ssrhip_lstm_args;
 int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stream);
 /* residual vector quantisation (quantization/core_vq.py:164-179, 382-400): emb [B][T][D] time-major;

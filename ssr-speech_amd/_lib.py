@@ -100,7 +100,8 @@ class LstmArgs(C.Structure):
                 ("hbuf", C.c_void_p), ("cbuf", C.c_void_p), ("gates", C.c_void_p),
                 ("B", C.c_int32), ("T", C.c_int32), ("C", C.c_int32),
                 ("gin_bstride", C.c_int64), ("out_bstride", C.c_int64), ("skip_bstride", C.c_int64),
-                ("t_begin", C.c_int32), ("t_end", C.c_int32), ("w_packed", C.c_int32), ("out_act", C.c_int32)]
+                ("t_begin", C.c_int32), ("t_end", C.c_int32), ("w_packed", C.c_int32), ("out_act", C.c_int32),
+                ("w_split", C.c_void_p), ("hsplit", C.c_void_p)]
 
 
 _PP = C.POINTER(C.c_void_p)

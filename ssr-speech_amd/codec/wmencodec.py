@@ -127,6 +127,20 @@ class _ConvTr:
         self.trim_l = pt - self.trim_r
 
 
+def pack_lstm_whh_planes(planes: torch.Tensor) -> torch.Tensor:
+    """bf16 planes [3][4C][C] of a recurrent matrix (`ssrhip_split_weights` of `weight_hh`, torch's gate order i f g o) -> the fragment
+    order `csrc/lstm_split.hip` streams them in (include/ssrhip.h ssrhip_lstm_args.w_split):
+        out[ub][w][s][mb][q][lh][li][e] = planes[q][g C + 16 ub + u][w C/4 + 16 s + 8 lh + e]      with 32 mb + li = 16 g + u,
+    ub = unit block (C/16), w = wave = K quarter, s = k-step of 16 inside the quarter (C/64 of them), lane = 32 lh + li. Needs C % 64 == 0."""
+    q3, rows, Cc = planes.shape
+    assert q3 == 3 and rows == 4 * Cc and Cc % 64 == 0, planes.shape
+    ks = Cc // 64
+    x = planes.reshape(3, 4, Cc // 16, 16, 4, ks, 2, 8)           # q, g, ub, u, w, s, lh, e
+    x = x.permute(2, 4, 5, 1, 3, 0, 6, 7)                         # ub, w, s, g, u, q, lh, e
+    x = x.reshape(Cc // 16, 4, ks, 2, 32, 3, 2, 8)                # (g, u) -> m = 16 g + u = 32 mb + li
+    return x.permute(0, 1, 2, 3, 5, 6, 4, 7).contiguous()         # ub, w, s, mb, q, lh, li, e
+
+
 class _Lstm:
     def __init__(self, sd, pfx, layers, dev):
         self.layers = []
@@ -143,6 +157,7 @@ class _Lstm:
                 self.packed.append(whh.view(4, Cc // 4, 4, Cc // 16, 4, 4).permute(1, 3, 4, 2, 0, 5).contiguous())
             else:
                 self.packed.append(None)
+        self.split = [None] * layers     # W_hh planes in MFMA fragment order (csrc/lstm_split.hip), made by CodecModel._prepare_planes when enabled
 
 
 class _SeaNet:
@@ -190,6 +205,9 @@ class WMEncodecModel:
         self.fuse_resblock = True            # tests switch it off to compare with the two-GEMM path
         self.force_few_out = False           # tests: take the few-output-channel kernel also for short inputs
         self.lstm_packed = os.environ.get("SSRHIP_LSTM_PACKED", "1") != "0"      # A/B knob for the packed recurrent matrix
+        # the recurrence on the bf16 matrix cores with split operands (csrc/lstm_split.hip): written at the end of round 4 without GPU
+        # minutes left — OFF until it has passed the codec fixtures on hardware
+        self.lstm_split = os.environ.get("SSRHIP_LSTM_SPLIT", "0") not in ("", "0")
         # channel counts whose residual block runs as one kernel (env knob for A/B runs: e.g. SSRHIP_RESBLOCK_FUSE=64,128,256,512).
         # Measured at 32 clips x 30 s (encode / decode ms): {64}: 86.9 / 88.8; {64,128}: 86.4 / 87.7 and 1.9 GB less memory;
         # adding 256 or 512 (short time axes, wide weights): 88.3 / 89.1-90.5 — the chained kernel's LDS footprint leaves one
@@ -254,8 +272,10 @@ class WMEncodecModel:
                     if obj[0].Cin in self.fuse_channels:
                         self._resblock_planes(obj[0], obj[1])
                 elif kind == "lstm":
-                    for wih, _, _ in obj.layers:
+                    for l, (wih, whh, _) in enumerate(obj.layers):
                         self._planes(wih)
+                        if self.lstm_split and obj.C % 128 == 0 and obj.split[l] is None:
+                            obj.split[l] = pack_lstm_whh_planes(self._split_planes(whh))
         if self.has_wm:
             for Wa, _ in self.wm_cls:
                 self._planes(Wa)
@@ -278,6 +298,12 @@ class WMEncodecModel:
             _lib.check(self.lib.ssrhip_split_weights(W.data_ptr(), hit.data_ptr(), W.numel(), self._s()), "ssrhip_split_weights")
             self._plane_cache[key] = hit
         return hit
+
+    def _split_planes(self, W: torch.Tensor) -> torch.Tensor:
+        """bf16 planes [3][N][K] of any fp32 matrix (uncached: for callers that repack them, e.g. pack_lstm_whh_planes)"""
+        out = torch.empty(3, W.shape[0], W.shape[1], dtype=torch.int16, device=W.device)
+        _lib.check(self.lib.ssrhip_split_weights(W.data_ptr(), out.data_ptr(), W.numel(), self._s()), "ssrhip_split_weights")
+        return out
 
     def _resblock_planes(self, c3, c1):
         """bf16 planes of a residual block's two matrices for csrc/resblock_split.hip (C in {64, 128}): W3 [C/2][3C] as it is, W1 [C][C/2]
@@ -430,6 +456,9 @@ class WMEncodecModel:
         hbufs = [torch.empty(2, rows, Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
         cbufs = [torch.empty(B, Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
         outs = [self._alloc_for(B, T, Cc, nxt, x.lens) if l == nl - 1 else TM(B, T, Cc, 0, 0, dev) for l in range(nl)]
+        # h of the split-operand path: two buffers of bf16 planes in fragment order (zeroed by the library at t = 0)
+        hsplits = [torch.empty(2 * ((B + 63) // 64) * 64 * Cc * 3, dtype=torch.int16, device=dev) if (self.lstm_split and L.split[l] is not None) else None
+                   for l in range(nl)]
 
         def in_gemm(l, t0, t1):                                        # gin_l[:, t0:t1] = in_l[:, t0:t1] W_ih^T + b
             src_ptr, src_bs = (x.interior, x.bstride) if l == 0 else (outs[l - 1].interior, outs[l - 1].bstride)
@@ -443,6 +472,8 @@ class WMEncodecModel:
             use_packed = (not small_b) and L.packed[l] is not None and self.lstm_packed
             a.gin, a.w_hh, a.out = gins[l].data_ptr(), (L.packed[l] if use_packed else L.layers[l][1]).data_ptr(), outs[l].interior
             a.w_packed = int(use_packed)
+            if self.lstm_split and (not small_b) and L.split[l] is not None and B >= 32:      # ssrhip_lstm_split_eligible
+                a.w_split, a.hsplit = L.split[l].data_ptr(), hsplits[l].data_ptr()
             a.skip = x.interior if l == nl - 1 else 0                   # y = lstm(x) + x (lstm.py:21-23)
             a.hbuf, a.cbuf, a.gates = hbufs[l].data_ptr(), cbufs[l].data_ptr(), 0
             a.B, a.T, a.C = B, T, Cc
@@ -458,7 +489,7 @@ class WMEncodecModel:
             # stream still has work queued on it must not be handed to a new allocation of `main`). The event chain below already orders
             # every access (main waits for `fin` before anything is freed); record_stream makes that independent of who frees what when.
             if os.environ.get("SSRHIP_NO_RECORD_STREAM", "0") in ("", "0"):        # (the knob exists for the experiment in DESIGN.md §4b)
-                for tns in gins + hbufs + cbufs + [o.data for o in outs] + [x.data]:
+                for tns in gins + hbufs + cbufs + [o.data for o in outs] + [x.data] + [h for h in hsplits if h is not None]:
                     tns.record_stream(side)
             in_gemm(0, 0, T)
             for t0 in range(0, T, self.LSTM_CHUNK):
@@ -480,7 +511,7 @@ class WMEncodecModel:
         out = outs[-1]
         out.elu = post_elu
         self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
-        self._keep[torch.cuda.current_stream(dev).cuda_stream] = (gins, hbufs, cbufs, outs)
+        self._keep[torch.cuda.current_stream(dev).cuda_stream] = (gins, hbufs, cbufs, outs, hsplits)
         return out
 
     def _side_stream(self):

@@ -648,6 +648,9 @@ extern "C" int ssrhip_pad_ragged(float* buf, const int32_t* lens, int32_t B, int
   return 0;
 }
 
+bool ssrhip_lstm_split_eligible(const ssrhip_lstm_args* a);                             // lstm_split.hip
+int ssrhip_lstm_split_steps(const ssrhip_lstm_args* a, int t_lo, int t_hi, hipStream_t s);
+
 extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->gin && a->w_hh && a->out && a->hbuf && a->cbuf, "ssrhip_lstm_layer: null argument");
   SSR_REQUIRE(a->B > 0 && a->T > 0 && a->C > 0 && a->C % 16 == 0 && a->C <= 4096, "ssrhip_lstm_layer: need C %% 16 == 0, C <= 4096");
@@ -657,6 +660,8 @@ extern "C" int ssrhip_lstm_layer(const ssrhip_lstm_args* a, ssrhip_stream_t stre
   const size_t hc = small_b ? (size_t)a->B * a->C : (size_t)nbt * 16 * a->C;
   const int t_lo = a->t_begin, t_hi = a->t_end > 0 ? a->t_end : a->T;
   SSR_REQUIRE(t_lo >= 0 && t_lo < t_hi && t_hi <= a->T, "ssrhip_lstm_layer: bad time window [%d, %d) of %d", t_lo, t_hi, a->T);
+  SSR_REQUIRE(!a->w_split == !a->hsplit, "ssrhip_lstm_layer: w_split and hsplit go together");
+  if (!small_b && ssrhip_lstm_split_eligible(a)) return ssrhip_lstm_split_steps(a, t_lo, t_hi, s);   // bf16 matrix cores, split operands
   if (t_lo == 0) hipLaunchKernelGGL(zero_kernel, dim3(nblocks(2 * hc)), dim3(256), 0, s, a->hbuf, (long)(2 * hc));   // h_0 = 0
   {
     // small-batch kernel: C in {256, 512, 1024, 2048}; anything else (e.g. the narrow test configs) takes the matrix-core

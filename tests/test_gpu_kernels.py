@@ -1051,3 +1051,57 @@ def test_resblock_split_dma_kernel_matches_fp64(L, Cc, T, out_act):
     torch.testing.assert_close(outs[0], outs[1], rtol=2e-5, atol=2e-5)
     a.w3_split, a.w1_split = p3.data_ptr(), 0
     assert L.ssrhip_resblock(C.byref(a), _lib.stream_ptr()) != 0                           # the two plane pointers come together
+
+
+@pytest.mark.parametrize("B,Cc,T", [(70, 128, 6), (64, 256, 4), (33, 1024, 3)])
+@pytest.mark.parametrize("skip,out_act", [(False, 0), (True, _lib.ACT_ELU)])
+def test_lstm_split_step_matches_fp64(L, B, Cc, T, skip, out_act):
+    """csrc/lstm_split.hip (LSTM recurrence on the bf16 matrix cores, both operands exactly split, streamed in MFMA fragment order; opt-in
+    SSRHIP_LSTM_SPLIT=1) through `ssrhip_lstm_layer` with `w_split` / `hsplit`, in two time windows (the chunked two-stream pipeline's
+    calling pattern), against an fp64 evaluation of torch.nn.LSTM's cell (gates i f g o; modules/lstm.py:10-25) — and against the fp32
+    matrix-pipe kernel the same call takes without the planes. A batch that does not fill its last 64-row group, three widths
+    (C / 64 = 2, 4, 16 k-steps per wave: both prefetch depths), skip + ELU-on-store epilogue. Error no larger than the fp32 path's."""
+    from ssr_speech_amd.codec.wmencodec import pack_lstm_whh_planes
+    g = torch.Generator().manual_seed(B + Cc + T + int(skip))
+    whh = torch.randn(4 * Cc, Cc, generator=g) / math.sqrt(Cc)
+    gin = torch.randn(B, T, 4 * Cc, generator=g)
+    xs = torch.randn(B, T, Cc, generator=g)
+    h, c = torch.zeros(B, Cc, dtype=torch.float64), torch.zeros(B, Cc, dtype=torch.float64)
+    want = []
+    for t in range(T):
+        gt = gin[:, t].double() + h @ whh.double().t()
+        i, f, gg, o = gt[:, :Cc], gt[:, Cc:2 * Cc], gt[:, 2 * Cc:3 * Cc], gt[:, 3 * Cc:]
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        y = h + xs[:, t].double() if skip else h
+        want.append(F.elu(y) if out_act else y)
+    want = torch.stack(want, 1)
+    dw, dgin, dxs = dev(whh), dev(gin), dev(xs)
+    packed_fp32 = dev(whh.view(4, Cc // 4, 4, Cc // 16, 4, 4).permute(1, 3, 4, 2, 0, 5).contiguous())        # ssrhip_lstm_args.w_packed
+    planes = torch.empty(3, 4 * Cc, Cc, dtype=torch.int16, device="cuda")
+    _lib.check(L.ssrhip_split_weights(dw.data_ptr(), planes.data_ptr(), dw.numel(), _lib.stream_ptr()))
+    wsplit = pack_lstm_whh_planes(planes)
+    rows = (B + 15) // 16 * 16
+    outs = []
+    for split in (True, False):
+        out = torch.full((B, T, Cc), float("nan"), device="cuda")
+        hbuf, cbuf = torch.zeros(2, rows, Cc, device="cuda"), torch.zeros(B, Cc, device="cuda")
+        hs = torch.full((2 * ((B + 63) // 64) * 64 * Cc * 3,), 0x7FC0, dtype=torch.int16, device="cuda")     # NaNs: the library has to zero it at t = 0
+        for t0, t1 in ((0, T // 2), (T // 2, T)):
+            a = _lib.LstmArgs()
+            a.gin, a.w_hh, a.out = dgin.data_ptr(), packed_fp32.data_ptr(), out.data_ptr()
+            a.w_packed = 1
+            a.skip = dxs.data_ptr() if skip else 0
+            a.hbuf, a.cbuf, a.gates = hbuf.data_ptr(), cbuf.data_ptr(), 0
+            a.B, a.T, a.C = B, T, Cc
+            a.gin_bstride, a.out_bstride, a.skip_bstride = T * 4 * Cc, T * Cc, T * Cc
+            a.t_begin, a.t_end, a.out_act = t0, t1, out_act
+            if split:
+                a.w_split, a.hsplit = wsplit.data_ptr(), hs.data_ptr()
+            _lib.check(L.ssrhip_lstm_layer(C.byref(a), _lib.stream_ptr()))
+        sync()
+        outs.append(out.cpu())
+        torch.testing.assert_close(out.cpu().double(), want, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(outs[0], outs[1], rtol=2e-5, atol=2e-5)
+    a.w_split, a.hsplit = wsplit.data_ptr(), 0
+    assert L.ssrhip_lstm_layer(C.byref(a), _lib.stream_ptr()) != 0                                          # the two pointers come together

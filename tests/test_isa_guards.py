@@ -224,3 +224,21 @@ def test_codec_epilogues_request_the_added_operand_a_block_at_a_time(tmp_path_fa
         assert body.count("global_store_dwordx4 ") >= 4 * mt, sym                  # the 16-byte form's stores
         # general loop: up to 4 loads per output (C, R, class id -> class bias), 16 outputs per block; + a handful in the prologue
         assert _serialized_loads(body) <= 4 * 16 * mt + 4, (sym, _serialized_loads(body))
+
+
+def test_split_lstm_step_keeps_its_prefetch_distance(tmp_path_factory):
+    """lstm_step_split_kernel (csrc/lstm_split.hip, opt-in): one wave per SIMD streams both MFMA operands from L2 with nobody to hide a
+    round trip behind, so the refills must stay DEPTH - 1 MFMA blocks ahead: no scratch, the bf16 matrix instruction, and no `vmcnt(0)`
+    inside the k-loop (what a branch around the refill produced in the first version: every iteration drained the whole ring)."""
+    asm = _asm(tmp_path_factory, "lstm_split")
+    meta = {k: v for k, v in _kernel_meta(asm).items() if "lstm_step_split_kernel" in k}
+    assert len(meta) == 2, sorted(meta)
+    for sym, (vgpr, scratch) in meta.items():
+        assert scratch == 0 and vgpr <= 512, (sym, vgpr, scratch)
+        body = _whole_body(asm, sym)
+        lo = body.index("=>This Inner Loop Header")
+        loop = body[lo:body.index("s_barrier", lo)]
+        last_back = loop.rindex("s_cbranch")                        # the loop's back edge
+        loop = loop[:last_back]
+        assert loop.count("v_mfma_f32_32x32x16_bf16") >= 48, sym
+        assert "vmcnt(0)" not in loop, sym
