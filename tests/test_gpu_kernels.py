@@ -1053,6 +1053,9 @@ def test_resblock_split_dma_kernel_matches_fp64(L, Cc, T, out_act):
     assert L.ssrhip_resblock(C.byref(a), _lib.stream_ptr()) != 0                           # the two plane pointers come together
 
 
+@pytest.mark.skipif(os.environ.get("SSRHIP_RUN_UNVALIDATED", "0") in ("", "0"),
+                    reason="csrc/lstm_split.hip was written after round 4's GPU minutes were spent and has never run: SSRHIP_RUN_UNVALIDATED=1 "
+                           "runs this test (tools/r05_labs.sh does); the skip goes away with the kernel's first green run")
 @pytest.mark.parametrize("B,Cc,T", [(70, 128, 6), (64, 256, 4), (33, 1024, 3)])
 @pytest.mark.parametrize("skip,out_act", [(False, 0), (True, _lib.ACT_ELU)])
 def test_lstm_split_step_matches_fp64(L, B, Cc, T, skip, out_act):
