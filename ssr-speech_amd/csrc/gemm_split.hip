@@ -227,7 +227,11 @@ enum { GD_KO_MFMA = 1, GD_KO_ALOAD = 2, GD_KO_ASTORE = 4, GD_KO_DMA = 8, GD_KO_S
 constexpr int GD_NSTAMP = 128, GD_STEPS = 40;              // stamps 3 s + {0, 1, 2} of step s < GD_STEPS: loop top, tile ready, MFMA block issued; 124 / 125: entry / end
 __device__ unsigned* g_gd_prof = nullptr;                  // [sampled workgroup][GD_NSTAMP]
 
-template <int BM, bool ELU, int KO = 0>
+// TMF (opt-in instantiation, SSRHIP_EPILOGUE_TM=1; written without GPU minutes left, never run): whole tiles of a TRANSPOSED convolution's
+// GEMM — time mask tm_c > 0 with N % tm_c == 0 and tm_c % 4 == 0, nothing added behind the activation (the launcher checks) — take the
+// 16-byte epilogue with the mask as a per-row predicate: element (m, n) belongs to time row (m N + n) / tm_c = m (N / tm_c) + n / tm_c, the
+// second term one 32-bit division per LANE. The general loop those launches take today pays a 64-bit division per OUTPUT (32 per lane).
+template <int BM, bool ELU, int KO = 0, bool TMF = false>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_split_dma_kernel(const ssrhip_gemm_args a0, const int wide) {
   constexpr int MT = BM / 64, LA = BM / 64, APL = BM * 64;           // accumulators per wave, A loader passes, bytes per A plane
   extern __shared__ __attribute__((aligned(1024))) char ldsb[];
@@ -374,6 +378,38 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   const int n = n0 + wn * 32 + li;
   if (n >= N) return;
   const float bias = a.bias ? a.bias[n] : 0.f;
+  if constexpr (TMF) {
+    if (m0 + BM <= M && n0 + wn * 32 + 32 <= N) {                    // uniform per wave; ragged tiles fall through to the general loop
+      float* const tr = reinterpret_cast<float*>(ldsb) + wave * 1024;
+      const int trow = lane >> 3, tc4 = (lane & 7) * 4, nu = n0 + wn * 32;
+      const unsigned cld = (unsigned)a.ldc;
+      const int ratio = N / a.tm_c, nq = (nu + tc4) / a.tm_c;        // the four columns of a lane share n / tm_c (tm_c % 4 == 0)
+      const bool elu_out = a.act_out == SSRHIP_ACT_ELU;
+      const int act = a.act;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int mu = m0 + (wm * MT + mt) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = act_fn(acc[mt][r] + bias, act);
+        __builtin_amdgcn_wave_barrier();
+        float4 o[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o[p] = *reinterpret_cast<const float4*>(tr + (trow + 8 * p) * 32 + tc4);
+        __builtin_amdgcn_wave_barrier();
+        if (elu_out) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) o[p] = make_float4(elu1(o[p].x), elu1(o[p].y), elu1(o[p].z), elu1(o[p].w));
+        }
+        float* dst = a.C + ((size_t)mu * cld + nu);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const long u = (long)(mu + trow + 8 * p) * ratio + nq;
+          if (u >= a.tm_lo && u < a.tm_hi) *reinterpret_cast<float4*>(dst + (unsigned)(trow + 8 * p) * cld + (unsigned)tc4) = o[p];
+        }
+      }
+      return;
+    }
+  }
   // Whole tiles without a time mask or class bias, with at most ONE operand added behind the activation (C itself or R: a residual block's
   // second convolution): its 16 values per accumulator block are requested together and the 16 stores follow together. The general loop
   // below (load -> add -> store per element under a row predicate) compiles to one dependent HBM round trip per output — 32 per lane, the
@@ -499,6 +535,10 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
   static const bool dma_off = getenv("SSRHIP_GEMM_SPLIT_DMA") && getenv("SSRHIP_GEMM_SPLIT_DMA")[0] == '0';   // A/B knob: the 4-wave kernels
   const bool dma = !dma_off && ((size_t)127 * a->lda + a->K) * 4 < 0x7FFFFFF0ull && (size_t)128 * a->K * 2 < 0x7FFFFFF0ull;
   static const int wide = !(getenv("SSRHIP_EPILOGUE_WIDE") && getenv("SSRHIP_EPILOGUE_WIDE")[0] == '0');      // A/B knob: 0 = dword epilogue
+  // opt-in (never run on hardware yet): the transposed convolutions' time mask as a row predicate of the 16-byte epilogue
+  static const bool tm_knob = getenv("SSRHIP_EPILOGUE_TM") && getenv("SSRHIP_EPILOGUE_TM")[0] != '0';
+  const bool tmf = tm_knob && wide && a->tm_c > 0 && a->N % a->tm_c == 0 && a->tm_c % 4 == 0 && !a->R && !a->residual && !a->rbias && a->ldc % 4 == 0 &&
+                   a->strideC % 4 == 0 && ((uintptr_t)a->C & 15) == 0 && (long)a->M * (a->N / a->tm_c) < 0x7FFFFFFFL;
   if (dma) {
     static ssr_once_per_device once;
     if (once.need()) {
@@ -506,12 +546,19 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
       SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(128)));
       SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(64)));
       SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(64)));
+      if (tm_knob) {
+        SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<128, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(128)));
+        SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_dma_kernel<128, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dma_lds(128)));
+      }
     }
   }
   if (tiles128 >= 384 && !half_empty) {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 127) / 128, (unsigned)nb);
     ssr_gemm_log(a, grid.x, grid.y, grid.z, 1);
-    if (dma) {
+    if (dma && tmf) {
+      if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<128, true, 0, true>), grid, dim3(512), dma_lds(128), s, *a, wide);
+      else hipLaunchKernelGGL((gemm_split_dma_kernel<128, false, 0, true>), grid, dim3(512), dma_lds(128), s, *a, wide);
+    } else if (dma) {
       if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<128, true>), grid, dim3(512), dma_lds(128), s, *a, wide);
       else hipLaunchKernelGGL((gemm_split_dma_kernel<128, false>), grid, dim3(512), dma_lds(128), s, *a, wide);
     } else if (elu) hipLaunchKernelGGL((gemm_split_kernel<128, true>), grid, dim3(256), 0, s, *a);
