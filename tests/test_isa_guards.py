@@ -106,7 +106,7 @@ def test_split_gemm_kernels_use_the_bf16_matrix_core_and_do_not_spill(tmp_path_f
     # the 8-wave DMA kernel: four waves per SIMD need <= 128 VGPRs; W reaches LDS through buffer_load ... lds (three planes per tile, in the
     # prologue and in the loop), A through branch-free buffer loads (no exec-mask branch around a load anywhere in the k-loop)
     dma = {k: v for k, v in _kernel_meta(asm).items() if "gemm_split_dma_kernel" in k}
-    assert len(dma) == 4, sorted(dma)                                # 128- / 64-row tiles x ELU on load or not
+    assert len(dma) == 6, sorted(dma)                                # 128- / 64-row tiles x ELU on load or not, + the two opt-in time-mask instantiations
     for sym, (vgpr, scratch) in dma.items():
         assert vgpr <= 128 and scratch == 0, (sym, vgpr, scratch)
         body = _body(asm, sym)
@@ -155,7 +155,7 @@ def test_split_gemm_drains_its_dma_before_the_tile_barrier(tmp_path_factory):
     barrier that publishes the tile (until round 4 only the compiler's conservative wait placement guaranteed it)."""
     asm = _asm(tmp_path_factory, "gemm_split")
     syms = [k for k in _kernel_meta(asm) if "gemm_split_dma_kernel" in k]
-    assert len(syms) == 4, syms
+    assert len(syms) == 6, syms
     for sym in syms:
         body = _body(asm, sym)
         lo = body.index("=>This Inner Loop Header")
@@ -216,7 +216,7 @@ def test_codec_epilogues_request_the_added_operand_a_block_at_a_time(tmp_path_fa
         assert _serialized_loads(body) == per_lane, (sym, _serialized_loads(body))   # the ragged last tile's plain loop, nothing else
     asm = _asm(tmp_path_factory, "gemm_split")
     syms = [k for k in _kernel_meta(asm) if "gemm_split_dma_kernel" in k]
-    assert len(syms) == 4, syms
+    assert len(syms) == 6, syms
     for sym in syms:
         body = _whole_body(asm, sym)
         mt = 2 if "ILi128E" in sym else 1
