@@ -89,3 +89,45 @@ def test_first_generation_padded_rows_read_clean_but_store_two_way():
     assert extra == 48
     wave_k_tiles = (4096 // 128) ** 2 * (4096 // 32) * 8                   # 4096^3: workgroups x k-tiles x waves
     assert abs(extra * wave_k_tiles - 50_724_864) / 50_724_864 < 0.01     # SQ_LDS_BANK_CONFLICT of that run
+
+
+def test_epilogue_transposition_through_lds_is_conflict_free():
+    """The 16-byte epilogues (gemm_split_dma_kernel, and resblock_split_dma_kernel behind SSRHIP_EPILOGUE_WIDE=1) turn a 32 x 32
+    accumulator block through a wave-private [32 rows][32 dwords] tile: lane (li, lh) stores register r at row (r & 3) + 8 (r >> 2) + 4 lh,
+    column li (`ds_write_b32`: two groups of 32 lanes, bank = dword address mod 32), then lane l reads the float4 at row l / 8 + 8 p,
+    columns 4 (l % 8) .. + 3 (`ds_read_b128` lane groups). Unpadded 128-byte rows are conflict-free for both — and every element written
+    is read exactly once."""
+    written = set()
+    for r in range(16):
+        addrs = [(((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)) * 4 for l in range(64)]
+        groups = [list(range(0, 32)), list(range(32, 64))]
+        assert _extra_cycles(addrs, groups, 4, 32) == 0, r
+        written |= set(addrs)
+    assert len(written) == 32 * 32
+    read = set()
+    for p in range(4):
+        def addr(l, p=p):
+            return (((l >> 3) + 8 * p) * 32 + (l & 7) * 4) * 4
+        assert _read_extra(addr) == 0, p
+        for l in range(64):
+            read |= {addr(l) + 4 * d for d in range(4)}
+    assert read == written
+
+
+def test_split_lstm_partial_tiles_in_lds():
+    """lstm_step_split_kernel (csrc/lstm_split.hip): the four waves' partial 64 x 64 tiles meet in LDS as part[wave][n][65 floats]. The
+    accumulator stores (lane li = column n, register r = row m: `ds_write_b32`) are conflict-free with the 65-float row stride (64 would
+    put all 32 lanes of a group on one bank); the finishing reads (lane = unit u of batch row bl: 16 lanes share a row) are 2-way."""
+    PS = 65
+    for mb, nb, r in itertools.product(range(2), range(2), range(16)):
+        addrs = [((nb * 32 + (l & 31)) * PS + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 4 for l in range(64)]
+        assert _extra_cycles(addrs, [list(range(0, 32)), list(range(32, 64))], 4, 32) == 0, (mb, nb, r)
+        bad = [((nb * 32 + (l & 31)) * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 4 for l in range(64)]
+        assert _extra_cycles(bad, [list(range(0, 32)), list(range(32, 64))], 4, 32) == 62        # the unpadded form: 32-way twice
+    for i, g in itertools.product(range(4), range(4)):
+        addrs = []
+        for l in range(64):
+            p = l + 256 * i                                        # wave 0's lanes; the other waves differ by a multiple of 4 batch rows
+            u, bl = p & 15, p >> 4
+            addrs.append((bl * PS + g * 16 + u) * 4)
+        assert _extra_cycles(addrs, [list(range(0, 32)), list(range(32, 64))], 4, 32) <= 2, (i, g)
