@@ -1108,3 +1108,17 @@ def test_lstm_split_step_matches_fp64(L, B, Cc, T, skip, out_act):
     torch.testing.assert_close(outs[0], outs[1], rtol=2e-5, atol=2e-5)
     a.w_split, a.hsplit = wsplit.data_ptr(), 0
     assert L.ssrhip_lstm_layer(C.byref(a), _lib.stream_ptr()) != 0                                          # the two pointers come together
+
+
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_both_epilogue_forms_of_the_codec_kernels_pass_their_parity_tests(wide):
+    """The split DMA GEMM and the residual-block kernel each have a dword and a 16-byte epilogue (same arithmetic; `SSRHIP_EPILOGUE_WIDE`,
+    read once per process) and each DEFAULTS to a different one — so the suite above exercises one form per kernel. This runs the two
+    kernels' parity tests again in a child process with the knob forced either way."""
+    import subprocess, sys
+    env = dict(os.environ, SSRHIP_EPILOGUE_WIDE=wide)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-x", "-q", "-k",
+                          "resblock_split_dma or gemm_split or gemm_batched_strided"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-2000:]
