@@ -205,9 +205,12 @@ class WMEncodecModel:
         self.fuse_resblock = True            # tests switch it off to compare with the two-GEMM path
         self.force_few_out = False           # tests: take the few-output-channel kernel also for short inputs
         self.lstm_packed = os.environ.get("SSRHIP_LSTM_PACKED", "1") != "0"      # A/B knob for the packed recurrent matrix
-        # the recurrence on the bf16 matrix cores with split operands (csrc/lstm_split.hip): written at the end of round 4 without GPU
-        # minutes left — OFF until it has passed the codec fixtures on hardware
-        self.lstm_split = os.environ.get("SSRHIP_LSTM_SPLIT", "0") not in ("", "0")
+        # the recurrence on the bf16 matrix cores with split operands (csrc/lstm_split.hip). Written blind at the end of round 4; round 5's
+        # first GPU call ran it: kernel test vs fp64 green, all codec fixtures green with it, 21.0 us per step alone / 35.6 with both layers'
+        # chains sharing the GPU against 31.0 / 56.8 for the fp32-pipe kernel at 256 items, config 5 373.9 / 383.6 -> 335.7 / 344.3 ms
+        # (profiles/r05_microbench/codec256_ab.log). Default for batches of `lstm_split_min_b` items and more; SSRHIP_LSTM_SPLIT=0 = fp32 pipe.
+        self.lstm_split = os.environ.get("SSRHIP_LSTM_SPLIT", "1") not in ("", "0")
+        self.lstm_split_min_b = int(os.environ.get("SSRHIP_LSTM_SPLIT_MIN_B", "128"))
         # channel counts whose residual block runs as one kernel (env knob for A/B runs: e.g. SSRHIP_RESBLOCK_FUSE=64,128,256,512).
         # Measured at 32 clips x 30 s (encode / decode ms): {64}: 86.9 / 88.8; {64,128}: 86.4 / 87.7 and 1.9 GB less memory;
         # adding 256 or 512 (short time axes, wide weights): 88.3 / 89.1-90.5 — the chained kernel's LDS footprint leaves one
@@ -457,7 +460,8 @@ class WMEncodecModel:
         cbufs = [torch.empty(B, Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
         outs = [self._alloc_for(B, T, Cc, nxt, x.lens) if l == nl - 1 else TM(B, T, Cc, 0, 0, dev) for l in range(nl)]
         # h of the split-operand path: two buffers of bf16 planes in fragment order (zeroed by the library at t = 0)
-        hsplits = [torch.empty(2 * ((B + 63) // 64) * 64 * Cc * 3, dtype=torch.int16, device=dev) if (self.lstm_split and L.split[l] is not None) else None
+        use_split = self.lstm_split and B >= self.lstm_split_min_b and not (B <= 4 and Cc in (256, 512, 1024, 2048))
+        hsplits = [torch.empty(2 * ((B + 63) // 64) * 64 * Cc * 3, dtype=torch.int16, device=dev) if (use_split and L.split[l] is not None) else None
                    for l in range(nl)]
 
         def in_gemm(l, t0, t1):                                        # gin_l[:, t0:t1] = in_l[:, t0:t1] W_ih^T + b
@@ -472,7 +476,7 @@ class WMEncodecModel:
             use_packed = (not small_b) and L.packed[l] is not None and self.lstm_packed
             a.gin, a.w_hh, a.out = gins[l].data_ptr(), (L.packed[l] if use_packed else L.layers[l][1]).data_ptr(), outs[l].interior
             a.w_packed = int(use_packed)
-            if self.lstm_split and (not small_b) and L.split[l] is not None and B >= 32:      # ssrhip_lstm_split_eligible
+            if use_split and L.split[l] is not None:
                 a.w_split, a.hsplit = L.split[l].data_ptr(), hsplits[l].data_ptr()
             a.skip = x.interior if l == nl - 1 else 0                   # y = lstm(x) + x (lstm.py:21-23)
             a.hbuf, a.cbuf, a.gates = hbufs[l].data_ptr(), cbufs[l].data_ptr(), 0

@@ -25,8 +25,8 @@ namespace {
 #endif
 __device__ __forceinline__ float4 ld_kv(const float* p) { return SSR_ATTN_NT ? ld_nt(p) : ld4(p); }
 
-template <int HD, bool SEQ>      // SEQ: rows carry an explicit sequence id (a.row_seq != NULL: the per-row prefill path); the decode step has none
-__global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args a) {
+template <int HD, bool SEQ, bool PIN = true>   // SEQ: rows carry an explicit sequence id (a.row_seq != NULL: the per-row prefill path); the decode step has none
+__global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args a) {   // PIN = false: round 4's schedule (A/B: SSRHIP_ATTN_PIN=0)
   constexpr int LPK = HD / 4;         // lanes per key row
   constexpr int KPI = 64 / LPK;       // key rows per wave-instruction
   constexpr int NI = 32 / KPI;        // load instructions for the wave's 32 keys
@@ -74,6 +74,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args
     const int j = min(wave * 32 + i * KPI + sub, jmax);
     vv[i] = ld_kv(vp + (size_t)j * HD + c4);
   }
+  // Nothing moves across this line. Without it hipcc's occupancy-driven scheduler consumed the K rows as they arrived, re-used their
+  // registers, and requested the V rows only after the LAST K row had landed (`s_waitcnt vmcnt(0)` between the 16th K and the first V
+  // request; kernel at 77 VGPRs): two dependent HBM round trips per launch where the source asks for one (read off the ISA, round 5 —
+  // rounds 1-4 believed all 2 NI loads were in flight together). With the fence the wave holds K and V (2 NI float4) at once.
+  if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < NI; ++i) s[i] = dot4(q, kk[i], 0.f);
   // reduce each s[i] over the LPK lanes of its key row (DPP row rotations + permlane16_swap: no LDS)
@@ -506,6 +511,8 @@ extern "C" int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t str
     dim3 grid(s.max_splits, s.kv.n_head, n);
     if (s.kv.head_dim == 128) {
       if (s.row_seq) hipLaunchKernelGGL((attn_decode_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, s);
+      else if (const char* e = getenv("SSRHIP_ATTN_PIN"); e && e[0] == '0')   // A/B knob of round 5 (tools/decode_ab.py): round 4's load schedule
+        hipLaunchKernelGGL((attn_decode_kernel<128, false, false>), grid, dim3(256), 0, (hipStream_t)stream, s);
       else hipLaunchKernelGGL((attn_decode_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, s);
     } else {
       if (s.row_seq) hipLaunchKernelGGL((attn_decode_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, s);

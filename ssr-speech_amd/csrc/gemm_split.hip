@@ -227,7 +227,8 @@ enum { GD_KO_MFMA = 1, GD_KO_ALOAD = 2, GD_KO_ASTORE = 4, GD_KO_DMA = 8, GD_KO_S
 constexpr int GD_NSTAMP = 128, GD_STEPS = 40;              // stamps 3 s + {0, 1, 2} of step s < GD_STEPS: loop top, tile ready, MFMA block issued; 124 / 125: entry / end
 __device__ unsigned* g_gd_prof = nullptr;                  // [sampled workgroup][GD_NSTAMP]
 
-// TMF (opt-in instantiation, SSRHIP_EPILOGUE_TM=1; written without GPU minutes left, never run): whole tiles of a TRANSPOSED convolution's
+// TMF (default since round 5; SSRHIP_EPILOGUE_TM=0 = the general loop. Written blind at the end of round 4; round 5's first GPU call: GEMM tests
+// and all codec fixtures green with it, config-5 decode 383.6 -> 373.6 ms, profiles/r05_microbench/codec256_ab.log): whole tiles of a TRANSPOSED convolution's
 // GEMM — time mask tm_c > 0 with N % tm_c == 0 and tm_c % 4 == 0, nothing added behind the activation (the launcher checks) — take the
 // 16-byte epilogue with the mask as a per-row predicate: element (m, n) belongs to time row (m N + n) / tm_c = m (N / tm_c) + n / tm_c, the
 // second term one 32-bit division per LANE. The general loop those launches take today pays a 64-bit division per OUTPUT (32 per lane).
@@ -535,8 +536,8 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
   static const bool dma_off = getenv("SSRHIP_GEMM_SPLIT_DMA") && getenv("SSRHIP_GEMM_SPLIT_DMA")[0] == '0';   // A/B knob: the 4-wave kernels
   const bool dma = !dma_off && ((size_t)127 * a->lda + a->K) * 4 < 0x7FFFFFF0ull && (size_t)128 * a->K * 2 < 0x7FFFFFF0ull;
   static const int wide = !(getenv("SSRHIP_EPILOGUE_WIDE") && getenv("SSRHIP_EPILOGUE_WIDE")[0] == '0');      // A/B knob: 0 = dword epilogue
-  // opt-in (never run on hardware yet): the transposed convolutions' time mask as a row predicate of the 16-byte epilogue
-  static const bool tm_knob = getenv("SSRHIP_EPILOGUE_TM") && getenv("SSRHIP_EPILOGUE_TM")[0] != '0';
+  // the transposed convolutions' time mask as a row predicate of the 16-byte epilogue (SSRHIP_EPILOGUE_TM=0: the general per-element loop)
+  static const bool tm_knob = !(getenv("SSRHIP_EPILOGUE_TM") && getenv("SSRHIP_EPILOGUE_TM")[0] == '0');
   const bool tmf = tm_knob && wide && a->tm_c > 0 && a->N % a->tm_c == 0 && a->tm_c % 4 == 0 && !a->R && !a->residual && !a->rbias && a->ldc % 4 == 0 &&
                    a->strideC % 4 == 0 && ((uintptr_t)a->C & 15) == 0 && (long)a->M * (a->N / a->tm_c) < 0x7FFFFFFFL;
   if (dma) {

@@ -37,7 +37,7 @@ struct GemvK {
   int hd;         // head_dim (QKV epilogue / combine prologue)
   int seg_shift;  // segment kernel: log2(K / 1024)
   int rows_max;   // segment kernel: most rows a workgroup owns (sizes the LDS partials)
-  long long* prof;          // debug (ssrhip_debug_gemv_prof): 8 wall_clock64 stamps per workgroup, or NULL
+  long long* prof;          // -DSSR_GEMV_PROFILE builds only (ssrhip_debug_gemv_prof): 8 wall_clock64 stamps per workgroup, or NULL
   int rows_per, rows_rem;   // segment / front kernels: N / groups_x and N % groups_x (workgroup b owns rows_per + (b < rows_rem) rows)
 };
 
@@ -259,6 +259,29 @@ __device__ __forceinline__ void finalize(const GemvK& p, int g, int n, int b, fl
   }
 }
 
+// K / V base addresses (head 0) of the cache position this step appends, for the batch row `bsel` of the calling thread. The chain
+// kv_pos -> page table -> pool stays on the SCALAR path for all B rows side by side: the B position words, one wait, the B table words,
+// one wait — two scalar round trips whatever B — and the thread's own row is picked with selects (a branch per row made hipcc walk the
+// rows' chains one after the other inside exec-masked blocks: 2 B dependent round trips).
+template <int B>
+__device__ __forceinline__ void kv_append_bases(const ssrhip_gemv_args& a, int bsel, float* (&kvb)[2]) {
+  int pos[B], page[B];
+#pragma unroll
+  for (int b = 0; b < B; ++b) pos[b] = a.kv_pos[b];
+#pragma unroll
+  for (int b = 0; b < B; ++b) page[b] = a.kv.table[(size_t)b * a.kv.max_pages + (pos[b] / SSRHIP_PAGE)];
+  size_t ok = 0, ov = 0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const size_t k0 = ((((size_t)page[b] * a.kv.n_layer + a.layer) * 2 + 0) * a.kv.n_head) * SSRHIP_PAGE + (pos[b] % SSRHIP_PAGE);
+    const size_t v0 = ((((size_t)page[b] * a.kv.n_layer + a.layer) * 2 + 1) * a.kv.n_head) * SSRHIP_PAGE + (pos[b] % SSRHIP_PAGE);
+    ok = (bsel == b) ? k0 : ok;
+    ov = (bsel == b) ? v0 : ov;
+  }
+  kvb[0] = a.kv.pool + ok * a.kv.head_dim;
+  kvb[1] = a.kv.pool + ov * a.kv.head_dim;
+}
+
 template <bool FULL>
 __device__ __forceinline__ void load_row(float4 (&w)[MAXCH], const float* wrow, int lane, int nch, int len) {
 #pragma unroll
@@ -469,6 +492,23 @@ void launch_b(const GemvK& p, dim3 grid, size_t smem, hipStream_t s) {
 //     exchanged through LDS (one barrier), merged exactly (Chan) — gamma / beta folded into W / bias by the host;
 //   * split-KV combine prologue: one float4 column per thread and row (512 threads x 4 = K = 2048), 6 pages prefetched;
 //   * 16 waves per CU (two workgroups): 128 VGPRs per lane (HIP's second launch-bound is waves per SIMD).
+// Loads of the merge prologue's COLD path (contexts beyond the SEG_CS prefetched pages), hidden from hipcc's wait-count bookkeeping: load
+// and wait in one asm statement. A compiler-visible load inside those loops made hipcc put `s_waitcnt vmcnt(0)` on the HOT path as well
+// (the loops' pre-headers and the first use of a prefetched partial behind them): every out-projection drained its whole weight slice
+// before the merge arithmetic, a barrier and an LDS round trip instead of under them (read off the ISA, round 5). The asm wait drains the
+// queue too — but only when a late page exists.
+__device__ __forceinline__ float4 ld4_late(const float* p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f v;
+  asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 ld2_late(const float* p) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f v;
+  asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return make_float2(v.x, v.y);
+}
 constexpr int SEG = 1024;            // floats per unit
 constexpr int SEG_TH = 512, SEG_NW = 8;
 template <int B> struct SegCS { static constexpr int v = (B <= 2) ? 6 : 2; };   // pages prefetched by the combine prologue (register budget: 128)
@@ -482,7 +522,15 @@ template <int B> struct SegCS { static constexpr int v = (B <= 2) ? 6 : 2; };   
 template <int B, int PRO, bool TWO>
 __global__ __launch_bounds__(SEG_TH, (TWO && PRO == SSRHIP_PRO_ATTN_COMBINE) ? 2 : 4) void gemv_seg_kernel(const GemvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // Time stamps exist only in a -DSSR_GEMV_PROFILE build (tools/gemv_prof.py). Round 4 shipped them as a runtime `if (p.prof ..)`: the
+  // exec-mask branch at kernel entry split the kernel-argument fetch into two dependent scalar round trips, and — worse — its global store
+  // made every later uniform load "possibly clobbered", so the kv_pos -> page table chain of the QKV launch left the scalar path and became
+  // vector loads behind `s_waitcnt vmcnt(0)`: four drains of the first unit's weight loads per wave (read off the ISA, round 5).
+#ifdef SSR_GEMV_PROFILE
 #define GSTAMP(i) do { if (p.prof && threadIdx.x == 0) p.prof[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
   GSTAMP(0);
   constexpr int SEG_CS = SegCS<B>::v;
   const ssrhip_gemv_args& a = p.a;
@@ -499,6 +547,14 @@ __global__ __launch_bounds__(SEG_TH, (TWO && PRO == SSRHIP_PRO_ATTN_COMBINE) ? 2
   float* aux = smem + p.rows_max * S * B;                          // prologue scratch
   const float* Wg = a.W + ((size_t)g * N + r0) * K + seg * SEG + lane * 4;
 
+  // ---- 0. epilogue operands of the (row, b) this thread finalises: the OLDEST loads of the wave. They used to be requested behind the first
+  // units; hipcc packs the merge / dot arithmetic into v_pk_fma_f32 and one of those register PAIRS held the residual in its unused half, so
+  // the first use of a prefetched partial waited for the youngest load of the wave — `s_waitcnt vmcnt(0)`, the whole weight slice drained
+  // before the merge arithmetic (read off the ISA, round 5). As the oldest loads such a false dependency costs nothing.
+  RowEpi efin = {0.f, 0.f};
+  const int bfin = t % B, rfin = min(t / B, nrows - 1), nfin = r0 + rfin;
+  efin.bias = a.bias ? a.bias[(size_t)g * N + nfin] : 0.f;
+  efin.resid = (a.epi == SSRHIP_EPI_RESIDUAL) ? a.y[(size_t)bfin * a.y_stride + (size_t)g * N + nfin] : 0.f;
   // ---- 1. activations (L2) — issued first, they return first
   float4 xr[B][4];
   float4 co[(PRO == SSRHIP_PRO_ATTN_COMBINE) ? B : 1][SEG_CS];
@@ -542,21 +598,8 @@ __global__ __launch_bounds__(SEG_TH, (TWO && PRO == SSRHIP_PRO_ATTN_COMBINE) ? 2
     }
   }
   GSTAMP(1);
-  // ---- epilogue operands of the (row, b) this thread finalises
-  RowEpi efin = {0.f, 0.f};
-  const int bfin = t % B, rfin = min(t / B, nrows - 1), nfin = r0 + rfin;
-  efin.bias = a.bias ? a.bias[(size_t)g * N + nfin] : 0.f;
-  efin.resid = (a.epi == SSRHIP_EPI_RESIDUAL) ? a.y[(size_t)bfin * a.y_stride + (size_t)g * N + nfin] : 0.f;
   float* kvb[2] = {nullptr, nullptr};
-  if (a.epi == SSRHIP_EPI_QKV_APPEND) {                            // scalar-path address chain (kv_pos -> page table -> pool)
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const int pos = a.kv_pos[b];
-      float* kb = kv_addr(a.kv, b, a.layer, 0, 0, pos);
-      float* vb = kv_addr(a.kv, b, a.layer, 1, 0, pos);
-      if (bfin == b) { kvb[0] = kb; kvb[1] = vb; }
-    }
-  }
+  if (a.epi == SSRHIP_EPI_QKV_APPEND) kv_append_bases<B>(a, bfin, kvb);   // scalar-path address chain (kv_pos -> page table -> pool)
   // ---- 3. prologue math, under the latency of the first units
   if constexpr (PRO == SSRHIP_PRO_LAYERNORM) {
     float m[B], q[B];
@@ -600,17 +643,17 @@ __global__ __launch_bounds__(SEG_TH, (TWO && PRO == SSRHIP_PRO_ATTN_COMBINE) ? 2
 #pragma unroll
       for (int i = 0; i < SEG_CS; ++i)
         if (i < n) M = fmaxf(M, cml[i].x);
-      for (int s2 = SEG_CS; s2 < n; ++s2) M = fmaxf(M, ml[2 * s2]);
+      for (int s2 = SEG_CS; s2 < n; ++s2) M = fmaxf(M, ld2_late(ml + 2 * s2).x);
       float den = 0.f;
 #pragma unroll
       for (int i = 0; i < SEG_CS; ++i)
         if (i < n) den = fmaf(expf(cml[i].x - M), cml[i].y, den);
-      for (int s2 = SEG_CS; s2 < n; ++s2) den = fmaf(expf(ml[2 * s2] - M), ml[2 * s2 + 1], den);
+      for (int s2 = SEG_CS; s2 < n; ++s2) { const float2 v = ld2_late(ml + 2 * s2); den = fmaf(expf(v.x - M), v.y, den); }
       const float inv = 1.0f / den;
 #pragma unroll
       for (int i = 0; i < SEG_CS; ++i)
         if (i < n) wtab[t * MS + i] = expf(cml[i].x - M) * inv;
-      for (int s2 = SEG_CS; s2 < n; ++s2) wtab[t * MS + s2] = expf(ml[2 * s2] - M) * inv;
+      for (int s2 = SEG_CS; s2 < n; ++s2) wtab[t * MS + s2] = expf(ld2_late(ml + 2 * s2).x - M) * inv;
     }
     __syncthreads();
     const int e = t * 4, h = e / hd, d = e % hd;
@@ -630,7 +673,7 @@ __global__ __launch_bounds__(SEG_TH, (TWO && PRO == SSRHIP_PRO_ATTN_COMBINE) ? 2
       const float* po = a.part_o + (((size_t)b * H + h) * MS) * hd + d;
       for (int s2 = SEG_CS; s2 < ns[b]; ++s2) {                    // contexts beyond the prefetched pages: the rest, loaded late
         const float ws = w[s2];
-        const float4 o = ld4(po + (size_t)s2 * hd);
+        const float4 o = ld4_late(po + (size_t)s2 * hd);
         acc.x = fmaf(ws, o.x, acc.x);
         acc.y = fmaf(ws, o.y, acc.y);
         acc.z = fmaf(ws, o.z, acc.z);
@@ -707,6 +750,113 @@ __global__ __launch_bounds__(SEG_TH, (TWO && PRO == SSRHIP_PRO_ATTN_COMBINE) ? 2
 #undef GSTAMP
 }
 
+// Round 5: the segment kernel in the form tools/gemv_floor_lab.hip measured fastest for a dependent chain (modes 5 / 6: 9.16-9.27 us for
+// 50.3 MB against 9.44-9.49 for the geometry above): ONE 8-wave workgroup per CU, every wave keeps DEPTH units (DEPTH x 4 loads per lane)
+// in flight and re-requests a 16-byte piece for unit j + DEPTH right after unit j used it. The number of units per wave NUW is a template
+// parameter — the 830M step's shapes divide evenly (QKV 24 rows x 2 segments / 8 waves = 6, FFN1 32 x 2 / 8 = 8, FFN2 8 x 8 / 8 = 8,
+// head-MLP1 16 x 2 / 8 = 4) — so the unit loop is straight-line code: every re-request is unconditional AND none is wasted (no peeled
+// tail, no clamping, exact `s_waitcnt vmcnt(n)` everywhere). Half the workgroups of the form above: half the x traffic from L2 (8 waves
+// fetch their slices instead of 16), half the LayerNorm statistics, one barrier pair per CU instead of two, 256 dispatches instead of 512.
+// Per unit, per segment and per output the SAME operations in the same order as gemv_seg_kernel: bit-identical results (tests compare).
+template <int B, int PRO, int NUW, int DEPTH>
+__global__ __launch_bounds__(SEG_TH, 2) void gemv_segu_kernel(const GemvK p) {
+  static_assert(PRO == SSRHIP_PRO_NONE || PRO == SSRHIP_PRO_LAYERNORM, "the split-KV merge prologue stays on gemv_seg_kernel");
+  static_assert(DEPTH >= 1 && DEPTH <= NUW, "units in flight");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const ssrhip_gemv_args& a = p.a;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int g = blockIdx.y;
+  const int K = a.K, N = a.N, S = p.nslice, sh = p.seg_shift;
+  const int nrows = p.rows_per;                                    // exact: the host takes this kernel only when N % G == 0
+  const int r0 = (int)blockIdx.x * nrows;
+  const int seg = wave & (S - 1);
+  float* part = smem;                                              // [nrows][S][B]
+  float* aux = smem + nrows * S * B;                               // LayerNorm statistics of the S segments
+  const float* Wg = a.W + ((size_t)g * N + r0) * K + seg * SEG + lane * 4;
+
+  // ---- 0. epilogue operands of the (row, b) this thread finalises: the wave's oldest loads (see gemv_seg_kernel)
+  RowEpi efin = {0.f, 0.f};
+  const int bfin = t % B, rfin = min(t / B, nrows - 1), nfin = r0 + rfin;
+  efin.bias = a.bias ? a.bias[(size_t)g * N + nfin] : 0.f;
+  efin.resid = (a.epi == SSRHIP_EPI_RESIDUAL) ? a.y[(size_t)bfin * a.y_stride + (size_t)g * N + nfin] : 0.f;
+  // ---- 1. the wave's x slice (L2), then its first DEPTH units (HBM, non-temporal)
+  float4 xr[B][4];
+#pragma unroll
+  for (int b = 0; b < B; ++b)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xr[b][i] = ld4(a.x + (size_t)b * a.x_stride + (size_t)g * K + seg * SEG + (i * 64 + lane) * 4);
+  float4 w[DEPTH][4];
+#pragma unroll
+  for (int j = 0; j < DEPTH; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(Wg + (size_t)((wave + SEG_NW * j) >> sh) * K + i * 256);
+  float* kvb[2] = {nullptr, nullptr};
+  if (a.epi == SSRHIP_EPI_QKV_APPEND) kv_append_bases<B>(a, bfin, kvb);
+  // ---- 2. LayerNorm statistics under the latency of the first units (the arithmetic of gemv_seg_kernel, operation for operation)
+  if constexpr (PRO == SSRHIP_PRO_LAYERNORM) {
+    float m[B], q[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      float s0 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s0 += (xr[b][i].x + xr[b][i].y) + (xr[b][i].z + xr[b][i].w);
+      m[b] = wave_sum(s0) * (1.0f / SEG);
+      float q0 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dx = xr[b][i].x - m[b], dy = xr[b][i].y - m[b], dz = xr[b][i].z - m[b], dw = xr[b][i].w - m[b];
+        q0 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+      q[b] = wave_sum(q0);
+      if (wave < S && lane == 0) { aux[(wave * B + b) * 2] = m[b]; aux[(wave * B + b) * 2 + 1] = q[b]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      float mean = 0.f, M2 = 0.f, dev = 0.f;
+      for (int s2 = 0; s2 < S; ++s2) mean += aux[(s2 * B + b) * 2];
+      mean /= (float)S;
+      for (int s2 = 0; s2 < S; ++s2) { const float dm = aux[(s2 * B + b) * 2] - mean; M2 += aux[(s2 * B + b) * 2 + 1]; dev = fmaf(dm, dm, dev); }
+      const float var = (M2 + (float)SEG * dev) / (float)K;
+      const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        xr[b][i] = make_float4((xr[b][i].x - mean) * rstd, (xr[b][i].y - mean) * rstd, (xr[b][i].z - mean) * rstd, (xr[b][i].w - mean) * rstd);
+    }
+  }
+  // ---- 3. the units, straight-line: use a piece, then re-request it in place for unit j + DEPTH
+#pragma unroll
+  for (int j = 0; j < NUW; ++j) {
+    float4 (&wj)[4] = w[j % DEPTH];
+    float acc[B][2];
+#pragma unroll
+    for (int b = 0; b < B; ++b) acc[b][0] = acc[b][1] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[b][i & 1] = dot4(wj[i], xr[b][i], acc[b][i & 1]);
+      if (j + DEPTH < NUW) {
+        __builtin_amdgcn_sched_barrier(0);
+        wj[i] = ld_nt(Wg + (size_t)((wave + SEG_NW * (j + DEPTH)) >> sh) * K + i * 256);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const float sum = wave_sum(acc[b][0] + acc[b][1]);
+      if (lane == b) mine = sum;
+    }
+    if (lane < B) part[(wave + SEG_NW * j) * B + lane] = mine;     // unit u = local_row * S + seg
+  }
+  __syncthreads();
+  if (t < nrows * B) {
+    float v = 0.f;
+    for (int s2 = 0; s2 < S; ++s2) v += part[(rfin * S + s2) * B + bfin];
+    finalize(p, g, nfin, bfin, v, efin, kvb);
+  }
+}
+
 // Round 4 measured the opposite organisation too — ALL of a wave's units requested at kernel entry, one 8-wave workgroup per CU (256 VGPRs):
 // bit-identical results, 12.4 us per launch in the step against 10.5 here (profiles/r04_microbench/decode_ab.log; the lab form of the same
 // idea is tools/gemv_floor_lab.hip mode 4: 10.0 us against 9.2-9.5 for 1-4 units in flight). Removed again.
@@ -745,6 +895,35 @@ bool try_seg(const ssrhip_gemv_args* a, int num_cu, hipStream_t s) {
   if (a->pro == SSRHIP_PRO_LAYERNORM) smem += (size_t)S * B * 2 * sizeof(float);
   if (a->pro == SSRHIP_PRO_ATTN_COMBINE) smem += ((size_t)B * a->K + (size_t)B * H * a->max_splits) * sizeof(float);
   smem = (smem + 15) / 16 * 16;
+  // round 5: one workgroup per CU, NUW units per wave straight-line, DEPTH in flight (gemv_segu_kernel) when the shape divides evenly
+  int segu_depth = 4;                                               // SSRHIP_GEMV_SEGU = 0 (off) | 2 | 4 (default): units in flight per wave; read at
+  if (const char* e = getenv("SSRHIP_GEMV_SEGU")) { segu_depth = atoi(e); if (segu_depth != 0 && segu_depth != 2) segu_depth = 4; }   // every call
+  if constexpr (B == 2) {
+    const int G1 = num_cu / a->groups;
+    if (segu_depth && a->pro != SSRHIP_PRO_ATTN_COMBINE && G1 >= 1 && a->N % G1 == 0 && ((a->N / G1) * S) % SEG_NW == 0) {
+      const int nuw = (a->N / G1) * S / SEG_NW;
+      if (nuw == 4 || nuw == 6 || nuw == 8) {
+        p.rows_max = p.rows_per = a->N / G1;
+        p.rows_rem = 0;
+        p.groups_x = G1;
+        size_t sm = (size_t)p.rows_per * S * B * sizeof(float) + (size_t)S * B * 2 * sizeof(float);
+        sm = (sm + 15) / 16 * 16;
+        const dim3 g1(G1, a->groups);
+#define SEGU_LAUNCH(PRO_, NUW_)                                                                                                       \
+        do {                                                                                                                           \
+          if (segu_depth == 2) hipLaunchKernelGGL((gemv_segu_kernel<B, PRO_, NUW_, 2>), g1, dim3(SEG_TH), sm, s, p);                    \
+          else hipLaunchKernelGGL((gemv_segu_kernel<B, PRO_, NUW_, 4>), g1, dim3(SEG_TH), sm, s, p);                                    \
+        } while (0)
+        if (a->pro == SSRHIP_PRO_LAYERNORM) {
+          if (nuw == 4) SEGU_LAUNCH(SSRHIP_PRO_LAYERNORM, 4); else if (nuw == 6) SEGU_LAUNCH(SSRHIP_PRO_LAYERNORM, 6); else SEGU_LAUNCH(SSRHIP_PRO_LAYERNORM, 8);
+        } else {
+          if (nuw == 4) SEGU_LAUNCH(SSRHIP_PRO_NONE, 4); else if (nuw == 6) SEGU_LAUNCH(SSRHIP_PRO_NONE, 6); else SEGU_LAUNCH(SSRHIP_PRO_NONE, 8);
+        }
+#undef SEGU_LAUNCH
+        return true;
+      }
+    }
+  }
   dim3 grid(G, a->groups);
   static int two_mode = -1;                                         // SSRHIP_GEMV_SEG_TWO=0: A/B knob (the in-place form for every shape)
   if (two_mode < 0) { const char* e = getenv("SSRHIP_GEMV_SEG_TWO"); two_mode = (e && e[0] == '0') ? 0 : 1; }
@@ -775,8 +954,10 @@ int g_blocks_per_cu = 3;   // A/B in the real (dependent-launch) decode step: 1 
 
 int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s);   // gemv_mfma.hip: 5..16 rows on the matrix core
 
-// debug hook (not part of the ABI; tools/gemv_prof.py): per-workgroup time stamps of every later gemv_seg_kernel launch
+#ifdef SSR_GEMV_PROFILE
+// debug hook of a profiling build (not part of the ABI; tools/gemv_prof.py): per-workgroup time stamps of every later gemv_seg_kernel launch
 extern "C" void ssrhip_debug_gemv_prof(void* dev_ptr) { g_gemv_prof = (long long*)dev_ptr; }
+#endif
 
 extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->W && a->y, "ssrhip_gemv: null argument");

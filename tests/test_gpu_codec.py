@@ -212,17 +212,23 @@ def test_fused_resblock_equals_two_gemm_path(pad_mode):
     assert (c1 != c0).float().mean() < 0.02
 
 
+@pytest.mark.parametrize("split_lstm", [False, True])
 @pytest.mark.parametrize("B", [6, 20])
 @pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
-def test_large_batch_kernels_match_the_oracle_directly(B, pad_mode):
+def test_large_batch_kernels_match_the_oracle_directly(B, pad_mode, split_lstm):
     """The kernels only batches > 4 reach — `lstm_step_mfma` (16-item batch tiles; B=20: two tiles, the second ragged), the
     fused residual blocks and the batched strided-view GEMMs — against oracle/codec.py itself (not against this package's
-    small-batch path): full config, both pad modes, ragged length. Every item of the batch is checked."""
+    small-batch path): full config, both pad modes, ragged length. Every item of the batch is checked. `split_lstm`: the same with the
+    recurrence forced onto `csrc/lstm_split.hip` (bf16 matrix cores, split operands; the default only from 128 items up), whose 64-row
+    batch group is ragged at both sizes: encoder, decoder, skip-encoder and detector LSTMs all against the oracle."""
     import dataclasses
     cfg = dataclasses.replace(W.codec_config_full(), pad_mode=pad_mode)
     sd = W.codec_state_dict(cfg, seed=13)
     m = WMEncodecModel(cfg, sd, "cuda")
     m.lanes = 1                                                     # B=20 in ONE lane: two batch tiles, the second ragged
+    if split_lstm:
+        assert m.lstm_split, "SSRHIP_LSTM_SPLIT=0 in the environment: nothing to force"
+        m.lstm_split_min_b = 1
     g = torch.Generator().manual_seed(5)
     wav = torch.randn(B, 1, cfg.hop * 11 + 129, generator=g) * 0.2
     codes, _, emb = m.encode(wav.cuda())

@@ -251,6 +251,56 @@ print("ERR", err)
     assert err < 3e-5, err
 
 
+def test_gemv_segu_kernel_is_bit_identical_to_the_segment_kernel(L, tmp_path):
+    """Round 5's `gemv_segu_kernel` (one 8-wave workgroup per CU, NUW units per wave as straight-line code, 2 or 4 in flight) performs per
+    unit, per segment and per output the operations of `gemv_seg_kernel` in the same order: the outputs of the step's four shapes it takes
+    (LN+QKV with the K/V append, LN+FFN1+ReLU, FFN2+residual, LN+head-MLP1+GELU; 2 rows) must be BIT-identical with the knob at 0 / 2 / 4.
+    The knob is read once per process: three child processes write their outputs, the parent compares."""
+    import subprocess, sys
+    code = f"""
+import ctypes as C, math, sys, numpy as np, torch
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import ssr_speech_amd
+from ssr_speech_amd import _lib
+L = _lib.lib()
+out = {{}}
+B = 2
+for name, N, K, pro, act, epi in [("qkv", 6144, 2048, 1, 0, 2), ("ffn1", 8192, 2048, 1, 1, 0), ("ffn2", 2048, 8192, 0, 0, 1), ("head1", 4096, 2048, 1, 2, 0)]:
+    g = torch.Generator().manual_seed(N + K)
+    Wt = (torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    x = (torch.randn(B, K, generator=g) * 1.5 + 0.3).cuda()
+    y = torch.randn(B, K if epi == 2 else N, generator=g).cuda()
+    a = _lib.GemvArgs()
+    a.W, a.bias, a.x, a.y = Wt.data_ptr(), bias.data_ptr(), x.data_ptr(), y.data_ptr()
+    a.B, a.N, a.K, a.groups, a.x_stride, a.y_stride = B, N, K, 1, K, (K if epi == 2 else N)
+    a.pro, a.act, a.epi, a.ln_eps = pro, act, epi, 1e-5
+    if epi == 2:
+        H, hd, n_layer, max_pages = 16, 128, 2, 4
+        pool = torch.zeros(2 * max_pages + 1, n_layer, 2, H, _lib.PAGE, hd, device="cuda")
+        table = torch.tensor([[5, 2, 7, 1], [0, 6, 3, 4]], dtype=torch.int32, device="cuda")
+        pos = torch.tensor([130, 300], dtype=torch.int32, device="cuda")
+        a.kv = _lib.KV(pool.data_ptr(), table.data_ptr(), max_pages, n_layer, H, hd)
+        a.layer, a.kv_pos = 1, pos.data_ptr()
+    _lib.check(L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    out[name] = y.cpu().numpy()
+    if epi == 2:
+        out["pool"] = pool.cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+    res = {}
+    for knob in ("0", "2", "4"):
+        f = str(tmp_path / f"segu{knob}.npz")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, SSRHIP_GEMV_SEGU=knob), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[knob] = dict(np.load(f))
+    assert np.abs(res["0"]["pool"]).sum() > 0                        # the append landed somewhere
+    for knob in ("2", "4"):
+        for key, want in res["0"].items():
+            assert np.array_equal(res[knob][key], want), (knob, key, float(np.abs(res[knob][key] - want).max()))
+
+
 @pytest.mark.parametrize("max_pages", [8, 7, 5, 1])
 @pytest.mark.parametrize("B", [1, 2, 4])
 def test_gemv_seg_combine_and_qkv_append_at_2048(L, B, max_pages):
@@ -1053,14 +1103,11 @@ def test_resblock_split_dma_kernel_matches_fp64(L, Cc, T, out_act):
     assert L.ssrhip_resblock(C.byref(a), _lib.stream_ptr()) != 0                           # the two plane pointers come together
 
 
-@pytest.mark.skipif(os.environ.get("SSRHIP_RUN_UNVALIDATED", "0") in ("", "0"),
-                    reason="csrc/lstm_split.hip was written after round 4's GPU minutes were spent and has never run: SSRHIP_RUN_UNVALIDATED=1 "
-                           "runs this test (tools/r05_labs.sh does); the skip goes away with the kernel's first green run")
 @pytest.mark.parametrize("B,Cc,T", [(70, 128, 6), (64, 256, 4), (33, 1024, 3)])
 @pytest.mark.parametrize("skip,out_act", [(False, 0), (True, _lib.ACT_ELU)])
 def test_lstm_split_step_matches_fp64(L, B, Cc, T, skip, out_act):
-    """csrc/lstm_split.hip (LSTM recurrence on the bf16 matrix cores, both operands exactly split, streamed in MFMA fragment order; opt-in
-    SSRHIP_LSTM_SPLIT=1) through `ssrhip_lstm_layer` with `w_split` / `hsplit`, in two time windows (the chunked two-stream pipeline's
+    """csrc/lstm_split.hip (LSTM recurrence on the bf16 matrix cores, both operands exactly split, streamed in MFMA fragment order; the codec's
+    default from 128 items up) through `ssrhip_lstm_layer` with `w_split` / `hsplit`, in two time windows (the chunked two-stream pipeline's
     calling pattern), against an fp64 evaluation of torch.nn.LSTM's cell (gates i f g o; modules/lstm.py:10-25) — and against the fp32
     matrix-pipe kernel the same call takes without the planes. A batch that does not fill its last 64-row group, three widths
     (C / 64 = 2, 4, 16 k-steps per wave: both prefetch depths), skip + ELU-on-store epilogue. Error no larger than the fp32 path's."""
