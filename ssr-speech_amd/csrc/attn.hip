@@ -25,13 +25,16 @@ namespace {
 #endif
 __device__ __forceinline__ float4 ld_kv(const float* p) { return SSR_ATTN_NT ? ld_nt(p) : ld4(p); }
 
-template <int HD, bool SEQ, bool PIN = true>   // SEQ: rows carry an explicit sequence id (a.row_seq != NULL: the per-row prefill path); the decode step has none
-__global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args a) {   // PIN = false: round 4's schedule (A/B: SSRHIP_ATTN_PIN=0)
+template <int HD, bool SEQ, int VAT = -1>   // SEQ: rows carry an explicit sequence id (a.row_seq != NULL: the per-row prefill path); the decode step has none
+__global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args a, const int head_fastest) {   // VAT: see the V requests below
   constexpr int LPK = HD / 4;         // lanes per key row
   constexpr int KPI = 64 / LPK;       // key rows per wave-instruction
   constexpr int NI = 32 / KPI;        // load instructions for the wave's 32 keys
   __shared__ __attribute__((aligned(16))) float sm[4][HD + 4];   // row stride keeps float4 stores 16-B aligned
-  const int split = blockIdx.x, h = blockIdx.y, r = blockIdx.z;
+  // Workgroup b runs on XCD b % 8 (observed, for speed only). With the page index as the fastest grid dimension and 8 pages of capacity
+  // every workgroup of page p sat on XCD p: a 600-position context used 5 XCDs' L2s and fabric links and left 3 idle. `head_fastest`
+  // makes the head the fastest dimension: the live (page, head, row) items spread over all XCDs whatever the context.
+  const int split = head_fastest ? blockIdx.y : blockIdx.x, h = head_fastest ? blockIdx.x : blockIdx.y, r = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPK;         // which key row inside one wave-instruction
   const int c4 = (lane % LPK) * 4;    // this lane's 4 columns
@@ -69,18 +72,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args
     const int j = min(wave * 32 + i * KPI + sub, jmax);
     kk[i] = ld_kv(kp + (size_t)j * HD + c4);
   }
+  // VAT >= 0 (experiment knob SSRHIP_ATTN_VAT): the V rows are requested when VAT of the wave's NI K rows have been consumed — pinned with
+  // scheduling fences; -1 leaves the order to hipcc (which requests them behind the LAST K row, see below).
+  if constexpr (VAT >= 0) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < VAT; ++i) s[i] = dot4(q, kk[i], 0.f);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int j = min(wave * 32 + i * KPI + sub, jmax);
     vv[i] = ld_kv(vp + (size_t)j * HD + c4);
   }
-  // Nothing moves across this line. Without it hipcc's occupancy-driven scheduler consumed the K rows as they arrived, re-used their
-  // registers, and requested the V rows only after the LAST K row had landed (`s_waitcnt vmcnt(0)` between the 16th K and the first V
-  // request; kernel at 77 VGPRs): two dependent HBM round trips per launch where the source asks for one (read off the ISA, round 5 —
-  // rounds 1-4 believed all 2 NI loads were in flight together). With the fence the wave holds K and V (2 NI float4) at once.
-  if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+  if constexpr (VAT >= 0) __builtin_amdgcn_sched_barrier(0);
+  // What hipcc makes of the two loops above (read off the ISA, round 5; rounds 1-4 believed all 2 NI requests fly together): its
+  // occupancy-driven scheduler consumes the K rows as they arrive, re-uses their registers and requests the V rows only once the last K
+  // row has landed (77 VGPRs). Pinning all 2 NI requests in front of the first use (`sched_barrier(0)` here, 146 VGPRs) was measured on
+  // the 830M step, same box, alternating engines: 7.60 -> 7.89 us per launch, 0.8224 -> 0.8243 ms/step (profiles/r05_microbench/
+  // decode_ab.log, variants r4sched / pin) — SLOWER: with K first the score / softmax arithmetic runs under the V rows' flight, while 64 KB
+  // + 64 KB requested at once arrive together behind one CU's 64 B/clk port and leave nothing to overlap. The compiler's order stays.
 #pragma unroll
-  for (int i = 0; i < NI; ++i) s[i] = dot4(q, kk[i], 0.f);
+  for (int i = (VAT >= 0 ? VAT : 0); i < NI; ++i) s[i] = dot4(q, kk[i], 0.f);
   // reduce each s[i] over the LPK lanes of its key row (DPP row rotations + permlane16_swap: no LDS)
 #pragma unroll
   for (int i = 0; i < NI; ++i) s[i] = (LPK == 32) ? half32_sum(s[i]) : row16_sum(s[i]);
@@ -508,15 +521,22 @@ extern "C" int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t str
   for (int r0 = 0; r0 < a->R; r0 += MAX_GRID_ROWS) {
     const int n = min(a->R - r0, (int)MAX_GRID_ROWS);
     const ssrhip_attn_args s = a->R <= MAX_GRID_ROWS ? *a : row_slice(*a, r0, n);
-    dim3 grid(s.max_splits, s.kv.n_head, n);
+    int hf = 1;                                                      // SSRHIP_ATTN_HEAD_FASTEST=0: round 4's grid order (A/B knob, read per call)
+    if (const char* e = getenv("SSRHIP_ATTN_HEAD_FASTEST")) hf = e[0] != '0';
+    dim3 grid(hf ? s.kv.n_head : s.max_splits, hf ? s.max_splits : s.kv.n_head, n);
     if (s.kv.head_dim == 128) {
-      if (s.row_seq) hipLaunchKernelGGL((attn_decode_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, s);
-      else if (const char* e = getenv("SSRHIP_ATTN_PIN"); e && e[0] == '0')   // A/B knob of round 5 (tools/decode_ab.py): round 4's load schedule
-        hipLaunchKernelGGL((attn_decode_kernel<128, false, false>), grid, dim3(256), 0, (hipStream_t)stream, s);
-      else hipLaunchKernelGGL((attn_decode_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, s);
+      if (s.row_seq) hipLaunchKernelGGL((attn_decode_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
+      else {
+        int vat = -1;
+        if (const char* e = getenv("SSRHIP_ATTN_VAT")) vat = atoi(e);
+        if (vat == 4) hipLaunchKernelGGL((attn_decode_kernel<128, false, 4>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
+        else if (vat == 8) hipLaunchKernelGGL((attn_decode_kernel<128, false, 8>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
+        else if (vat == 12) hipLaunchKernelGGL((attn_decode_kernel<128, false, 12>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
+        else hipLaunchKernelGGL((attn_decode_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
+      }
     } else {
-      if (s.row_seq) hipLaunchKernelGGL((attn_decode_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, s);
-      else hipLaunchKernelGGL((attn_decode_kernel<64, false>), grid, dim3(256), 0, (hipStream_t)stream, s);
+      if (s.row_seq) hipLaunchKernelGGL((attn_decode_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
+      else hipLaunchKernelGGL((attn_decode_kernel<64, false>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
     }
     SSR_LAUNCH_CHECK();
   }

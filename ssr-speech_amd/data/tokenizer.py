@@ -124,19 +124,22 @@ def write_wav(path: str, wav: torch.Tensor, sample_rate: int) -> None:
 
 
 def convert_audio(wav: torch.Tensor, sr: int, target_sr: int, target_channels: int) -> torch.Tensor:
-    """data/tokenizer.py:82-97."""
-    assert wav.shape[0] in [1, 2], "Audio must be mono or stereo."
-    if target_channels == 1:
-        wav = wav.mean(0, keepdim=True)
-    elif target_channels == 2:
-        *shape, _, length = wav.shape
-        wav = wav.expand(*shape, target_channels, length)
-    elif wav.shape[0] == 1:
-        wav = wav.expand(target_channels, -1)
-    if sr != target_sr:
-        from .resample import resample                       # torchaudio.transforms.Resample(sr, target_sr) of the reference (:96)
-        wav = resample(wav, sr, target_sr)
-    return wav
+    """Channel layout, then sample rate (the contract of data/tokenizer.py:82-97): stereo -> mono is the mean of the two channels, mono ->
+    n channels repeats the samples (as views), anything else keeps its channels; the rate conversion is this package's GPU resampler
+    (`torchaudio.transforms.Resample(sr, target_sr)` in the reference, :96), skipped when there is nothing to convert."""
+    n_in = int(wav.shape[0])
+    if n_in not in (1, 2):
+        raise AssertionError("Audio must be mono or stereo.")
+    if n_in == 2 and target_channels == 1:
+        mixed = wav.mean(dim=0, keepdim=True)
+    elif n_in == 1 and target_channels > 1:
+        mixed = wav.expand(target_channels, wav.shape[-1])
+    else:
+        mixed = wav
+    if sr == target_sr:
+        return mixed
+    from .resample import resample
+    return resample(mixed, sr, target_sr)
 
 
 # ----------------------------------------------------------------------------- tokenizers
@@ -187,20 +190,20 @@ class AudioTokenizer:
 
 
 def tokenize_audio(tokenizer: AudioTokenizer, audio_path: str, offset=-1, num_frames=-1, multiple=320):
-    """data/tokenizer.py:141-159: load, zero-pad to a multiple of `multiple`, convert, encode."""
-    if offset != -1 and num_frames != -1:
-        wav, sr = read_wav(audio_path, frame_offset=offset, num_frames=num_frames)
-    else:
-        wav, sr = read_wav(audio_path)
-    current_length = wav.shape[-1]
-    padding_length = (multiple - (current_length % multiple)) % multiple
-    if padding_length > 0:
-        wav = F.pad(wav, (0, padding_length), "constant", 0)
-    wav = convert_audio(wav, sr, tokenizer.sample_rate, tokenizer.channels)
-    wav = wav.unsqueeze(0)
+    """File (or the window [offset, offset + num_frames) of it) -> (codes [1, K, T'], scale, emb) (data/tokenizer.py:141-159). The samples
+    are placed at the front of a zero buffer whose length is the next multiple of `multiple` (whole codec hops, before any channel /
+    rate conversion, as the reference pads), converted to the codec's layout and encoded as a batch of one."""
+    window = {"frame_offset": offset, "num_frames": num_frames} if (offset != -1 and num_frames != -1) else {}
+    samples, sr = read_wav(audio_path, **window)
+    n = int(samples.shape[-1])
+    whole = -(-n // multiple) * multiple
+    if whole != n:
+        buf = samples.new_zeros(samples.shape[:-1] + (whole,))
+        buf[..., :n] = samples
+        samples = buf
+    batch = convert_audio(samples, sr, tokenizer.sample_rate, tokenizer.channels)[None]
     with torch.no_grad():
-        encoded_frames, scale, emb = tokenizer.encode(wav)
-    return encoded_frames, scale, emb
+        return tokenizer.encode(batch)
 
 
 def split_phonemized(phonemized: str, word_sep: str = "_", phone_sep: str = "|") -> List[str]:

@@ -122,12 +122,15 @@ def run_manifest(args, model, phn2num, audio_tokenizer, device) -> list:
     world, rank = (dist.get_world_size(), dist.get_rank()) if in_group else (1, 0)
     text_tokenizer = None
     K = int(model.args.n_codebooks)
-    # pass 1 (every rank, cheap: no codec call): text ids and prompt length of every entry -> the cost-balanced plan
-    ids_all, wav_all, names, costs = [], [], [], []
+    # pass 1 (every rank, cheap: no codec call): text ids and prompt length of every entry -> the cost-balanced plan and the bound on
+    # every utterance's result length (the all-gather's fixed block layout). Only (path, samples) is kept per entry: a rank holds the
+    # waveforms of its OWN shard only (pass 2 reloads them; round 4 kept every prompt of the manifest in memory on every rank).
+    ids_all, cut_all, names, costs, caps = [], [], [], [], []
     for i, e in enumerate(entries):
         wav, sr = _prompt_16k(e["orig_audio"], args.codec_audio_sr)
         cut = float(e.get("prompt_end", args.prompt_end if args.prompt_end is not None else args.prompt_length))
         n = int(min(cut, wav.shape[-1] / sr) * sr)
+        del wav
         if "phoneme_ids" in e:
             ids = [int(v) for v in e["phoneme_ids"]]
         else:
@@ -136,27 +139,31 @@ def run_manifest(args, model, phn2num, audio_tokenizer, device) -> list:
             text = ((e.get("orig_transcript") or "") + " " + e["target_transcript"]).strip()
             ids = [phn2num[p] for p in text_tokenizer([text])[0] if p in phn2num]
         ids_all.append(ids)
-        wav_all.append((wav[:, :n], sr))
+        cut_all.append(n)
         names.append(e.get("savename", f"utt{i:05d}"))
-        costs.append(dp.utterance_cost(len(ids), (n + 319) // 320, K))
+        frames = (n + 319) // 320
+        costs.append(dp.utterance_cost(len(ids), frames, K))
+        caps.append(dp.token_cap(len(ids), frames, 1, K))
     owners = dp.balanced_shards(costs, world)
-    # pass 2: only THIS rank's utterances get their prompt written and encoded (ranks used to write — and race on — the same
+    # pass 2: only THIS rank's utterances get their prompt loaded, written and encoded (ranks used to write — and race on — the same
     # `{name}_prompt.wav` for every entry and encode all N prompts each). The file keeps the single-run flow's write -> read -> encode
     # round trip (identical prompt codes), under a per-rank name.
     utts = [None] * len(entries)
     for i in owners[rank]:
-        seg, sr = wav_all[i]
+        wav, sr = _prompt_16k(entries[i]["orig_audio"], args.codec_audio_sr)
+        seg = wav[:, :cut_all[i]]
         prompt_fn = os.path.join(work_dir, f"{names[i]}_prompt.wav" if world == 1 else f"{names[i]}_prompt.rank{rank}.wav")
         tmp_fn = prompt_fn + f".tmp{os.getpid()}"
         write_wav(tmp_fn, seg, sr)
         os.replace(tmp_fn, prompt_fn)                                  # atomic: a reader never sees a half-written file
         codes, _scale, _emb = tokenize_audio(audio_tokenizer, prompt_fn)
         frames = codes.shape[-1]
+        assert frames <= (cut_all[i] + 319) // 320, (frames, cut_all[i])   # the bound every rank computed in pass 1 holds
         utts[i] = {"x": torch.tensor(ids_all[i], dtype=torch.long).view(1, -1), "y": codes.transpose(2, 1).cpu(),
                    "mask_interval": torch.LongTensor([[[frames, frames]]]), "wav": prompt_fn}
     out_names = [f"{names[i]}_new_seed{args.seed + i}" for i in range(len(entries))]
     waves, mine, _tokens = dp.synthesize(model, audio_tokenizer, utts, seed=args.seed, use_watermark=bool(args.use_watermark), tts=True,
-                                         output_dir=args.output_dir, names=out_names, sample_rate=args.codec_audio_sr, costs=costs,
+                                         output_dir=args.output_dir, names=out_names, sample_rate=args.codec_audio_sr, costs=costs, caps=caps,
                                          top_k=args.top_k, top_p=args.top_p, temperature=args.temperature, stop_repetition=args.stop_repetition,
                                          cfg_coef=args.cfg_coef, cfg_stride=args.cfg_stride, aug_text=args.aug_text)
     assert list(mine) == list(owners[rank])

@@ -48,6 +48,19 @@ def test_balanced_shards_partition_and_balance():
     assert dp.utterance_cost(67, 150) > dp.utterance_cost(30, 150) > 0
 
 
+def _count_collectives(dist):
+    """wrap torch.distributed's collectives of THIS process so that a test can assert how many a call issued"""
+    calls = {}
+    for name in ("all_gather_into_tensor", "all_reduce", "all_gather", "broadcast", "all_to_all_single"):
+        def wrap(fn, name=name):
+            def inner(*a, **k):
+                calls[name] = calls.get(name, 0) + 1
+                return fn(*a, **k)
+            return inner
+        setattr(dist, name, wrap(getattr(dist, name)))
+    return calls
+
+
 def _tokens(i, K=4):
     g = torch.Generator().manual_seed(100 + i)
     T = 5 + (i * 7) % 11
@@ -61,8 +74,19 @@ def _worker(rank, world, port, n_total, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     s, e = dp.shard_range(n_total, world, rank)
     local = [_tokens(i) for i in range(s, e)]
-    allt = dp.gather_tokens(local, n_total, 4, pad_token=2048)
-    ok = len(allt) == n_total and all(torch.equal(allt[i], _tokens(i)) for i in range(n_total))
+    calls = _count_collectives(dist)
+    allt = dp.gather_tokens(local, n_total, 4, pad_token=2048)                       # no bound on the lengths: they travel first
+    ok = len(allt) == n_total and all(torch.equal(allt[i], _tokens(i)) for i in range(n_total)) and calls == {"all_gather_into_tensor": 2}
+    calls.clear()
+    allt = dp.gather_tokens(local, n_total, 4, pad_token=2048, caps=[16] * n_total)  # bounded lengths: ONE fixed-layout block
+    ok = ok and len(allt) == n_total and all(torch.equal(allt[i], _tokens(i)) for i in range(n_total)) and calls == {"all_gather_into_tensor": 1}
+    # a length beyond its bound on ONE rank: that rank reports failure inside the block and every rank raises — nobody hangs
+    try:
+        dp.gather_tokens(local, n_total, 4, pad_token=2048, caps=[16] * n_total if rank == 0 else [16] * (n_total - 1) + [16])
+        dp.gather_tokens([t[:, :3] for t in local] if rank == 0 else local, n_total, 4, pad_token=2048, caps=[4] * n_total)
+        ok = False
+    except RuntimeError as ex:
+        ok = ok and "rank(s) [1]" in str(ex)
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
@@ -118,8 +142,11 @@ def _gen_worker(rank, world, port, n_total, q):
     utts = _utts(n_total)
     ref = _StubModel().inference_batch(utts, seed=40, first_index=0)          # what ONE process would produce
     ok = True
+    calls = _count_collectives(dist)
     for balance in (True, False):
+        calls.clear()
         toks, (mine, outs) = dp.generate(_StubModel(), utts, seed=40, balance=balance)
+        ok = ok and calls == {"all_gather_into_tensor": 1}               # north_star: a SINGLE all-gather (no length exchange, no agreement all-reduce)
         want = _plan(n_total, world)[rank] if balance else list(range(*dp.shard_range(n_total, world, rank)))
         ok = ok and len(toks) == n_total and all(torch.equal(toks[i], ref[i][0][0]) for i in range(n_total)) and mine == want and len(outs) == len(mine) \
             and all(torch.equal(o[0], ref[gi][0]) for gi, o in zip(mine, outs))
@@ -159,11 +186,12 @@ def _fail_worker(rank, world, port, q):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     utts = _utts(6)
+    calls = _count_collectives(dist)
     try:
         dp.generate(_FailsOnRank1(), utts, seed=1)
         q.put((rank, "returned"))
     except RuntimeError as e:
-        q.put((rank, "this" if "this rank" in str(e) else "another"))
+        q.put((rank, ("this" if "on this rank" in str(e) else "another") + ("" if calls == {"all_gather_into_tensor": 1} else f" {calls}")))
     dist.barrier()                       # both ranks are still in step: nobody is stuck in the all-gather
     dist.destroy_process_group()
 

@@ -22,8 +22,12 @@ void ssrhip_set_error(const char*, ...) {}
 
 constexpr int K = 2048, TH = 512;
 
+// Round 5, modes 20 / 21 / 22 = mode 5 + a PREFETCH of the head of the NEXT launch's matrix (the first units its waves will request, same
+// geometry) with default-policy loads, so that they sit in the Infinity Cache when the next launch starts: 20 = requested right behind the
+// wave's own first units (shares the stream's bandwidth: no extra HBM bytes over the chain, the next launch's ramp is served by the
+// cache), 21 = requested behind the wave's last unit (flies under the reduction / barrier / store tail), 22 = as 20 with half the depth.
 template <int MODE>
-__global__ __launch_bounds__(TH, (MODE >= 10) ? 4 : 2) void k(const float* __restrict__ W, const float* __restrict__ x, float* __restrict__ y, int N) {
+__global__ __launch_bounds__(TH, (MODE >= 10 && MODE < 20) ? 4 : 2) void k(const float* __restrict__ W, const float* __restrict__ x, float* __restrict__ y, int N, const float* __restrict__ Wn = nullptr) {
   __shared__ float part[64 * 2 * 2];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int G = gridDim.x;
@@ -44,8 +48,9 @@ __global__ __launch_bounds__(TH, (MODE >= 10) ? 4 : 2) void k(const float* __res
     const int nu = R * 2;                        // (row, 1024-float segment) units
     const int seg = wave & 1;
     const float* Wg = W + (size_t)blockIdx.x * R * K + seg * 1024 + lane * 4;
-    constexpr int NUW = (MODE >= 10) ? 3 : 6;    // units per wave at N = 6144 (QKV): 48 units / 8 waves; two workgroups per CU: 24 / 8
-    constexpr int DEPTH = (MODE == 3 || MODE == 4) ? NUW : ((MODE == 5 || MODE == 7) ? 4 : (MODE == 6 ? 2 : 1));
+    constexpr int NUW = (MODE >= 10 && MODE < 20) ? 3 : 6;    // units per wave at N = 6144 (QKV): 48 units / 8 waves; two workgroups per CU: 24 / 8
+    constexpr int DEPTH = (MODE == 3 || MODE == 4) ? NUW : ((MODE == 5 || MODE == 7 || MODE >= 20) ? 4 : (MODE == 6 ? 2 : 1));
+    constexpr int PFD = (MODE == 20 || MODE == 21) ? 4 : (MODE == 22 ? 2 : 0);      // units of the next launch prefetched per wave
     constexpr bool XLDS = (MODE == 7 || MODE == 11);
     __shared__ __attribute__((aligned(16))) float xs[XLDS ? 2 * K : 4];
     float4 xr[2][4];
@@ -64,6 +69,14 @@ __global__ __launch_bounds__(TH, (MODE >= 10) ? 4 : 2) void k(const float* __res
     for (int j = 0; j < DEPTH; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(Wg + (size_t)(min(wave + 8 * j, nu - 1) >> 1) * K + i * 256);
+    float4 pf[PFD > 0 ? PFD : 1][4];
+    const float* Wng = Wn + (size_t)blockIdx.x * R * K + seg * 1024 + lane * 4;
+    if constexpr (MODE == 20 || MODE == 22) {
+#pragma unroll
+      for (int j = 0; j < PFD; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pf[j][i] = ld4(Wng + (size_t)(min(wave + 8 * j, nu - 1) >> 1) * K + i * 256);
+    }
     if constexpr (XLDS) {
 #pragma unroll
       for (int b = 0; b < 2; ++b) *reinterpret_cast<float4*>(xs + b * K + t * 4) = xg[b];
@@ -102,10 +115,24 @@ __global__ __launch_bounds__(TH, (MODE >= 10) ? 4 : 2) void k(const float* __res
         if (lane < 2 && u < nu) part[u * 2 + lane] = mine;
       }
     }
+    if constexpr (MODE == 21) {
+#pragma unroll
+      for (int j = 0; j < PFD; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pf[j][i] = ld4(Wng + (size_t)(min(wave + 8 * j, nu - 1) >> 1) * K + i * 256);
+    }
     if constexpr (MODE == 3) {
       y[blockIdx.x * TH + t] = tot + x[t];
     } else {
       __syncthreads();
+      if constexpr (PFD > 0) {                   // keep the prefetched registers alive to the end (never true)
+        float keep = 0.f;
+#pragma unroll
+        for (int j = 0; j < PFD; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) keep += (pf[j][i].x + pf[j][i].y) + (pf[j][i].z + pf[j][i].w);
+        if (keep == 1234.5678f) y[N * 2 + t] = keep;
+      }
       if (t < R * 2) {
         const int r = t >> 1, b = t & 1;
         y[b * N + blockIdx.x * R + r] = part[(r * 2 + 0) * 2 + b] + part[(r * 2 + 1) * 2 + b];
@@ -225,7 +252,7 @@ float run(const float* W, float* x, float* y, int N, int G, size_t wstride) {
   hipGraph_t g; hipGraphExec_t ex;
   hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
   for (int i = 0; i < 128; ++i)
-    hipLaunchKernelGGL(k<MODE>, dim3(G), dim3(TH), 0, s, W + (size_t)(i % 8) * wstride, (i & 1) ? x : y, (i & 1) ? y : x, N);
+    hipLaunchKernelGGL(k<MODE>, dim3(G), dim3(TH), 0, s, W + (size_t)(i % 8) * wstride, (i & 1) ? x : y, (i & 1) ? y : x, N, W + (size_t)((i + 1) % 8) * wstride);
   hipStreamEndCapture(s, &g);
   hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -265,6 +292,10 @@ int main() {
   printf("mode 5  4 units in flight                     %6.2f\n", run<5>(W, x, y, N, 256, wstride));
   printf("mode 6  2 units in flight                     %6.2f\n", run<6>(W, x, y, N, 256, wstride));
   printf("mode 7  4 units in flight, x via LDS          %6.2f\n", run<7>(W, x, y, N, 256, wstride));
+  printf("mode 20 mode 5 + next launch's head prefetched at entry (4 units/wave) %6.2f\n", run<20>(W, x, y, N, 256, wstride));
+  printf("mode 22 same, 2 units/wave                                            %6.2f\n", run<22>(W, x, y, N, 256, wstride));
+  printf("mode 21 prefetched behind the last unit (4 units/wave)                %6.2f\n", run<21>(W, x, y, N, 256, wstride));
+  printf("mode 5  again                                                         %6.2f\n", run<5>(W, x, y, N, 256, wstride));
   printf("mode 10 two workgroups per CU, 1 unit in flight %6.2f\n", run<10>(W, x, y, N, 512, wstride));
   printf("mode 11 same, x via LDS                       %6.2f\n", run<11>(W, x, y, N, 512, wstride));
   printf("mode 10z same on zeros                        %6.2f\n", run<10>(Wz, x, y, N, 512, wstride));
@@ -281,7 +312,7 @@ int main() {
     hipLaunchKernelGGL((k16<true, 2>), dim3(256), dim3(1024), 0, 0, W, x, y, N);
     hipMemcpy(b.data(), y, 2 * N * 4, hipMemcpyDeviceToHost);
     int bad = 0; for (int i = 0; i < 2 * N; ++i) bad += a[i] != b[i];
-    hipLaunchKernelGGL((k<10>), dim3(512), dim3(512), 0, 0, W, x, y, N);
+    hipLaunchKernelGGL((k<10>), dim3(512), dim3(512), 0, 0, W, x, y, N, W);
     hipMemcpy(b.data(), y, 2 * N * 4, hipMemcpyDeviceToHost);
     int bad2 = 0; for (int i = 0; i < 2 * N; ++i) bad2 += a[i] != b[i];
     printf("dynamic vs static: %d of %d outputs differ; mode 10 vs k16: %d differ\n", bad, 2 * N, bad2);
