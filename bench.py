@@ -539,16 +539,10 @@ def main():
         gemv_slots = [us for kind, us in slots if kind == "gemv"]
         n_gemv = len(gemv_slots)
         w_bytes = arena.nbytes_per_step() - 4 * (arena.K + 1) * arena.D      # GEMV-streamed bytes (embedding rows excluded)
-        n_fused = sum(1 for kind, _ in slots if kind == "attn+out_proj")    # layers whose attention + out-projection are ONE launch
-        if n_fused:                                                         # (csrc/attn_fused.hip): their W_o + bias leave the GEMV category
-            w_bytes -= 4 * n_fused * (arena.D * arena.D + arena.D)
         bytes_per_launch = w_bytes / n_gemv
         gemv_us_eager = sum(gemv_slots) / n_gemv
         gemv_us, n_cat = eng.time_category("gemv", 50)
-        if n_fused:
-            attn_us, fused_us = float("nan"), eng.time_category("attn+out_proj", 50)[0]
-        else:
-            attn_us, fused_us = eng.time_category("attn", 50)[0], float("nan")
+        attn_us = eng.time_category("attn", 50)[0]
         room = min(eng.max_steps - int(eng.states()[0].n_steps), eng.max_seq - int(L + T0 + eng.states()[0].n_steps)) - 8
         samp_us = eng.time_category("sample", min(50, room) - 3)[0] if room >= 10 else float("nan")   # the sampler advances the state
         assert n_cat == n_gemv
@@ -556,9 +550,7 @@ def main():
         # per-shape view of one layer (slots 0..4 = QKV, attention, out-proj, FFN1, FFN2 of layer 0.., averaged over layers)
         nl = arena.L
         ns_slots = (len(slots) - 3) // nl                 # launches per layer as the engine enqueued them
-        if 2 * U <= 4 and n_fused:
-            shape_names = ["ln1+qkv", "attn+out_proj", "ln2+ffn1", "ffn2"]
-        elif 2 * U <= 4:
+        if 2 * U <= 4:
             shape_names = ["ln1+qkv", "attn", "combine+out_proj", "ln2+ffn1", "ffn2"]
         elif ns_slots == 5:                               # > 4 rows, fused walk over the pages (ssrhip_attn_rows): no combine launch
             shape_names = ["ln1+qkv", "attn_rows", "out_proj", "ln2+ffn1", "ffn2"]
@@ -587,13 +579,12 @@ def main():
                          # for wide reads applied: 50.5 MB read + 0.1 MB written per GEMV launch vs 49.85 MB algorithmic
                          "traffic": TRAFFIC_BYTES_PER_GEMV_LAUNCH.get(2 * U) if (arena.D == 2048 and arena.L == 16) else None,
                          "traffic_source": TRAFFIC_SOURCE.get(2 * U, "not measured for this row count") + " (rocprofv3 --pmc passes of this command, gfx950 x2 FETCH_SIZE correction)",
-                         "kernel": (f"gemv_seg_kernel<2,*> (fused LN + GEMV + bias/act/residual), all {n_gemv} GEMV launches of a step" +
-                                    (f"; the {n_fused} out-projections run inside attn_outproj_kernel (attention + out-proj in one launch) and are NOT counted here" if n_fused else "")
+                         "kernel": (f"gemv_segu_kernel<2,*> / gemv_seg_kernel<2,*> (fused LN or split-KV merge + GEMV + bias/act/residual), all {n_gemv} GEMV launches of a step"
                                     if 2 * U <= 4 else
                                     f"gemv_rows_xreg_kernel / gemv_rows_stream_kernel (matrix-core GEMV, streaming-order weights), all {n_gemv} launches of a step"),
                          "bytes_per_launch": int(bytes_per_launch), "launches_per_step": n_gemv, "us_per_launch": round(gemv_us, 3),
                          "us_per_launch_eager_event_pair": round(gemv_us_eager, 3),
-                         "other_kernels_us_per_launch": {k_: round(v_, 3) for k_, v_ in (("attn_decode", attn_us), ("attn+out_proj_fused", fused_us), ("sample+embed", samp_us)) if v_ == v_},
+                         "other_kernels_us_per_launch": {k_: round(v_, 3) for k_, v_ in (("attn_decode", attn_us), ("sample+embed", samp_us)) if v_ == v_},
                          "step_level": {"bytes_per_step": int(arena.nbytes_per_step() + kv_bytes), "achieved": round(step_gbs, 1),
                                         "frac": round(step_gbs / HBM_PEAK_GBS, 4)},
                          "event_timed_us_per_launch": per_shape},

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSRHIP_VERSION 102
+#define SSRHIP_VERSION 103
 #define SSRHIP_PAGE 128          /* KV-cache page = 128 positions */
 #define SSRHIP_MAX_CODEBOOKS 4
 #define SSRHIP_MAX_SILENCE 8
@@ -132,20 +132,6 @@ int ssrhip_attn_rows(const ssrhip_attn_args* a, float* out /* [R][n_head*head_di
  * of sequence a->row_seq[seq_start[s]] (row_seq == NULL: sequence s), so a SUBSET of an engine's rows can be prefilled. */
 int ssrhip_attn_prefill(const ssrhip_attn_args* a, const int32_t* seq_start, int32_t n_seq, int32_t max_len, float* out,
                         ssrhip_stream_t stream);
-/* ssrhip_attn_decode FOLLOWED BY ssrhip_gemv(PRO_ATTN_COMBINE, EPI_RESIDUAL) — attention (activation.py:634), out_proj (:637) and the
- * residual add (transformer.py:328) of one decode layer — as ONE launch for <= 4 rows: every workgroup requests its slice of the
- * out-projection weight first, the attention partials are computed by the first workgroups and handed to all of them INSIDE the launch
- * (sharded arrival counters in `sync`, write-through stores, bounded spin), so the 17 MB weight stream and the K/V reads overlap instead
- * of waiting for each other at a kernel boundary. Bit-identical to the two-call sequence. `a` / `g` are exactly the arguments of the two
- * calls (g->x unused; g->part_o / part_ml / max_splits / row_len / kv must equal a's). `sync`: ssrhip_attn_outproj_sync_words() int32 of
- * device memory, ZERO before the first launch that uses them: arrival counters and a pass counter, all back to zero when the launch ends
- * (so consecutive launches on one stream share the block); the LAST word is set to 1 — and stays — if the bounded spin ever gave up
- * (results then undefined).
- * ssrhip_attn_outproj_supported() != 0 tells whether the shapes qualify (B in {1,2,4}, N == K == n_head * head_dim == 2048,
- * head_dim in {64,128}, row-major operands, no row_seq); otherwise issue the two calls. */
-int ssrhip_attn_outproj_supported(const ssrhip_attn_args* a, const ssrhip_gemv_args* g);
-int ssrhip_attn_outproj_sync_words(void);
-int ssrhip_attn_outproj(const ssrhip_attn_args* a, const ssrhip_gemv_args* g, int32_t* sync, ssrhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Token embedding + sinusoidal position: replaces embed_y (models/ssr.py:191-198, :655-660, :757-761),
@@ -385,8 +371,6 @@ typedef struct ssrhip_lm_buffers {      /* caller-allocated device workspaces */
   ssrhip_kv kv;
   ssrhip_sampler_cfg* cfg; ssrhip_sampler_state* state;
   const float* noise; int32_t* generated; float* dbg_logits;
-  int32_t* sync;   /* optional (NULL = the two-launch path): ssrhip_attn_outproj_sync_words() int32, zero-initialised by the caller once —
-                      hand-off counters of the fused attention + out-projection launch, shared by all layers; last word != 0 = a spin gave up */
 } ssrhip_lm_buffers;
 
 typedef struct ssrhip_lm ssrhip_lm;     /* opaque host-side object (graph + launch descriptors) */

@@ -138,7 +138,7 @@ class LMBuffers(C.Structure):
                 ("part_o", C.c_void_p), ("part_ml", C.c_void_p),
                 ("next_tok", C.c_void_p), ("next_pos", C.c_void_p), ("kv_pos", C.c_void_p), ("row_len", C.c_void_p),
                 ("kv", KV), ("cfg", C.c_void_p), ("state", C.c_void_p),
-                ("noise", C.c_void_p), ("generated", C.c_void_p), ("dbg_logits", C.c_void_p), ("sync", C.c_void_p)]
+                ("noise", C.c_void_p), ("generated", C.c_void_p), ("dbg_logits", C.c_void_p)]
 
 
 class PrefillArgs(C.Structure):
@@ -160,9 +160,6 @@ SYMBOLS = [
     ("ssrhip_attn_combine", C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_void_p]),
     ("ssrhip_attn_rows", C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_void_p]),
     ("ssrhip_attn_prefill", C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    ("ssrhip_attn_outproj_supported", C.c_int, [C.POINTER(AttnArgs), C.POINTER(GemvArgs)]),
-    ("ssrhip_attn_outproj_sync_words", C.c_int, []),
-    ("ssrhip_attn_outproj", C.c_int, [C.POINTER(AttnArgs), C.POINTER(GemvArgs), C.c_void_p, C.c_void_p]),
     ("ssrhip_embed", C.c_int, [C.POINTER(EmbedArgs), C.c_void_p]),
     ("ssrhip_sample", C.c_int, [C.POINTER(SampleArgs), C.c_void_p]),
     ("ssrhip_gemm", C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),

@@ -72,8 +72,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args
     const int j = min(wave * 32 + i * KPI + sub, jmax);
     kk[i] = ld_kv(kp + (size_t)j * HD + c4);
   }
-  // VAT >= 0 (experiment knob SSRHIP_ATTN_VAT): the V rows are requested when VAT of the wave's NI K rows have been consumed — pinned with
-  // scheduling fences; -1 leaves the order to hipcc (which requests them behind the LAST K row, see below).
+  // VAT >= 0: the V rows are requested when VAT of the wave's NI K rows have been consumed — pinned with scheduling fences; -1 leaves the
+  // order to hipcc (which keeps ~10 K requests in flight and asks for the V rows behind the LAST K row, see below). Measured at head_dim
+  // 128 on the 830M step, same box, alternating engines (profiles/r05_microbench/decode_ab_attn_vat.log): hipcc 6.84 us per launch,
+  // VAT 4 / 8 / 12: 6.69 / 6.45 / 6.56 — all 16 K rows in flight from the start and the V rows' flight under the second half of the
+  // score arithmetic. The decode step takes VAT = 8 (0.8095 -> 0.8033 ms/step); same arithmetic in the same order: identical tokens.
   if constexpr (VAT >= 0) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -527,12 +530,12 @@ extern "C" int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t str
     if (s.kv.head_dim == 128) {
       if (s.row_seq) hipLaunchKernelGGL((attn_decode_kernel<128, true>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
       else {
-        int vat = -1;
+        int vat = 8;                                                 // SSRHIP_ATTN_VAT = -1 | 4 | 12: A/B knob (profiles/r05_microbench/decode_ab_attn_vat.log), read per call
         if (const char* e = getenv("SSRHIP_ATTN_VAT")) vat = atoi(e);
         if (vat == 4) hipLaunchKernelGGL((attn_decode_kernel<128, false, 4>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
-        else if (vat == 8) hipLaunchKernelGGL((attn_decode_kernel<128, false, 8>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
         else if (vat == 12) hipLaunchKernelGGL((attn_decode_kernel<128, false, 12>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
-        else hipLaunchKernelGGL((attn_decode_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
+        else if (vat < 0) hipLaunchKernelGGL((attn_decode_kernel<128, false>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
+        else hipLaunchKernelGGL((attn_decode_kernel<128, false, 8>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);
       }
     } else {
       if (s.row_seq) hipLaunchKernelGGL((attn_decode_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, s, hf);

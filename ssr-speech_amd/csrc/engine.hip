@@ -55,13 +55,11 @@ struct ssrhip_lm {
   hipStream_t cap_stream = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  bool fuse_attn = false;     // SSRHIP_FUSE_ATTN=1: attention + out-projection as ONE launch (csrc/attn_fused.hip). Off by default: measured
-                              // 17.9 us against 7.6 + 7.1 us for the two launches (the in-launch hand-off costs what a boundary costs)
 };
 
 namespace {
 
-enum { CAT_GEMV = 0, CAT_ATTN = 1, CAT_SAMPLE = 2, CAT_FUSED = 3 };
+enum { CAT_GEMV = 0, CAT_ATTN = 1, CAT_SAMPLE = 2 };
 
 bool getenv_flag(const char* name) {      // tuning / A-B knobs, read once per process
   const char* e = getenv(name);
@@ -138,11 +136,6 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.pro = SSRHIP_PRO_ATTN_COMBINE; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_RESIDUAL;
     g.part_o = b.part_o; g.part_ml = b.part_ml; g.max_splits = b.max_splits; g.row_len = b.row_len;
     g.kv = b.kv;
-    // <= 4 rows at the 830M width: attention and out-projection in ONE launch (attn_fused.hip), bit-identical to the two below.
-    if (lm->fuse_attn && b.sync && B <= 4 && ssrhip_attn_outproj_supported(&at, &g)) {
-      STEP_CALL(CAT_FUSED, ssrhip_attn_outproj(&at, &g, b.sync, s));
-      goto ffn;
-    }
     if (fused_attn) {
       at.out_tiled = 1;
       STEP_CALL(CAT_ATTN, ssrhip_attn_rows(&at, b.h, s));
@@ -162,7 +155,6 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
       if (wt) { g.W = w.out_proj_wt[l]; g.w_tiled = 1; }
     }
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
-  ffn:
 
     // LN2 + FFN1 + ReLU
     memset(&g, 0, sizeof(g));
@@ -234,7 +226,6 @@ extern "C" int ssrhip_lm_create(const ssrhip_lm_dims* d, const ssrhip_lm_weights
               (long long)b->kv.max_pages * SSRHIP_PAGE, d->max_pos);
   ssrhip_lm* lm = new ssrhip_lm();
   lm->d = *d; lm->w = *w; lm->b = *b;
-  { const char* e = getenv("SSRHIP_FUSE_ATTN"); lm->fuse_attn = e && e[0] && e[0] != '0'; }
   // deep-copy the per-layer pointer arrays (the caller's ctypes arrays may be temporaries)
   const float* const** fields[12] = {&lm->w.ln1_w, &lm->w.ln1_b, &lm->w.in_proj_w, &lm->w.in_proj_b, &lm->w.out_proj_w, &lm->w.out_proj_b,
                                      &lm->w.ln2_w, &lm->w.ln2_b, &lm->w.ffn1_w, &lm->w.ffn1_b, &lm->w.ffn2_w, &lm->w.ffn2_b};
@@ -325,7 +316,7 @@ extern "C" int ssrhip_lm_time_steps(ssrhip_lm* lm, int32_t n_steps, ssrhip_strea
 
 extern "C" int ssrhip_lm_time_category(ssrhip_lm* lm, int32_t category, int32_t n_replays, ssrhip_stream_t stream, float* out_us_per_launch,
                                        int32_t* out_launches_per_step) {
-  SSR_REQUIRE(lm && category >= 0 && category <= CAT_FUSED && n_replays > 0 && out_us_per_launch && out_launches_per_step,
+  SSR_REQUIRE(lm && category >= 0 && category <= CAT_SAMPLE && n_replays > 0 && out_us_per_launch && out_launches_per_step,
               "ssrhip_lm_time_category: bad argument");
   hipStream_t s = (hipStream_t)stream;
   Timer tm;

@@ -516,7 +516,7 @@ template <int B> struct SegCS { static constexpr int v = (B <= 2) ? 6 : 2; };   
 // TWO: every wave owns at most two units (rows_max * S <= 16: the out-projection at one workgroup per CU, head-MLP1): BOTH are requested at
 // kernel entry instead of the second one being re-requested in place after the first was used. For the out-projection the first use comes
 // only after the split-KV merge prologue (a dependent L2 round trip + exp + two barriers), so the in-place form started its second HBM
-// round trip ~2 us into the kernel (tools/fused_prof.py shows the same prologue inside the fused launch); with both in flight from the
+// round trip ~2 us into the kernel (round 4's time stamps of the same prologue: tools/attn_fused_lab); with both in flight from the
 // start the whole 64 KB slice of the workgroup lands under the prologue. Same arithmetic per unit: bit-identical results.
 // (the merge-prologue variant with two units at entry runs at ONE workgroup per CU — try_seg — so it may take up to 256 VGPRs: at 128 it spilled)
 template <int B, int PRO, bool TWO>

@@ -358,7 +358,6 @@ class DecodeEngine:
         self.logits = torch.zeros(self.B, K, arena.card, **f32)
         self.part_o = torch.zeros(self.B * H * self.max_pages * self.hd, **f32)
         self.part_ml = torch.zeros(self.B * H * self.max_pages * 2, **f32)
-        self.sync = torch.zeros(self.lib.ssrhip_attn_outproj_sync_words(), **i32)        # hand-off counters of the fused attention + out-projection launch (csrc/attn_fused.hip)
         self.next_tok = torch.zeros(self.B, MAX_CODEBOOKS, **i32)
         self.next_pos = torch.zeros(self.B, **i32)
         self.kv_pos = torch.zeros(self.B, **i32)
@@ -397,7 +396,6 @@ class DecodeEngine:
         b.noise = self.noise.data_ptr()
         b.generated = self.generated.data_ptr()
         b.dbg_logits = self.dbg_logits.data_ptr() if self.dbg_logits is not None else 0
-        b.sync = self.sync.data_ptr()
         d = self.a.dims()
         ctx = C.c_void_p()
         _lib.check(self.lib.ssrhip_lm_create(C.byref(d), C.byref(self._w), C.byref(b), C.byref(ctx)), "ssrhip_lm_create")
@@ -845,7 +843,7 @@ class DecodeEngine:
         n = self.lib.ssrhip_lm_time_steps(self._ctx, int(n_steps), _lib.stream_ptr(), us, kind, n_out)
         if n < 0:
             _lib.check(n, "ssrhip_lm_time_steps")
-        names = ("gemv", "attn", "sample", "attn+out_proj")
+        names = ("gemv", "attn", "sample")
         return [(names[kind[i]], float(us[i])) for i in range(n)]
 
     def time_category(self, kind: str, n_replays: int = 50):
@@ -856,6 +854,6 @@ class DecodeEngine:
         if kind == "sample":                     # the sampler advances the positions on every replay (3 warm-up replays inside)
             self._steps_enqueued += int(n_replays) + 3
             self._grow_pages(self._steps_enqueued)
-        _lib.check(self.lib.ssrhip_lm_time_category(self._ctx, ("gemv", "attn", "sample", "attn+out_proj").index(kind), int(n_replays),
+        _lib.check(self.lib.ssrhip_lm_time_category(self._ctx, ("gemv", "attn", "sample").index(kind), int(n_replays),
                                                     _lib.stream_ptr(), C.byref(us), C.byref(n)), "ssrhip_lm_time_category")
         return float(us.value), int(n.value)

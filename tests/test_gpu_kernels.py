@@ -371,72 +371,6 @@ def test_gemv_seg_combine_and_qkv_append_at_2048(L, B, max_pages):
         want = y0 + F.linear(att.double(), Wo.double(), bo.double()).float()
         torch.testing.assert_close(dy.cpu(), want, rtol=3e-5, atol=3e-5)
 
-@pytest.mark.parametrize("hd", [128, 64])
-@pytest.mark.parametrize("max_pages", [10, 6, 3, 1])
-@pytest.mark.parametrize("B", [1, 2, 4])
-def test_attn_outproj_fused_equals_two_launches(L, B, max_pages, hd):
-    """ssrhip_attn_outproj (attention + out-projection + residual in ONE launch, hand-off through sharded arrival counters inside the
-    launch) against the two launches it replaces: BIT-IDENTICAL y and partials, for contexts of 1..10 pages (more than the 6 prefetched
-    by the merge; at 4 rows x 10 pages x 32 heads more items than workgroups), ragged row lengths, and five launches in a row on ONE
-    16-word sync block (the last workgroup through re-zeroes it). Also against the fp64 reference."""
-    g = torch.Generator().manual_seed(400 + 10 * B + max_pages + hd)
-    D = 2048
-    H, n_layer, layer = D // hd, 2, 1
-    cap = max_pages * _lib.PAGE
-    pool, table = _make_cache(B, max_pages, n_layer, H, hd, g)
-    dpool, dtable = dev(pool), dev(table)
-    sync_words = torch.zeros(L.ssrhip_attn_outproj_sync_words(), dtype=torch.int32, device="cuda")
-    Wo = torch.randn(D, D, generator=g) / math.sqrt(D)
-    bo = torch.randn(D, generator=g)
-    dWo, dbo = dev(Wo), dev(bo)
-    for it, lens in enumerate(([1000, 129, 1, 640], [5, 1024, 900, 257], [cap, cap - 1, cap, 1], [cap, cap, cap, cap], [300, 310, 290, 305])):
-        lens = [max(1, min(v, cap)) for v in lens[:B]]
-        q = torch.randn(B, D, generator=g)
-        y0 = torch.randn(B, D, generator=g)
-        dlen, dq = dev(torch.tensor(lens, dtype=torch.int32)), dev(q)
-        outs = []
-        for fused in (0, 1):
-            part_o = torch.full((B * H * max_pages * hd,), float("nan"), device="cuda")
-            part_ml = torch.full((B * H * max_pages * 2,), float("nan"), device="cuda")
-            dy = dev(y0.clone())
-            at = _lib.AttnArgs()
-            at.q, at.q_stride = dq.data_ptr(), 0
-            at.kv = _lib.KV(dpool.data_ptr(), dtable.data_ptr(), max_pages, n_layer, H, hd)
-            at.layer, at.row_seq, at.row_len, at.R, at.max_splits = layer, 0, dlen.data_ptr(), B, max_pages
-            at.scale, at.part_o, at.part_ml = 1.0 / math.sqrt(hd), part_o.data_ptr(), part_ml.data_ptr()
-            ga = _lib.GemvArgs()
-            ga.W, ga.bias, ga.y, ga.B, ga.N, ga.K, ga.groups, ga.x_stride, ga.y_stride = dWo.data_ptr(), dbo.data_ptr(), dy.data_ptr(), B, D, D, 1, D, D
-            ga.pro, ga.act, ga.epi = _lib.PRO_ATTN_COMBINE, 0, _lib.EPI_RESIDUAL
-            ga.part_o, ga.part_ml, ga.max_splits, ga.row_len, ga.kv = part_o.data_ptr(), part_ml.data_ptr(), max_pages, dlen.data_ptr(), at.kv
-            if fused:
-                assert L.ssrhip_attn_outproj_supported(C.byref(at), C.byref(ga)) == 1
-                _lib.check(L.ssrhip_attn_outproj(C.byref(at), C.byref(ga), sync_words.data_ptr(), _lib.stream_ptr()))
-            else:
-                _lib.check(L.ssrhip_attn_decode(C.byref(at), _lib.stream_ptr()))
-                _lib.check(L.ssrhip_gemv(C.byref(ga), _lib.stream_ptr()))
-            sync()
-            outs.append((dy.cpu(), part_o.cpu(), part_ml.cpu()))
-        assert not sync_words.cpu().any(), (it, sync_words.cpu().nonzero().flatten().tolist())       # counters back to zero, no give-up
-        (y_two, po_two, ml_two), (y_one, po_one, ml_one) = outs
-        live = ~torch.isnan(po_two)
-        assert torch.equal(torch.isnan(po_one), torch.isnan(po_two)) and torch.equal(po_one[live], po_two[live])
-        live = ~torch.isnan(ml_two)
-        assert torch.equal(torch.isnan(ml_one), torch.isnan(ml_two)) and torch.equal(ml_one[live], ml_two[live])
-        assert torch.equal(y_one, y_two), (it, float((y_one - y_two).abs().max()))
-        att = torch.zeros(B, D)
-        for r, ln in enumerate(lens):
-            for h in range(H):
-                k = _gather(pool, table, r, layer, 0, h, ln)
-                v = _gather(pool, table, r, layer, 1, h, ln)
-                att[r, h * hd:(h + 1) * hd] = F.scaled_dot_product_attention(q[r, h * hd:(h + 1) * hd].view(1, 1, 1, hd), k.view(1, 1, ln, hd), v.view(1, 1, ln, hd)).view(-1)
-        want = y0 + F.linear(att.double(), Wo.double(), bo.double()).float()
-        torch.testing.assert_close(y_one, want, rtol=3e-5, atol=3e-5)
-    # shapes outside the fused kernel's contract are refused, not mis-computed
-    ga.N = 1024
-    assert L.ssrhip_attn_outproj_supported(C.byref(at), C.byref(ga)) == 0
-    assert L.ssrhip_attn_outproj(C.byref(at), C.byref(ga), sync_words.data_ptr(), _lib.stream_ptr()) != 0
-
-
 # ------------------------------------------------------------------------------------------ attention
 def _make_cache(n_seq, max_pages, n_layer, H, hd, g):
     n_pages = n_seq * max_pages

@@ -134,22 +134,6 @@ def test_segment_kernel_prologue_has_no_integer_division(gemv_asm):
         assert not any("v_rcp_iflag_f32" in l for l in lines[:first]), sym          # the signature of an emulated integer division
 
 
-def test_fused_attention_outproj_keeps_its_contract_in_the_isa(tmp_path_factory):
-    """csrc/attn_fused.hip: no scratch, <= 256 VGPRs (one 8-wave workgroup per CU), write-through (sc1) partial stores, an explicit
-    vmcnt(0) drain in front of the arrival atomic, and NO cache invalidate on the default path that is not behind the A/B flag branch."""
-    asm = _asm(tmp_path_factory, "attn_fused")
-    meta = {k: v for k, v in _kernel_meta(asm).items() if "attn_outproj_kernel" in k}
-    assert len(meta) == 6, sorted(meta)
-    for sym, (vgpr, scratch) in meta.items():
-        # (the 4-row variants keep one 32-byte stack object — the per-row length arrays — and spill nothing)
-        assert vgpr <= 256 and scratch <= (32 if "ILi4E" in sym else 0), (sym, vgpr, scratch)
-        body = _body(asm, sym)
-        assert re.search(r"global_store_dword [^\n]* sc1", body), sym
-        pos = re.search(r"global_store_dword [^\n]* sc1", body).end()  # the first item's partial stores ...
-        i = body.index("global_atomic_add", pos)                        # ... are drained before its arrival atomic
-        assert "s_waitcnt vmcnt(0)" in body[pos:i], sym
-
-
 def test_split_gemm_drains_its_dma_before_the_tile_barrier(tmp_path_factory):
     """gemm_split_dma_kernel: W tiles arrive in LDS by DMA issued by OTHER waves; the k-loop must wait for its own DMA (vmcnt(0)) before the
     barrier that publishes the tile (until round 4 only the compiler's conservative wait placement guaranteed it)."""
