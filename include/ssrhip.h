@@ -389,8 +389,16 @@ typedef struct ssrhip_prefill_args {
   /* optional (NULL/0 = per-row attention through part_o / part_ml): the rows of sequence s are seq_start[s] .. seq_start[s+1]-1,
    * in position order -> the tiled prefill attention (ssrhip_attn_prefill); part_o / part_ml may then be NULL */
   const int32_t* seq_start; int32_t n_seq, max_len;
+  /* two-phase admission (continuous batching: a new utterance is prefilled on a SIDE stream while the graph keeps stepping the live rows):
+   * `table` != NULL replaces the engine's page table for THIS prefill (same layout) — the rows being filled are still parked on the
+   * scratch page in the table the decode step reads; `no_embed` != 0 skips the closing embedding of the rows' pending tokens into the
+   * residual stream (it is live decode state): the caller issues ssrhip_lm_embed_pending on the decode stream when it activates the rows. */
+  const int32_t* table; int32_t no_embed, reserved_;
 } ssrhip_prefill_args;
 int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ssrhip_stream_t stream);
+/* x[b] = embedding of row b's pending input token (next_tok / next_pos) for EVERY row of the engine — the closing step of ssrhip_lm_prefill
+ * on its own (rows in mid-decode get exactly what the sampler's fused embedding left there: same function, same inputs). */
+int ssrhip_lm_embed_pending(ssrhip_lm* lm, ssrhip_stream_t stream);
 
 /* run `n_steps` eager decode steps with a hipEvent pair around EVERY kernel launch (bench.py roofline).
  * out_us[i] = average microseconds of launch slot i of a step, out_kind[i] = 0 gemv | 1 attention | 2 sampler | 3 fused attention + out-proj;

@@ -147,7 +147,8 @@ class PrefillArgs(C.Structure):
                 ("R", C.c_int32), ("max_splits", C.c_int32),
                 ("x", C.c_void_p), ("xn", C.c_void_p), ("qkv", C.c_void_p), ("o", C.c_void_p), ("h", C.c_void_p),
                 ("part_o", C.c_void_p), ("part_ml", C.c_void_p),
-                ("seq_start", C.c_void_p), ("n_seq", C.c_int32), ("max_len", C.c_int32)]
+                ("seq_start", C.c_void_p), ("n_seq", C.c_int32), ("max_len", C.c_int32),
+                ("table", C.c_void_p), ("no_embed", C.c_int32), ("reserved_", C.c_int32)]
 
 
 # every symbol include/ssrhip.h declares: (name, restype, argtypes)
@@ -178,6 +179,7 @@ SYMBOLS = [
     ("ssrhip_lm_destroy", None, [C.c_void_p]),
     ("ssrhip_lm_decode", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("ssrhip_lm_prefill", C.c_int, [C.c_void_p, C.POINTER(PrefillArgs), C.c_void_p]),
+    ("ssrhip_lm_embed_pending", C.c_int, [C.c_void_p, C.c_void_p]),
     ("ssrhip_lm_time_steps", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, c_f32p, c_i32p, C.c_int32]),
     ("ssrhip_lm_time_category", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, c_f32p, c_i32p]),
 ]

@@ -360,6 +360,8 @@ extern "C" int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ss
   const ssrhip_lm_weights& w = lm->w;
   const int D = d.d_model, R = p->R;
   hipStream_t s = (hipStream_t)stream;
+  ssrhip_kv kv = lm->b.kv;
+  if (p->table) kv.table = p->table;              // two-phase admission: the rows being filled are not in the decode step's table yet
 
   ssrhip_embed_args ea;
   memset(&ea, 0, sizeof(ea));
@@ -377,11 +379,11 @@ extern "C" int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ss
     g.M = R; g.N = 3 * D; g.K = D; g.lda = D; g.ldc = 3 * D;
     if (lm->prefill_split) g.W_split = w.in_proj_ws[l];
     if (int rc = ssrhip_gemm(&g, s)) return rc;
-    if (int rc = ssrhip_kv_scatter(p->qkv, &lm->b.kv, l, p->row_seq, p->row_pos, R, s)) return rc;
+    if (int rc = ssrhip_kv_scatter(p->qkv, &kv, l, p->row_seq, p->row_pos, R, s)) return rc;
 
     ssrhip_attn_args at;
     memset(&at, 0, sizeof(at));
-    at.kv = lm->b.kv; at.layer = l; at.row_seq = p->row_seq; at.row_len = p->row_len;
+    at.kv = kv; at.layer = l; at.row_seq = p->row_seq; at.row_len = p->row_len;
     at.R = R; at.max_splits = p->max_splits; at.scale = 1.0f / sqrtf((float)(D / d.n_head));
     at.part_o = p->part_o; at.part_ml = p->part_ml;
     at.q = p->qkv; at.q_stride = 3 * D;   // q is the first third of each packed qkv row
@@ -411,8 +413,19 @@ extern "C" int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ss
     if (lm->prefill_split) g.W_split = w.ffn2_ws[l];
     if (int rc = ssrhip_gemm(&g, s)) return rc;
   }
+  if (p->no_embed) return 0;
+  return ssrhip_lm_embed_pending(lm, stream);
+}
+
+extern "C" int ssrhip_lm_embed_pending(ssrhip_lm* lm, ssrhip_stream_t stream) {
+  SSR_REQUIRE(lm, "ssrhip_lm_embed_pending: null argument");
+  const ssrhip_lm_dims& d = lm->d;
+  const ssrhip_lm_weights& w = lm->w;
+  const int D = d.d_model;
+  hipStream_t s = (hipStream_t)stream;
   // x of the first decode step: the rows' pending input tokens (the span-0 mask token, ssr.py:655-662)
   const ssrhip_lm_buffers& b = lm->b;
+  ssrhip_embed_args ea;
   memset(&ea, 0, sizeof(ea));
   ea.text_emb = w.text_emb; ea.audio_emb = w.audio_emb; ea.pe = w.pe;
   ea.alpha_text = w.alpha_text; ea.alpha_audio = w.alpha_audio;

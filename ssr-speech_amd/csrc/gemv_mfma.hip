@@ -24,6 +24,17 @@ namespace {
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
+// Phase time stamps of the rows-per-workgroup kernels exist only in a -DSSR_GEMVM_PROFILE build (tools/gemvm_lab.hip includes this file
+// with it): wave 0 of every workgroup leaves wall_clock64 (100 MHz) at: 0 entry, 6 x requests issued, 7 first weight requests issued, 1 x
+// has arrived (and the epilogue operands are requested), 2 LayerNorm done, 3 last MFMA issued, 4 behind the partial-tile barrier, 5
+// epilogue stores issued. Nothing of this is in the library build.
+#ifdef SSR_GEMVM_PROFILE
+__device__ long long* g_gemvm_prof = nullptr;
+#define MSTAMP(i) do { if (g_gemvm_prof && threadIdx.x == 0) g_gemvm_prof[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define MSTAMP(i) do { } while (0)
+#endif
+
 struct GemvM {
   ssrhip_gemv_args a;
   int nw;       // waves per workgroup
@@ -53,23 +64,39 @@ struct TileEpi {
   float* dst;
   float bias[4], res[4];
   int nvalid;        // 0: this lane stores nothing
+  int kv_which, kv_cc, kv_pos, kv_page;   // QKV launch, K / V rows (kv_which = 1 | 2): dst is resolved in tile_epilogue_finish
 };
 
-__device__ __forceinline__ TileEpi tile_epilogue_fetch(const ssrhip_gemv_args& a, int hd, int grp, int row0, int tile_rows, int lane) {
+// kv_pos of this lane's batch column for the QKV launch (0 otherwise): request it BEFORE the x / W loads (see tile_epilogue_fetch)
+__device__ __forceinline__ int tile_kvpos(const ssrhip_gemv_args& a, int lane) {
+  return (a.epi == SSRHIP_EPI_QKV_APPEND) ? a.kv_pos[min(lane & 15, a.B - 1)] : 0;
+}
+
+__device__ __forceinline__ TileEpi tile_epilogue_fetch(const ssrhip_gemv_args& a, int hd, int grp, int row0, int tile_rows, int lane, int kvpos) {
   TileEpi e;
   const int c = lane & 15, ks = lane >> 4;
   const int N = a.N, K = a.K, B = a.B;
   const int r0 = row0 + ks * 4;
   e.dst = nullptr;
-  e.nvalid = 0;
+  e.kv_which = 0; e.kv_cc = 0; e.kv_pos = kvpos; e.kv_page = 0;
+  // QKV launch: the address of a K / V row needs kv_pos[c] -> page table -> pool, two DEPENDENT loads. `kvpos` was requested by the caller
+  // as the wave's OLDEST load (in front of x and W); the table entry is requested here by EVERY lane (branch-free: q rows and idle lanes
+  // read a valid entry they never use) and first used in tile_epilogue_finish — so neither wait drains anything. Rounds 2-4 requested
+  // both here, back to back, under the lane's row predicate: each was followed by `s_waitcnt vmcnt(0)`, i.e. every wave of the LN + QKV
+  // launch drained its x slice and its first 16 weight loads — twice — before the LayerNorm could start; and a load under a divergent
+  // branch makes hipcc wait for it (`vmcnt(0)`) in the OTHER branch before it may reuse the destination register (read off the ISA,
+  // round 5; the 2-row kernel had the same disease, csrc/gemv.hip).
+  if (a.epi == SSRHIP_EPI_QKV_APPEND) e.kv_page = a.kv.table[(size_t)min(c, B - 1) * a.kv.max_pages + (kvpos / SSRHIP_PAGE)];
+  const bool live = c < B && r0 < N && ks * 4 < tile_rows;
+  e.nvalid = live ? min(4, N - r0) : 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { e.bias[j] = 0.f; e.res[j] = 0.f; }
-  if (c >= B || r0 >= N || ks * 4 >= tile_rows) return e;
-  e.nvalid = min(4, N - r0);
+  if (!live) return e;
   if (a.epi == SSRHIP_EPI_QKV_APPEND) {
     const int D = K, which = r0 / D, cc = r0 % D;
-    if (which == 0) e.dst = a.y + (size_t)c * a.y_stride + cc;
-    else e.dst = kv_addr(a.kv, c, a.layer, which - 1, cc / hd, a.kv_pos[c]) + (cc % hd);
+    e.kv_which = which;                                                // 0: a q row (plain store below); 1 | 2: resolved in tile_epilogue_finish
+    e.kv_cc = cc;
+    e.dst = a.y + (size_t)c * a.y_stride + cc;
   } else if (a.y_tiled) {
     e.dst = a.y + (size_t)grp * N * 16 + SSRHIP_TILED(c, r0);
   } else {
@@ -85,8 +112,13 @@ __device__ __forceinline__ TileEpi tile_epilogue_fetch(const ssrhip_gemv_args& a
   return e;
 }
 
-__device__ __forceinline__ void tile_epilogue_finish(const ssrhip_gemv_args& a, const TileEpi& e, f4v acc) {
-  if (e.nvalid == 0) return;
+__device__ __forceinline__ void tile_epilogue_finish(const ssrhip_gemv_args& a, const TileEpi& e0, f4v acc, int hd) {
+  if (e0.nvalid == 0) return;
+  TileEpi e = e0;
+  if (e.kv_which) {
+    const size_t off = ((((size_t)e.kv_page * a.kv.n_layer + a.layer) * 2 + (e.kv_which - 1)) * a.kv.n_head + e.kv_cc / hd) * SSRHIP_PAGE + (e.kv_pos % SSRHIP_PAGE);
+    e.dst = a.kv.pool + off * a.kv.head_dim + (e.kv_cc % hd);
+  }
   float v[4] = {acc[0], acc[1], acc[2], acc[3]};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -105,8 +137,8 @@ __device__ __forceinline__ void tile_epilogue_finish(const ssrhip_gemv_args& a, 
 }
 
 __device__ __forceinline__ void tile_epilogue(const ssrhip_gemv_args& a, int hd, int grp, int row0, int tile_rows, int lane, f4v acc) {
-  const TileEpi e = tile_epilogue_fetch(a, hd, grp, row0, tile_rows, lane);
-  tile_epilogue_finish(a, e, acc);
+  const TileEpi e = tile_epilogue_fetch(a, hd, grp, row0, tile_rows, lane, tile_kvpos(a, lane));
+  tile_epilogue_finish(a, e, acc, hd);
 }
 
 template <int PRO>
@@ -238,9 +270,26 @@ struct GemvR {
   int units;    // ceil(N / 8) 8-row units per group
   int wgs;      // workgroups per group (gridDim.x)
   int hd;
+  int xfirst;   // 1: the weights are requested only when the wave's x slice has ARRIVED (see below)
 };
 
 constexpr int MAXT = 4;     // 16-row tiles per workgroup (LDS: MAXT x 8 waves x 1 KiB of partial sums)
+
+// x and the LayerNorm BEFORE the weights (round 5; `xfirst` in the kernel parameters, SSRHIP_GEMVM_XFIRST=0 = round 4's order). What the
+// stamps of tools/gemvm_lab.hip showed on an LN + QKV launch at 16 rows (us after entry, median over 256 workgroups, wave 0):
+//     round 4's order:  x requested 1.1 | first 16 weight requests POSTED 5.1 | x seen 6.6 | LayerNorm done 8.4 | last MFMA 12.1 | end 15.2
+//     xfirst:           x requested 1.1 | x seen 1.7 | LayerNorm done 3.7 | weight requests posted 7.2 | last MFMA 12.6 | end 15.5
+// i.e. (1) the broadcast of x is NOT slow — 128 KB are in the registers of all eight waves 1.7 us after entry when nothing is queued in
+// front of them (tools/xbcast_lab.hip: 1.5 us for every CU reading the same 128 KB behind a kernel boundary); (2) POSTING 16 KB of weight
+// requests per wave takes 3.5-4 us in either order: a CU accepts HBM misses only at the rate earlier ones return (~36 GB/s), the wave is
+// in-order, so in round 4's order it sits in the request phase with its x long arrived, and the LayerNorm barrier waits for the slowest
+// wave to get through; (3) a bare s_barrier between the two request phases (all x requests in front of all weight requests) changed
+// nothing, and waiting for x without moving the LayerNorm did not either. With the LayerNorm in front of the weight requests the chain
+// x -> statistics -> barrier -> normalise runs while nothing else is queued, and the matrix work starts 1.1 us earlier (7.2 vs 8.3) on a
+// stream that started 2.6 us later: a wash inside one launch (gemvm_bench: 966.6 vs 980.0 us per step's GEMVs), slightly ahead in the
+// step. What a 16-row launch pays over the chain floor (9.5 us for 50 MB) is therefore: ~1 us to request x, ~4 us of a stream that runs at
+// 4.6-5.6 TB/s instead of 7.3 while the waves alternate between blocked request phases and matrix work, and ~3 us of tail (the slowest of
+// the eight K-slice waves reaches the partial-tile barrier 2 us after wave 0; merge + epilogue 1.1 us).
 
 __device__ __forceinline__ f4v mfma4(float a, float b, f4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -280,30 +329,44 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
   const unsigned xvoff = a.x_tiled ? (unsigned)(ks * 16 + c) * 4 : (unsigned)min(c, B - 1) * (unsigned)a.x_stride + ks * 4;
   const int xstep = a.x_tiled ? 256 : 16;
 
+  MSTAMP(0);
   float4 w[DEP];
   float4 xr[SPWX];
+  const int kvpos = tile_kvpos(a, lane);                                // the wave's oldest load (QKV launch only)
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = 0; t < SPWX; ++t) xr[t] = ld4(xbase + min(tbase + t, last) * xstep + xvoff);
   __builtin_amdgcn_sched_barrier(0);
+  MSTAMP(6);
   const float* wp = tile_wptr(wbase, row_lo, nun, 0, c, ks, N, K, a.w_tiled) + (PAIR ? (c >> 3) * 128 : 0);
-  if (PAIR) {
-#pragma unroll
-    for (int i = 0; i < SPWX / 2; ++i) w[i] = ld_nt(wp + min(tbase + 2 * i, last - 1) * wstep);   // host: steps even, SPWX / 2 <= DEP
-  } else {
-#pragma unroll
-    for (int i = 0; i < DEP; ++i) w[i] = ld_nt(wp + min(tbase + i, last) * wstep);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // what this wave's epilogue (tile `wave`) will need, requested now (behind the first weight loads, used after the last MFMA)
   const bool epi_mine = wave < ntile;
-  const TileEpi epi0 = tile_epilogue_fetch(a, p.hd, grp, row_lo + wave * 16, epi_mine ? ((2 * wave + 1 < nun) ? 16 : 8) : 0, lane);
-  __builtin_amdgcn_sched_barrier(0);
+  TileEpi epi0;
+  // the first weight requests + what this wave's epilogue (tile `wave`) will need (requested behind the weights, used after the last MFMA)
+  auto request_weights = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    if (PAIR) {
+#pragma unroll
+      for (int i = 0; i < SPWX / 2; ++i) w[i] = ld_nt(wp + min(tbase + 2 * i, last - 1) * wstep);   // host: steps even, SPWX / 2 <= DEP
+    } else {
+#pragma unroll
+      for (int i = 0; i < DEP; ++i) w[i] = ld_nt(wp + min(tbase + i, last) * wstep);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    MSTAMP(7);
+    epi0 = tile_epilogue_fetch(a, p.hd, grp, row_lo + wave * 16, epi_mine ? ((2 * wave + 1 < nun) ? 16 : 8) : 0, lane, kvpos);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // round 4's order: x requests, weight requests, then the LayerNorm. `xfirst`: x requests, wait, LayerNorm, THEN the weight requests (see
+  // `xfirst` above: a wave is stuck in the weight-request phase for ~4 us — the CU's request queue is full of x — and the LayerNorm barrier
+  // waits for the slowest of them).
+  if (!p.xfirst) request_weights();
 #pragma unroll
   for (int t = 0; t < SPWX; ++t) asm volatile("" : "+v"(xr[t].x), "+v"(xr[t].y), "+v"(xr[t].z), "+v"(xr[t].w));
 #pragma unroll
   for (int t = 0; t < SPWX; ++t)
     if (tbase + t > last) xr[t] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  MSTAMP(1);
   if (PRO == SSRHIP_PRO_LAYERNORM) {
     // LayerNorm on the register-resident x (gamma / beta folded into W / bias by the caller) with ONE workgroup barrier: every
     // wave computes the two-pass mean / sum of squared deviations of ITS K-slice, the slices are merged with the exact
@@ -347,6 +410,8 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
     }
   }
 
+  MSTAMP(2);
+  if (p.xfirst) request_weights();
   if (PAIR) {
     f4v aA = {0.f, 0.f, 0.f, 0.f}, aB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -364,13 +429,16 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
     f4v acc;
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = aA[e] + xor32_f(aB[e]);          // rows 0..7 (lanes < 32) = own rows + rows 8..15 of lane + 32
+    MSTAMP(3);
     part[0][wave][lane] = acc;
     __syncthreads();
+    MSTAMP(4);
     if (wave == 0) {
       f4v sum = part[0][0][lane];
       for (int v = 1; v < p.nw; ++v) sum += part[0][v][lane];
-      tile_epilogue_finish(a, epi0, sum);
+      tile_epilogue_finish(a, epi0, sum, p.hd);
     }
+    MSTAMP(5);
     return;
   }
   // all tiles but the last: the refills past this tile's k-range fetch the head of the next tile
@@ -405,13 +473,16 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
     }
     part[ntile - 1][wave][lane] = a0 + a1;
   }
+  MSTAMP(3);
   __syncthreads();
+  MSTAMP(4);
   for (int tile = wave; tile < ntile; tile += p.nw) {
     f4v acc = part[tile][0][lane];
     for (int v = 1; v < p.nw; ++v) acc += part[tile][v][lane];
-    if (tile == wave) tile_epilogue_finish(a, epi0, acc);
+    if (tile == wave) tile_epilogue_finish(a, epi0, acc, p.hd);
     else tile_epilogue(a, p.hd, grp, row_lo + tile * 16, (2 * tile + 1 < nun) ? 16 : 8, lane, acc);
   }
+  MSTAMP(5);
 }
 
 // K > 2048 without a LayerNorm prologue (FFN2, K = 8192): x no longer fits the registers of 8 waves, so it is streamed like W: per k-step one KiB of W (HBM) and one
@@ -439,18 +510,25 @@ __global__ __launch_bounds__(512) void gemv_rows_stream_kernel(const GemvR p) {
                     (a.x_tiled ? (unsigned)(ks * 16 + c) * 4 : (unsigned)min(c, B - 1) * (unsigned)a.x_stride + ks * 4);
   const int xstep = a.x_tiled ? 256 : 16;
 
+  MSTAMP(0);
   float4 w[DEP], xr[DEP];
+  const int kvpos = tile_kvpos(a, lane);                                // the wave's oldest load (QKV launch only)
+  __builtin_amdgcn_sched_barrier(0);
   const float* wp = tile_wptr(wbase, row_lo, nun, 0, c, ks, N, K, a.w_tiled) + (PAIR ? (c >> 3) * 128 : 0);
   if (PAIR) {
     // one 8-row unit per workgroup (see gemv_rows_xreg_kernel): per group of 16 k-steps 8 weight loads (k-step pairs) + 16 x loads
     float4 wq[DEP / 2];
 #pragma unroll
     for (int i = 0; i < DEP; ++i) xr[i] = ld4(xp + min(tbase + i, last) * xstep);
+    __builtin_amdgcn_sched_barrier(0);
+    if (p.xfirst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // x before W (see `xfirst`)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < DEP / 2; ++i) wq[i] = ld_nt(wp + min(tbase + 2 * i, last - 1) * wstep);
     __builtin_amdgcn_sched_barrier(0);
-    const TileEpi epi0 = tile_epilogue_fetch(a, p.hd, grp, row_lo, wave == 0 ? 8 : 0, lane);
+    const TileEpi epi0 = tile_epilogue_fetch(a, p.hd, grp, row_lo, wave == 0 ? 8 : 0, lane, kvpos);
     __builtin_amdgcn_sched_barrier(0);
+    MSTAMP(1);
     f4v aA = {0.f, 0.f, 0.f, 0.f}, aB = {0.f, 0.f, 0.f, 0.f};
     for (int g = 0; g < ngrp - 1; ++g) {                                   // all groups but the last: refill for group g + 1
       const int kb = tbase + g * DEP, kbn = kb + DEP;
@@ -493,25 +571,30 @@ __global__ __launch_bounds__(512) void gemv_rows_stream_kernel(const GemvR p) {
     f4v acc;
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = aA[e] + xor32_f(aB[e]);
+    MSTAMP(3);
     part[0][wave][lane] = acc;
     __syncthreads();
+    MSTAMP(4);
     if (wave == 0) {
       f4v sum = part[0][0][lane];
       for (int v = 1; v < p.nw; ++v) sum += part[0][v][lane];
-      tile_epilogue_finish(a, epi0, sum);
+      tile_epilogue_finish(a, epi0, sum, p.hd);
     }
+    MSTAMP(5);
     return;
   }
 #pragma unroll
-  for (int i = 0; i < DEP; ++i) {
-    const int kk = min(tbase + i, last);
-    xr[i] = ld4(xp + kk * xstep);
-    w[i] = ld_nt(wp + kk * wstep);
-  }
+  for (int i = 0; i < DEP; ++i) xr[i] = ld4(xp + min(tbase + i, last) * xstep);
+  __builtin_amdgcn_sched_barrier(0);
+  if (p.xfirst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // x before W (see `xfirst`)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < DEP; ++i) w[i] = ld_nt(wp + min(tbase + i, last) * wstep);
   __builtin_amdgcn_sched_barrier(0);
   const bool epi_mine = wave < ntile;
-  const TileEpi epi0 = tile_epilogue_fetch(a, p.hd, grp, row_lo + wave * 16, epi_mine ? ((2 * wave + 1 < nun) ? 16 : 8) : 0, lane);
+  const TileEpi epi0 = tile_epilogue_fetch(a, p.hd, grp, row_lo + wave * 16, epi_mine ? ((2 * wave + 1 < nun) ? 16 : 8) : 0, lane, kvpos);
   __builtin_amdgcn_sched_barrier(0);
+  MSTAMP(1);
   const int total = ntile * ngrp;
   f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   int tile = 0, kg = 0;
@@ -556,13 +639,16 @@ __global__ __launch_bounds__(512) void gemv_rows_stream_kernel(const GemvR p) {
     }
     part[ntile - 1][wave][lane] = a0 + a1;
   }
+  MSTAMP(3);
   __syncthreads();
+  MSTAMP(4);
   for (int t2 = wave; t2 < ntile; t2 += p.nw) {
     f4v acc = part[t2][0][lane];
     for (int v = 1; v < p.nw; ++v) acc += part[t2][v][lane];
-    if (t2 == wave) tile_epilogue_finish(a, epi0, acc);
+    if (t2 == wave) tile_epilogue_finish(a, epi0, acc, p.hd);
     else tile_epilogue(a, p.hd, grp, row_lo + t2 * 16, (2 * t2 + 1 < nun) ? 16 : 8, lane, acc);
   }
+  MSTAMP(5);
 }
 
 }  // namespace
@@ -602,6 +688,8 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s) {
     r.steps = a->K / 16;
     r.hd = hd;
     r.units = (a->N + 7) / 8;
+    r.xfirst = 1;                                                                   // 16-row step, same box, alternating engines: 1.3857 -> 1.3748 and
+    if (const char* e = getenv("SSRHIP_GEMVM_XFIRST")) r.xfirst = e[0] != '0';      // 1.3769 -> 1.3609 ms/step (A/B knob, read per call)
     const bool xreg = a->K <= 2048 || a->pro == SSRHIP_PRO_LAYERNORM;   // x slice of every wave in registers; else streamed beside W
     const int spwx = a->K <= 2048 ? 16 : 32;             // k-steps of x a wave keeps in registers
     if (xreg) {
