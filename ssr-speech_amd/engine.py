@@ -350,6 +350,14 @@ class DecodeEngine:
         self.n_admitted = 0                      # utterances admitted since the last start / run_queue (tests: refill happened)
         self.n_refills = 0                       # ... of which into a slot another utterance had used before
         self._utt_live = [False] * n_utt
+        # two-phase admission (run_queue): a slot that is being prefilled on the side stream. Its rows own KV pages, but the table the decode
+        # step reads still shows the scratch page for them — the pages are entered in `page_table_warm`, which only that prefill reads.
+        self._utt_warm = [False] * n_utt
+        self.page_table_warm = torch.full((self.B, self.max_pages), self.scratch_page, **i32)
+        self._table_warm_host = np.full((self.B, self.max_pages), self.scratch_page, dtype=np.int32)
+        self._side_stream = None
+        self._warm_pinned = self._warm_dev = None
+        self._warm_free = None                    # event: the last activation has read the warm staging buffers
         self.t_first_chunk = 0.0
         rows = self.B if self.B <= 4 else MAX_ROWS      # > 4 rows: x / q / h are 16-column tiled buffers (include/ssrhip.h SSRHIP_TILED)
         self.x = torch.zeros(rows, D, **f32)
@@ -443,8 +451,45 @@ class DecodeEngine:
         return self.admit(list(range(self.n_utt)), [text_rows[u * rpu:(u + 1) * rpu] for u in range(self.n_utt)], list(audio_cols), list(knobs),
                           use_noise=(noise is not None or host_noise))
 
+    def admit_begin(self, slots: Sequence[int], text_rows: Sequence[Sequence[np.ndarray]], audio_cols: Sequence[np.ndarray],
+                    knobs: Sequence[DecodeKnobs], use_noise: bool = False) -> dict:
+        """First half of a TWO-PHASE admission (continuous batching without stalling the live rows): KV pages for the new rows, the
+        integer arrays and the PREFILL of just those rows on a SIDE stream — concurrently with the decode chunks of the rows that keep
+        running; the decode step does not see the new rows yet (their slots stay parked: `done` set, table rows on the scratch page; the
+        prefill reads `page_table_warm`). `admit_finish(handle)` later puts them into the lock-step batch. Returns the handle."""
+        return self.admit(slots, text_rows, audio_cols, knobs, use_noise=use_noise, _two_phase=True)
+
+    def admit_finish(self, h: dict) -> None:
+        """Second half: on the caller's (decode) stream, behind the side stream's prefill — sampler configuration / state, pending token,
+        cache position and the table rows of the new slots, then the embedding of the pending tokens (every row: for rows in mid-decode
+        that re-writes what the sampler's fused embedding left). A few small device copies; the rows step with the next chunk."""
+        dev = self.device
+        main = torch.cuda.current_stream(dev)
+        main.wait_event(h["prefill_done"])
+        csz, ssz = C.sizeof(_lib.SamplerCfg), C.sizeof(_lib.SamplerState)
+        for i, u in enumerate(h["slots"]):
+            self.cfg_dev[u * csz:(u + 1) * csz].copy_(torch.frombuffer(bytearray(bytes(h["cfgs"][i])), dtype=torch.uint8))
+            self.state_dev[u * ssz:(u + 1) * ssz].copy_(torch.frombuffer(bytearray(bytes(h["sts"][i])), dtype=torch.uint8))
+        idx = h["rows_d"].long()
+        self.next_tok.index_copy_(0, idx, h["nt_d"])
+        self.next_pos.index_copy_(0, idx, h["t0s"])
+        self.kv_pos.index_copy_(0, idx, h["kv0"])
+        self.row_len.index_copy_(0, idx, h["kv0"] + 1)
+        for u in h["slots"]:
+            self._utt_warm[u] = False
+            self._utt_live[u] = True
+            self._admit_step[u] = self._steps_enqueued
+            for b in range(u * self.rows_per_utt, (u + 1) * self.rows_per_utt):
+                self._table_host[b, :] = self._table_warm_host[b, :]
+                self._table_warm_host[b, :] = self.scratch_page
+        self.page_table.copy_(torch.from_numpy(self._table_host))
+        _lib.check(self.lib.ssrhip_lm_embed_pending(self._ctx, _lib.stream_ptr()), "ssrhip_lm_embed_pending")
+        self._warm_free = torch.cuda.Event()
+        self._warm_free.record(main)
+        self._keep_warm = h                       # staging views stay alive until the stream has consumed them
+
     def admit(self, slots: Sequence[int], text_rows: Sequence[Sequence[np.ndarray]], audio_cols: Sequence[np.ndarray],
-              knobs: Sequence[DecodeKnobs], use_noise: bool = False) -> int:
+              knobs: Sequence[DecodeKnobs], use_noise: bool = False, _two_phase: bool = False):
         """Put new utterances into the utterance slots `slots` (free ones: never used, or released by `release_utterance`) while
         the other slots keep decoding: KV pages from the pool, sampler configuration / state, pending input token, and the
         PREFILL of just those rows (the reference prefills one utterance at a time anyway: models/ssr.py:627-642). Everything is
@@ -478,10 +523,21 @@ class DecodeEngine:
                 rows_b.append(b)
                 assert not self._row_pages[b], "slot still owns KV pages"
                 self._kv0[b] = Lb + T0
-            self._utt_live[u] = True
-            self._admit_step[u] = self._steps_enqueued
+            if _two_phase:
+                assert not self._utt_warm[u]
+                self._utt_warm[u] = True
+            else:
+                self._utt_live[u] = True
+                self._admit_step[u] = self._steps_enqueued
             self.n_admitted += 1
-        self._grow_pages(0)                      # pages for the prompts (+ the first decoded position) of the new rows
+        if _two_phase:                           # pages for the prompts (+ the first decoded position), entered in the WARM table only
+            for b in rows_b:
+                for have in range(min(self._kv0[b] // PAGE + 1, self.max_pages)):
+                    pg = self.pages.take(b)
+                    self._row_pages[b].append(pg)
+                    self._table_warm_host[b, have] = pg
+        else:
+            self._grow_pages(0)                  # pages for the prompts (+ the first decoded position) of the new rows
         # Every integer array of this admission goes to the device in ONE copy: packed into a pinned staging buffer, sent asynchronously
         # into a persistent int32 workspace, addressed by views (ten small synchronous pageable copies per admit stalled the
         # rows that were still decoding). Layout (int32): tok[R][4] | pos[R] | kind[R] | seq[R] | rpos[R] | rlen[R] | seq_start[n+1] |
@@ -498,23 +554,48 @@ class DecodeEngine:
         parts = [tok_h.reshape(-1), np.concatenate(poss), np.concatenate(kinds), np.concatenate(seqs), rpos_h, rpos_h + 1, starts,
                  nt_h.reshape(-1), t0_h, kv0_h, np.asarray(rows_b, dtype=np.int32)]
         total = sum(int(p_.size) for p_ in parts)
-        if self._admit_pinned is None or self._admit_pinned.numel() < total:
+        side = None
+        if _two_phase:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(dev)
+            side = self._side_stream
+            if self._warm_pinned is None or self._warm_pinned.numel() < total:
+                cap_n = max(total, 2 * (self._warm_pinned.numel() if self._warm_pinned is not None else 0), 4096)
+                torch.cuda.synchronize(dev)       # growth is rare: nothing in flight may still read the old buffer, and the new block (allocated
+                self._warm_pinned = torch.empty(cap_n, dtype=torch.int32).pin_memory()
+                self._warm_dev = torch.empty(cap_n, dtype=torch.int32, device=dev)     # on this stream, used on the side stream) has no pending user
+            side.synchronize()                    # the previous two-phase prefill is through (>= one 16-step chunk ago): its staging is free
+            if self._warm_free is not None:
+                side.wait_event(self._warm_free)  # ... and the activation that read the staging views has run
+            stage_np = self._warm_pinned.numpy()
+            offs, o = [], 0
+            for p_ in parts:
+                stage_np[o:o + p_.size] = p_.astype(np.int32, copy=False).reshape(-1)
+                offs.append(o)
+                o += int(p_.size)
+            with torch.cuda.stream(side):
+                self._warm_dev[:total].copy_(self._warm_pinned[:total], non_blocking=True)
+                self.page_table_warm.copy_(torch.from_numpy(self._table_warm_host))
+            stage_dev = self._warm_dev
+        elif self._admit_pinned is None or self._admit_pinned.numel() < total:
             cap_n = max(total, 2 * (self._admit_pinned.numel() if self._admit_pinned is not None else 0), 4096)
             self._admit_pinned = torch.empty(cap_n, dtype=torch.int32).pin_memory()
             self._admit_dev = torch.empty(cap_n, dtype=torch.int32, device=dev)
             self._admit_sent = None
-        if self._admit_sent is not None:
-            self._admit_sent.synchronize()       # the previous admission's copy has left the staging buffer (admissions are >= 16 steps apart)
-        stage_np = self._admit_pinned.numpy()
-        offs, o = [], 0
-        for p_ in parts:
-            stage_np[o:o + p_.size] = p_.astype(np.int32, copy=False).reshape(-1)
-            offs.append(o)
-            o += int(p_.size)
-        self._admit_dev[:total].copy_(self._admit_pinned[:total], non_blocking=True)
-        self._admit_sent = torch.cuda.Event()
-        self._admit_sent.record(torch.cuda.current_stream(dev))
-        view = lambda i, n: self._admit_dev[offs[i]: offs[i] + n]
+        if not _two_phase:
+            if self._admit_sent is not None:
+                self._admit_sent.synchronize()   # the previous admission's copy has left the staging buffer (admissions are >= 16 steps apart)
+            stage_np = self._admit_pinned.numpy()
+            offs, o = [], 0
+            for p_ in parts:
+                stage_np[o:o + p_.size] = p_.astype(np.int32, copy=False).reshape(-1)
+                offs.append(o)
+                o += int(p_.size)
+            self._admit_dev[:total].copy_(self._admit_pinned[:total], non_blocking=True)
+            self._admit_sent = torch.cuda.Event()
+            self._admit_sent.record(torch.cuda.current_stream(dev))
+            stage_dev = self._admit_dev
+        view = lambda i, n: stage_dev[offs[i]: offs[i] + n]
         tok, pos, kind, seq, rpos, rlen = view(0, 4 * R).view(R, MAX_CODEBOOKS), view(1, R), view(2, R), view(3, R), view(4, R), view(5, R)
         seq_start = view(6, len(lens) + 1)
         nt_d, t0s, kv0, rows_d = view(7, 4 * nrow).view(nrow, MAX_CODEBOOKS), view(8, nrow), view(9, nrow), view(10, nrow)
@@ -543,13 +624,17 @@ class DecodeEngine:
             st.span, st.num_gen, st.num_eog, st.num_cfg_tag, st.prev_token, st.consec_silence = 0, 0, 0, 1, -1, 0
             st.audio_pos = int(np.asarray(au).shape[1])
             st.n_steps, st.done = 0, 0
-        if whole:
+        if _two_phase:
+            pass                                 # the decode step must not see the new slots yet: admit_finish writes cfg / state / pending token
+        elif whole:
             self.cfg_dev.copy_(torch.frombuffer(bytearray(bytes(cfgs)), dtype=torch.uint8))
             self.state_dev.copy_(torch.frombuffer(bytearray(bytes(sts)), dtype=torch.uint8))
         else:
             for i, u in enumerate(slots):
                 self.cfg_dev[u * csz:(u + 1) * csz].copy_(torch.frombuffer(bytearray(bytes(cfgs[i])), dtype=torch.uint8))
                 self.state_dev[u * ssz:(u + 1) * ssz].copy_(torch.frombuffer(bytearray(bytes(sts[i])), dtype=torch.uint8))
+        if _two_phase:
+            assert self._arena_gen == a.generation and self._ctx is not None, "two-phase admission needs the running engine's context"
         if self._arena_gen != a.generation:          # the arena re-allocated a table (position table grown): refresh the pointers
             self._w = a.c_struct()
             self._arena_gen = a.generation
@@ -558,8 +643,10 @@ class DecodeEngine:
             self._create_ctx()
 
         # first decode input of the new rows: the span-0 mask token at audio position T0 (ssr.py:655-662)
-        idx = rows_d.long() if rows_b != list(range(self.B)) else None
-        if idx is None:                          # every row (the first fill): plain copies, no index tensor
+        idx = rows_d.long() if (rows_b != list(range(self.B)) and not _two_phase) else None
+        if _two_phase:
+            pass                                 # admit_finish
+        elif idx is None:                        # every row (the first fill): plain copies, no index tensor
             self.next_tok.copy_(nt_d)
             self.next_pos.copy_(t0s)
             self.kv_pos.copy_(kv0)
@@ -575,6 +662,8 @@ class DecodeEngine:
         D, F, H = a.D, a.F, a.H
         ms = (max(lens) + PAGE - 1) // PAGE
         if self._prefill_ws is None or self._prefill_ws["x"].shape[0] < R:
+            if _two_phase:
+                torch.cuda.synchronize(dev)      # (rare) the workspace is allocated on this stream and used on the side stream
             Rc = max(R, int(1.25 * (self._prefill_ws["x"].shape[0] if self._prefill_ws is not None else 0)))
             self._prefill_ws = dict(x=torch.empty(Rc, D, **f32), xn=torch.empty(Rc, D, **f32), qkv=torch.empty(Rc, 3 * D, **f32),
                                     o=torch.empty(Rc, D, **f32), h=torch.empty(Rc, F, **f32))
@@ -589,6 +678,14 @@ class DecodeEngine:
         for k, v in ws.items():
             setattr(p, k, v.data_ptr())
         p.seq_start, p.n_seq, p.max_len = seq_start.data_ptr(), len(lens), int(max(lens))
+        if _two_phase:
+            # on the SIDE stream, against the warm table, without the closing embedding (x is live decode state): see admit_begin
+            p.table, p.no_embed = self.page_table_warm.data_ptr(), 1
+            with torch.cuda.stream(side):
+                _lib.check(self.lib.ssrhip_lm_prefill(self._ctx, C.byref(p), _lib.stream_ptr()), "ssrhip_lm_prefill")
+                done = torch.cuda.Event()
+                done.record(side)
+            return dict(slots=list(slots), rows=R, prefill_done=done, cfgs=cfgs, sts=sts, nt_d=nt_d, t0s=t0s, kv0=kv0, rows_d=rows_d, ws=ws)
         # (the prefill ends by embedding the pending input token of EVERY row into x: for rows in mid-decode that re-writes the
         # very values the sampler's fused embedding left there — same function, same inputs)
         _lib.check(self.lib.ssrhip_lm_prefill(self._ctx, C.byref(p), _lib.stream_ptr()), "ssrhip_lm_prefill")
@@ -753,9 +850,20 @@ class DecodeEngine:
             slot_free[buf_i] = ev
             return ev
 
-        def admit_into(slots: Sequence[int]):
+        # Two-phase admission is built, bit-exact and OFF by default: on the bench's ragged queue (64 utterances through 8
+        # slots, 56 refills) it measured 19,785 codec-tokens/s against 19,930 for the blocking form, same token CRC
+        # (profiles/r05_microbench/dp64_ragged_two_phase_ab.log). The 9 ms of prefill work do not disappear by moving to a side stream: the
+        # prefill's workgroups take CU slots from the decode step's 83 dependent launches, each of which then starts late — the two
+        # time-slice the GPU instead of overlapping HBM-bound with matrix-bound work — and the admitted slot idles one more 16-step chunk.
+        two_phase = os.environ.get("SSRHIP_ADMIT_TWO_PHASE", "0") not in ("", "0")
+
+        def take_jobs(slots: Sequence[int]):
             take = [pending.pop(0) for _ in slots[: len(pending)]]
-            slots = list(slots[: len(take)])
+            return list(slots[: len(take)]), take
+
+        def admit_into(slots: Sequence[int]):
+            """blocking admission (the first fill; refills with SSRHIP_ADMIT_TWO_PHASE=0): prefill on the decode stream"""
+            slots, take = take_jobs(slots)
             if not take:
                 return
             for u, j in zip(slots, take):
@@ -768,14 +876,37 @@ class DecodeEngine:
             if sampling:
                 waits.append(upload(2, slots))                 # the new utterances' first chunk, before their first step
 
+        def begin_into(slots: Sequence[int]):
+            """two-phase admission, first half: the prefill of the new rows starts on the side stream NOW and overlaps the decode chunk that
+            is already enqueued; the slots join the lock-step batch at the next poll (`finish_warm`)"""
+            slots, take = take_jobs(slots)
+            if not take:
+                return None
+            h = self.admit_begin(slots, [jobs[j]["text_rows"] for j in take], [jobs[j]["audio_cols"] for j in take],
+                                 [jobs[j]["knobs"] for j in take], use_noise=sampling)
+            h["jobs"] = take
+            return h
+
+        def finish_warm(h: dict):
+            self.admit_finish(h)
+            for u, j in zip(h["slots"], h["jobs"]):
+                slot_job[u] = j
+                local[u] = 0
+                if sampling:
+                    feed.reset_slot(u, jobs[j].get("gen"))
+            if sampling:
+                waits.append(upload(2, h["slots"]))             # the new utterances' first chunk, before their first step
+
         # first fill: as `start` (pool reset), but only as many slots as there are jobs; the others stay parked on the scratch page
         self.pages.reset()
         self._table_host[:] = self.scratch_page
+        self._table_warm_host[:] = self.scratch_page
         self._row_pages = [[] for _ in range(self.B)]
         self._kv0 = [0] * self.B
         self._steps_enqueued = 0
         self._admit_step = [0] * self.n_utt
         self._utt_live = [False] * self.n_utt
+        self._utt_warm = [False] * self.n_utt
         self.n_admitted = self.n_refills = 0
         # idle slots: done = 1 so that the sampler leaves them alone
         idle = (_lib.SamplerState * self.n_utt)()
@@ -786,24 +917,31 @@ class DecodeEngine:
         admit_into(list(range(self.n_utt)))
         ci = 0
         ready = None
-        while any(j is not None for j in slot_job):
+        warm = None                                             # handle of the slots being prefilled on the side stream
+        in_flight: List[int] = []                               # slots stepping in the chunk that is enqueued and not yet polled
+
+        def enqueue_chunk():
+            nonlocal waits, ready, ci, in_flight
             for ev in waits:
                 main.wait_event(ev)
             waits = []
             if ready is not None:
                 main.wait_event(ready)
-            live = [u for u in range(self.n_utt) if slot_job[u] is not None]
+            in_flight = [u for u in range(self.n_utt) if slot_job[u] is not None]
             self.decode(chunk, use_graph)
-            for u in live:
+            for u in in_flight:
                 local[u] += chunk
             if sampling:
-                ready = upload(ci & 1, live)                    # host draws the next chunk while the GPU runs this one
+                ready = upload(ci & 1, in_flight)               # host draws the next chunk while the GPU runs this one
             ci += 1
-            states = self.states()                              # blocks until the chunk has finished
+
+        enqueue_chunk()
+        while True:
+            states = self.states()                              # blocks until the enqueued chunk has finished
             if ci == 1:
                 self.t_first_chunk = time.perf_counter()
             freed = []
-            for u in live:
+            for u in in_flight:
                 st, j = states[u], slot_job[u]
                 cap_j = min(int(jobs[j]["cap"]), self.max_steps)
                 over = local[u] >= cap_j
@@ -827,9 +965,27 @@ class DecodeEngine:
                     self.release_utterance(u)
                     slot_job[u] = None
                     freed.append(u)
-            if freed and pending:
-                self.n_refills += min(len(freed), len(pending))
-                admit_into(freed)
+            in_flight = []
+            # the slots whose prefill was started one poll ago join the batch now (their prefill had a whole chunk to finish)
+            if warm is not None:
+                finish_warm(warm)
+                warm = None
+            free_slots = [u for u in range(self.n_utt) if slot_job[u] is None]
+            any_live = any(j is not None for j in slot_job)
+            if two_phase and any_live:
+                # keep the GPU busy FIRST: the next chunk of the live rows is enqueued before the host prepares the admission, whose
+                # prefill then overlaps that chunk on the side stream
+                enqueue_chunk()
+                if free_slots and pending:
+                    self.n_refills += min(len(free_slots), len(pending))
+                    warm = begin_into(free_slots)
+                continue
+            if free_slots and pending:                          # nothing is decoding (or the knob is off): the blocking form
+                self.n_refills += min(len(free_slots), len(pending))
+                admit_into(free_slots)
+            if not any(j is not None for j in slot_job):
+                break
+            enqueue_chunk()
         return results
 
     def time_kernels(self, n_steps: int):

@@ -422,9 +422,12 @@ def test_sixteen_rows_sixteen_heads_full_generation_equals_batch1(greedy):
         assert torch.equal(batch[i][0], one[0]) and torch.equal(batch[i][1], one[1]) and batch[i][2] == one[2], i
 
 
+@pytest.mark.parametrize("two_phase", ["0", "1"])
 @pytest.mark.parametrize("greedy", [True, False])
-def test_inference_batch_refill_equals_batch1(greedy):
-    """Continuous batching: 24 utterances of very different lengths (L in [6, 40] phonemes => 30..330 steps under
+def test_inference_batch_refill_equals_batch1(greedy, two_phase, monkeypatch):
+    """`two_phase` = SSRHIP_ADMIT_TWO_PHASE: the refilled slot's prefill on the decode stream (default), or on a side stream against a private
+    page table with the slot joining at the next poll (round 5: built, identical tokens, measured no faster — opt-in).
+    Continuous batching: 24 utterances of very different lengths (L in [6, 40] phonemes => 30..330 steps under
     the reference's 10 x L cap, prompts of 5..60 frames, one two-span edit) through 8 utterance slots. A slot whose utterance is done
     at a 16-step poll releases its KV pages and takes the next pending utterance (prefill of just those rows, sampler state reset, same
     graph) while the others keep decoding. Contract unchanged: utterance i == its batch-1 run seeded seed + i (greedy and sampled)."""
@@ -441,7 +444,9 @@ def test_inference_batch_refill_equals_batch1(greedy):
     utts[5]["mask_interval"] = torch.LongTensor([[[1, 2], [T5 - 2, T5 - 1]]]) if T5 >= 8 else utts[5]["mask_interval"]
     kw = dict(top_k=1, top_p=1.0) if greedy else dict(top_k=12, top_p=0.9)
     kw.update(temperature=1.0, stop_repetition=2, silence_tokens=[3, 7, 11], cfg_coef=1.5, cfg_stride=2, aug_text=True)
+    monkeypatch.setenv("SSRHIP_ADMIT_TWO_PHASE", two_phase)
     batch = m.inference_batch(utts, seed=700, group=8, **kw)
+    monkeypatch.delenv("SSRHIP_ADMIT_TWO_PHASE")
     eng = next(iter(m._engines.values()))
     assert eng.n_utt == 8 and eng.n_admitted == 24 and eng.n_refills == 16          # every utterance beyond the first 8 went into a used slot
     assert eng.pages.n_free == eng.pages.n_pages                                     # every page came back
