@@ -103,7 +103,8 @@ def cpu_baseline(args_lm, sd_gpu, x, y, unc, n_steps=25):
 
 def codec_leg(dev, with_cpu):
     """Extra (not `value`): wmencodec encode + decode throughput at the full SEANet config (SURVEY §8 rows B1-B7, config 5
-    shape scaled to 16 clips x 10 s so that the default run stays short), and the oracle's CPU time on one 2 s clip."""
+    shape scaled to 16 clips x 10 s so that the default run stays short), and the oracle's CPU time on 4 clips x 30 s
+    with the GPU's codes / waveform on the same clips beside it."""
     from ssr_speech_amd import weights as W
     from ssr_speech_amd.codec.wmencodec import WMEncodecModel
     cfg = W.codec_config_full()
@@ -130,18 +131,26 @@ def codec_leg(dev, with_cpu):
            "encode_tflops": round(GF * audio_s / (t1 - t0) / 1e12, 1), "decode_tflops": round(GF * audio_s / (t2 - t1) / 1e12, 1),
            "mfma_fp32_peak_tflops": 157.3, "out_shape": list(out_wav.shape)}
     if with_cpu:
+        # "codec: one 30 s clip x B=4 scaled linearly to B=256" — the oracle on 4 clips x 30 s, and the GPU on the SAME clips
+        # so that the comparison in this record means something (round 4 compared a 2 s cut on the CPU with the GPU's 10 s clip: different
+        # right context through the non-causal convolutions and the LSTM, hence a meaningless 3 % "mismatch").
         from oracle import codec as OC
         torch.set_num_threads(min(32, os.cpu_count() or 1))
-        w1 = wav[:1, :, : 2 * 16000].cpu()
+        g4 = torch.Generator().manual_seed(1)
+        w4 = torch.randn(4, 1, 30 * 16000, generator=g4) * 0.1
         c0 = time.perf_counter()
-        ccodes, _, _ = OC.encode(csd, w1, cfg)
+        ccodes, _, _ = OC.encode(csd, w4, cfg)
         c1 = time.perf_counter()
-        OC.decode(csd, ccodes, cfg)
+        cwav = OC.decode(csd, ccodes, cfg)
         c2 = time.perf_counter()
-        out["cpu_baseline"] = {"kind": "port", "cores": torch.get_num_threads(), "sample": "oracle/codec.py on 1 clip x 2 s",
-                               "encode_audio_s_per_s": round(2.0 / (c1 - c0), 2), "decode_audio_s_per_s": round(2.0 / (c2 - c1), 2)}
-        same = float((ccodes != codes[:1, :, : ccodes.shape[-1]].cpu()).float().mean())
-        out["cpu_baseline"]["code_mismatch_vs_gpu_first_2s"] = round(same, 4)   # informational: clip context differs beyond the receptive field
+        gcodes, _, _ = m.encode(w4.to(dev))
+        gwav = m.decode(ccodes.to(dev))
+        n_diff = int((gcodes.cpu() != ccodes).sum())
+        out["cpu_baseline"] = {"kind": "port", "cores": torch.get_num_threads(), "sample": "oracle/codec.py on 4 clips x 30 s (BASELINE.md: scaled linearly to 256 clips)",
+                               "encode_audio_s_per_s": round(120.0 / (c1 - c0), 2), "decode_audio_s_per_s": round(120.0 / (c2 - c1), 2),
+                               "encode_ms_scaled_to_256_clips": round(1000 * (c1 - c0) * 64, 0), "decode_ms_scaled_to_256_clips": round(1000 * (c2 - c1) * 64, 0),
+                               "gpu_codes_differing_on_the_same_clips": n_diff, "codes_compared": int(ccodes.numel()),
+                               "gpu_max_abs_wav_diff_on_the_same_codes": float((gwav.cpu() - cwav).abs().max())}
     return out
 
 
@@ -511,6 +520,19 @@ def main():
             break
         seed_try += 1           # the sampler drew <eog> inside the timed region: different stream, same workload
     elapsed = t1 - t0
+    # the same W + K steps again (restart, warm-up, K timed steps: same context range), listed beside the headline: the driver's timed region
+    # is ~17 ms and boxes differ by 3-5 %, so one pass cannot resolve a 1 % change. `ms_per_step` stays the FIRST pass.
+    extra_passes = []
+    if dist is None:
+        for _rep in range(4):
+            eng.start(text_rows, [cated] * U, kns, noise=None)
+            torch.cuda.synchronize()
+            eng.decode(a.warmup, use_graph=not a.no_graph)
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            eng.decode(a.steps, use_graph=not a.no_graph)
+            torch.cuda.synchronize()
+            extra_passes.append(1000 * (time.perf_counter() - p0) / a.steps)
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -566,7 +588,8 @@ def main():
         out = {
             "metric": "codec-tokens/sec/GPU (AR decode) + RTF for 10 s TTS, English 830M",
             "value": round(value, 1), "unit": "codec-tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "ms_per_step_passes": [round(ms_per_step, 4)] + [round(v, 4) for v in extra_passes],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"English-830M-shape zero-shot TTS decode, cfg_stride=5, top_k=40/top_p=0.8 sampling, batch={U} ({2 * U} CFG rows) per GPU; "
                                    f"L={L} phonemes, {N}-frame prompt, context {L + T0 + a.warmup}..{L + T0 + total}",
