@@ -773,6 +773,10 @@ __global__ __launch_bounds__(SEG_TH, (TWO && PRO == SSRHIP_PRO_ATTN_COMBINE) ? 2
 // tail, no clamping, exact `s_waitcnt vmcnt(n)` everywhere). Half the workgroups of the form above: half the x traffic from L2 (8 waves
 // fetch their slices instead of 16), half the LayerNorm statistics, one barrier pair per CU instead of two, 256 dispatches instead of 512.
 // Per unit, per segment and per output the SAME operations in the same order as gemv_seg_kernel: bit-identical results (tests compare).
+// Measured and NOT kept (round 5): requesting only the wave's FIRST unit at entry and units 1 .. DEPTH-1 behind the LayerNorm — the 16-row
+// kernels gain from getting their LayerNorm out of the way of the weight requests (csrc/gemv_mfma.hip), here 16 KB of x per workgroup is no
+// obstacle and the later requests only cost: 0.8196 -> 0.8340 ms/step, 655.1 -> 674.6 us per step's GEMVs
+// (profiles/r05_microbench/decode_ab_ramp.log, gemvm_bench_2_ramp.log). Everything is requested at entry.
 template <int B, int PRO, int NUW, int DEPTH>
 __global__ __launch_bounds__(SEG_TH, 2) void gemv_segu_kernel(const GemvK p) {
   static_assert(PRO == SSRHIP_PRO_NONE || PRO == SSRHIP_PRO_LAYERNORM, "the split-KV merge prologue stays on gemv_seg_kernel");
