@@ -39,19 +39,16 @@ struct GemvK {
   int rows_max;   // segment kernel: most rows a workgroup owns (sizes the LDS partials)
   long long* prof;          // -DSSR_GEMV_PROFILE builds only (ssrhip_debug_gemv_prof): 8 wall_clock64 stamps per workgroup, or NULL
   int rows_per, rows_rem;   // segment / front kernels: N / groups_x and N % groups_x (workgroup b owns rows_per + (b < rows_rem) rows)
-  int xfirst;               // segment kernels: 1 = the first weight requests are posted when the wave's activations have arrived
 };
 
-// Activations BEFORE weights (round 5, found on the 16-row kernels: csrc/gemv_mfma.hip has the measurements): the L2 fills of the x (or
-// attention-partial) lines queue on the memory side behind the weight requests all CUs post in their first microsecond, and the LayerNorm /
-// merge barrier then holds EVERY wave until the last slice has arrived. `xfirst` = 1: a wave posts its first weight requests only when its
-// activations have ARRIVED. SSRHIP_GEMV_XFIRST is the A/B knob (read per call); a bare s_barrier between the two request phases was
-// measured first and is slower than doing nothing (0.8052 -> 0.8105 ms/step, profiles/r05_microbench/decode_ab_xfirst_barrier.log).
-int seg_xfirst(int pro) {               // SSRHIP_GEMV_XFIRST: bit 0 = the x-operand launches (LayerNorm / no prologue), bit 1 = the split-KV merge launch
-  int mask = 0;                         // measured at 2 rows (profiles/r05_microbench/decode_ab_xwait.log): 0.8273 ms/step; 1: 0.8392; 2: 0.8269; 3: 0.8393 —
-  if (const char* e = getenv("SSRHIP_GEMV_XFIRST")) mask = atoi(e);   // 16 KB of x does not fill the CU's request queue, the later weight requests only cost
-  return (mask & (pro == SSRHIP_PRO_ATTN_COMBINE ? 2 : 1)) != 0;
-}
+// Measured and NOT kept at 1..4 rows (round 5): posting a wave's first weight requests only when its activations (x / attention partials)
+// have arrived. The 16-row kernels gain from it (csrc/gemv_mfma.hip: 128 KB of x per CU); here 16 KB per workgroup is no obstacle and the
+// later weight requests only cost: 0.8273 ms/step as is, 0.8392 with the wait in the x-operand launches, 0.8269 in the merge launch only,
+// 0.8393 in both; a bare s_barrier between the two request phases 0.8052 -> 0.8105 (profiles/r05_microbench/decode_ab_xwait.log,
+// decode_ab_xfirst_barrier.log). The experiment's `asm volatile("s_waitcnt vmcnt(0)" ::: "memory")` also taught a lesson by staying in the
+// source behind a runtime flag: its memory clobber made every later uniform load "possibly clobbered", the kv_pos -> page-table chain of the
+// QKV launch left the scalar path again (vector loads behind vmcnt(0)) and the step lost 2 % with the flag OFF — caught by the ISA guard
+// tests/test_isa_guards.py::test_round5_decode_kernels_keep_their_request_order_in_the_isa. Removed.
 
 long long* g_gemv_prof = nullptr;   // debug: ssrhip_debug_gemv_prof
 constexpr int PRO_LN_REGS = 3;   // internal: LayerNorm with gamma/beta folded into W/bias, whole row per wave (no LDS)
@@ -594,9 +591,6 @@ __global__ __launch_bounds__(SEG_TH, (TWO && PRO == SSRHIP_PRO_ATTN_COMBINE) ? 2
                                                                                                   // round trip ahead of these); pages beyond the row are dropped below
     }
   }
-  __builtin_amdgcn_sched_barrier(0);
-  if (p.xfirst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // uniform: see `xfirst`
-  __builtin_amdgcn_sched_barrier(0);
   // ---- 2. the wave's first unit, unconditional (clamped to the workgroup's last unit). FOUR loads in flight per lane, 16 waves per
   // CU: 64 KB per CU cover the HBM latency-bandwidth product; `tools/overlap_bench orders`: 8 in flight cost +1.5 us per launch.
   float4 wa[4];
@@ -804,9 +798,6 @@ __global__ __launch_bounds__(SEG_TH, 2) void gemv_segu_kernel(const GemvK p) {
   for (int b = 0; b < B; ++b)
 #pragma unroll
     for (int i = 0; i < 4; ++i) xr[b][i] = ld4(a.x + (size_t)b * a.x_stride + (size_t)g * K + seg * SEG + (i * 64 + lane) * 4);
-  __builtin_amdgcn_sched_barrier(0);
-  if (p.xfirst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // uniform: see `xfirst`
-  __builtin_amdgcn_sched_barrier(0);
   float4 w[DEPTH][4];
 #pragma unroll
   for (int j = 0; j < DEPTH; ++j)
@@ -911,7 +902,6 @@ bool try_seg(const ssrhip_gemv_args* a, int num_cu, hipStream_t s) {
   p.rows_per = a->N / G;
   p.rows_rem = a->N % G;
   p.prof = g_gemv_prof;
-  p.xfirst = seg_xfirst(a->pro);
   p.groups_x = G;
   p.hd = (a->kv.head_dim > 0) ? a->kv.head_dim : 1;
   size_t smem = (size_t)rows_max * S * B * sizeof(float);
@@ -1027,7 +1017,6 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   p.rows_max = 0;
   p.rows_per = p.rows_rem = 0;
   p.prof = nullptr;
-  p.xfirst = 0;
   p.nslice = a->K <= 2048 ? 1 : (a->K <= 4096 ? 2 : 4);
   p.slice_len = ((a->K + p.nslice - 1) / p.nslice + 3) / 4 * 4;
   p.nch = (p.slice_len + 255) / 256;

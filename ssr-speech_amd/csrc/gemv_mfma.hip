@@ -521,8 +521,6 @@ __global__ __launch_bounds__(512) void gemv_rows_stream_kernel(const GemvR p) {
 #pragma unroll
     for (int i = 0; i < DEP; ++i) xr[i] = ld4(xp + min(tbase + i, last) * xstep);
     __builtin_amdgcn_sched_barrier(0);
-    if (p.xfirst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // x before W (see `xfirst`)
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < DEP / 2; ++i) wq[i] = ld_nt(wp + min(tbase + 2 * i, last - 1) * wstep);
     __builtin_amdgcn_sched_barrier(0);
@@ -585,8 +583,6 @@ __global__ __launch_bounds__(512) void gemv_rows_stream_kernel(const GemvR p) {
   }
 #pragma unroll
   for (int i = 0; i < DEP; ++i) xr[i] = ld4(xp + min(tbase + i, last) * xstep);
-  __builtin_amdgcn_sched_barrier(0);
-  if (p.xfirst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // x before W (see `xfirst`)
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < DEP; ++i) w[i] = ld_nt(wp + min(tbase + i, last) * wstep);

@@ -76,6 +76,49 @@ def test_segment_kernel_loop_rerequests_in_place(gemv_asm):
         assert found, f"{sym}: no loop with four in-place non-temporal re-requests behind vmcnt(3) waits"
 
 
+def test_round5_decode_kernels_keep_their_request_order_in_the_isa(gemv_asm, tmp_path_factory):
+    """Round 5 read four inefficiencies of the 2-row decode step off the ISA; each is easy to bring back with an innocent edit:
+      * a runtime profiling hook at kernel entry (exec-mask branch + global store) split the kernel-argument fetch into two dependent scalar
+        round trips and pushed the kv_pos -> page-table chain of the QKV launch off the scalar path (vector loads behind `vmcnt(0)`): the
+        straight-line `gemv_segu_kernel` variants must reach their first load behind ONE `s_waitcnt lgkmcnt`, never use v_readfirstlane,
+        fit 128 VGPRs without scratch, and drain (`vmcnt(0)`) only once — behind their last unit;
+      * the split-KV merge prologue of the out-projection drained its whole weight slice before the merge arithmetic (a loop pre-header's
+        `vmcnt(0)` and a false dependency through a v_pk_fma register pair): between its first two barriers no `vmcnt(0)` outside the
+        cold path's asm statements;
+      * the decode attention requested its V rows behind the LAST K row: with VAT = 8 all 16 K requests precede the first wait, the 16 V
+        requests follow in one run."""
+    meta = _kernel_meta(gemv_asm)
+    segu = [k for k in meta if "gemv_segu_kernel" in k]
+    assert len(segu) == 12, sorted(segu)                              # 2 rows x {no prologue, LayerNorm} x {4, 6, 8} units per wave x depth {2, 4}
+    for sym in segu:
+        vgpr, scratch = meta[sym]
+        assert vgpr <= 128 and scratch == 0, (sym, vgpr, scratch)
+        body = _body(gemv_asm, sym)
+        head = body[:body.index("global_load")]
+        assert head.count("s_waitcnt lgkmcnt") == 1, (sym, head.count("s_waitcnt lgkmcnt"))
+        assert "v_readfirstlane" not in body, sym
+        assert body.count("vmcnt(0)") == 1, (sym, body.count("vmcnt(0)"))
+    merge = [k for k in meta if "gemv_seg_kernelILi2ELi2ELb1E" in k]
+    assert len(merge) == 1, merge
+    body = _body(gemv_asm, merge[0])
+    bars = [m.start() for m in re.finditer(r"s_barrier", body)]
+    assert len(bars) >= 2
+    hot = re.sub(r";;#ASMSTART.*?;;#ASMEND", "", body[bars[0]:bars[1]], flags=re.S)
+    assert "vmcnt(0)" not in hot, "the out-projection's merge prologue drains its weight loads again"
+    attn = _asm(tmp_path_factory, "attn")
+    sym = next(k for k in _kernel_meta(attn) if "attn_decode_kernelILi128ELb0ELi8E" in k)
+    seq = []
+    for ln in _body(attn, sym).split("\n"):
+        t = ln.strip()
+        if t.startswith("global_load_dwordx4") and t.endswith("nt"):
+            seq.append("L")
+        elif t.startswith("s_waitcnt") and "vmcnt" in t:
+            seq.append("w")
+    joined = "".join(seq)
+    assert joined.startswith("L" * 16 + "w"), joined[:40]            # all K rows in flight before the first wait
+    assert "L" * 16 in joined[17:], joined                            # the V rows in one run
+
+
 def test_generic_and_matrix_core_gemv_kernels_do_not_spill(gemv_asm, tmp_path_factory):
     assert not [k for k in _kernel_meta(gemv_asm) if "gemv_fast_kernel" in k]          # the intermediate generation is gone (round 3)
     generic = {k: v for k, v in _kernel_meta(gemv_asm).items() if "gemv_kernel" in k and "ILi2E" in k}
