@@ -286,8 +286,10 @@ constexpr int MAXT = 4;     // 16-row tiles per workgroup (LDS: MAXT x 8 waves x
 // wave to get through; (3) a bare s_barrier between the two request phases (all x requests in front of all weight requests) changed
 // nothing, and waiting for x without moving the LayerNorm did not either. With the LayerNorm in front of the weight requests the chain
 // x -> statistics -> barrier -> normalise runs while nothing else is queued, and the matrix work starts 1.1 us earlier (7.2 vs 8.3) on a
-// stream that started 2.6 us later: a wash inside one launch (gemvm_bench: 966.6 vs 980.0 us per step's GEMVs), slightly ahead in the
-// step. What a 16-row launch pays over the chain floor (9.5 us for 50 MB) is therefore: ~1 us to request x, ~4 us of a stream that runs at
+// stream that started 2.6 us later: a wash. Measured three ways: tools/decode_ab.py (same box, alternating engines) 1.3857 -> 1.3748 and
+// 1.3769 -> 1.3609 ms/step in its favour; gemvm_bench (one shape chained) 966.6 -> 980.0 us per step's GEMVs against it; the kernel trace
+// of bench.py --utts 8 17.62 us per LayerNorm launch against round 4's 16.09 (other kernels within 2 % between the two boxes) against it.
+// It stays a knob, OFF. What a 16-row launch pays over the chain floor (9.5 us for 50 MB) is therefore: ~1 us to request x, ~4 us of a stream that runs at
 // 4.6-5.6 TB/s instead of 7.3 while the waves alternate between blocked request phases and matrix work, and ~3 us of tail (the slowest of
 // the eight K-slice waves reaches the partial-tile barrier 2 us after wave 0; merge + epilogue 1.1 us).
 
@@ -684,8 +686,8 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s) {
     r.steps = a->K / 16;
     r.hd = hd;
     r.units = (a->N + 7) / 8;
-    r.xfirst = 1;                                                                   // 16-row step, same box, alternating engines: 1.3857 -> 1.3748 and
-    if (const char* e = getenv("SSRHIP_GEMVM_XFIRST")) r.xfirst = e[0] != '0';      // 1.3769 -> 1.3609 ms/step (A/B knob, read per call)
+    r.xfirst = 0;                                                                   // measured three ways, no consistent gain (see `xfirst` above): off
+    if (const char* e = getenv("SSRHIP_GEMVM_XFIRST")) r.xfirst = e[0] != '0';      // (A/B knob, read per call)
     const bool xreg = a->K <= 2048 || a->pro == SSRHIP_PRO_LAYERNORM;   // x slice of every wave in registers; else streamed beside W
     const int spwx = a->K <= 2048 ? 16 : 32;             // k-steps of x a wave keeps in registers
     if (xreg) {
