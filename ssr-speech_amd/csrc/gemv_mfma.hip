@@ -270,28 +270,27 @@ struct GemvR {
   int units;    // ceil(N / 8) 8-row units per group
   int wgs;      // workgroups per group (gridDim.x)
   int hd;
-  int xfirst;   // 1: the weights are requested only when the wave's x slice has ARRIVED (see below)
 };
 
 constexpr int MAXT = 4;     // 16-row tiles per workgroup (LDS: MAXT x 8 waves x 1 KiB of partial sums)
 
-// x and the LayerNorm BEFORE the weights (round 5; `xfirst` in the kernel parameters, SSRHIP_GEMVM_XFIRST=0 = round 4's order). What the
-// stamps of tools/gemvm_lab.hip showed on an LN + QKV launch at 16 rows (us after entry, median over 256 workgroups, wave 0):
-//     round 4's order:  x requested 1.1 | first 16 weight requests POSTED 5.1 | x seen 6.6 | LayerNorm done 8.4 | last MFMA 12.1 | end 15.2
-//     xfirst:           x requested 1.1 | x seen 1.7 | LayerNorm done 3.7 | weight requests posted 7.2 | last MFMA 12.6 | end 15.5
-// i.e. (1) the broadcast of x is NOT slow — 128 KB are in the registers of all eight waves 1.7 us after entry when nothing is queued in
-// front of them (tools/xbcast_lab.hip: 1.5 us for every CU reading the same 128 KB behind a kernel boundary); (2) POSTING 16 KB of weight
-// requests per wave takes 3.5-4 us in either order: a CU accepts HBM misses only at the rate earlier ones return (~36 GB/s), the wave is
-// in-order, so in round 4's order it sits in the request phase with its x long arrived, and the LayerNorm barrier waits for the slowest
-// wave to get through; (3) a bare s_barrier between the two request phases (all x requests in front of all weight requests) changed
-// nothing, and waiting for x without moving the LayerNorm did not either. With the LayerNorm in front of the weight requests the chain
-// x -> statistics -> barrier -> normalise runs while nothing else is queued, and the matrix work starts 1.1 us earlier (7.2 vs 8.3) on a
-// stream that started 2.6 us later: a wash. Measured three ways: tools/decode_ab.py (same box, alternating engines) 1.3857 -> 1.3748 and
-// 1.3769 -> 1.3609 ms/step in its favour; gemvm_bench (one shape chained) 966.6 -> 980.0 us per step's GEMVs against it; the kernel trace
-// of bench.py --utts 8 17.62 us per LayerNorm launch against round 4's 16.09 (other kernels within 2 % between the two boxes) against it.
-// It stays a knob, OFF. What a 16-row launch pays over the chain floor (9.5 us for 50 MB) is therefore: ~1 us to request x, ~4 us of a stream that runs at
-// 4.6-5.6 TB/s instead of 7.3 while the waves alternate between blocked request phases and matrix work, and ~3 us of tail (the slowest of
-// the eight K-slice waves reaches the partial-tile barrier 2 us after wave 0; merge + epilogue 1.1 us).
+// Where a 16-row launch spends its time (round 5, VERDICT r4 item 3: "attribute, do not guess") — the stamps of tools/gemvm_lab.hip on an
+// LN + QKV launch (us after entry, median over 256 workgroups, wave 0), and an experiment built on them that did NOT pay:
+//     as shipped:       x requested 1.1 | first 16 weight requests POSTED 5.1 | x seen 6.6 | LayerNorm done 8.4 | last MFMA 12.1 | end 15.2
+//     LayerNorm first:  x requested 1.1 | x seen 1.7 | LayerNorm done 3.7 | weight requests posted 7.2 | last MFMA 12.6 | end 15.5
+// (1) the broadcast of x is NOT slow — 128 KB are in the registers of all eight waves 1.7 us after entry when nothing is queued in front of
+// them (tools/xbcast_lab.hip: 1.5 us for every CU reading the same 128 KB behind a kernel boundary); (2) POSTING 16 KB of weight requests
+// per wave takes 3.5-4 us in either order: a CU accepts HBM misses only at the rate earlier ones return (~36 GB/s), the wave is in-order,
+// so as shipped it sits in the request phase with its x long arrived, and the LayerNorm barrier waits for the slowest wave to get through;
+// (3) a bare s_barrier between the two request phases (all x requests in front of all weight requests) changed nothing, waiting for x
+// without moving the LayerNorm did not either; (4) with the LayerNorm in FRONT of the weight requests the matrix work starts 1.1 us earlier
+// on a stream that started 2.6 us later — a wash: tools/decode_ab.py 1.3857 -> 1.3748 and 1.3769 -> 1.3609 ms/step for it, gemvm_bench
+// 966.6 -> 980.0 us per step's GEMVs against it. Not kept — and its runtime switch alone cost 1 us per LayerNorm launch while it was in
+// the source: with the weight requests under a (uniform) branch hipcc can no longer count them and waits for ALL of them before the
+// LayerNorm (`vmcnt(7) .. vmcnt(0)` where the straight-line code has `vmcnt(23) .. vmcnt(16)`; kernel trace 16.09 -> 17.13 us; logs under
+// profiles/r05_microbench/). What a 16-row launch pays over the chain floor (9.5 us for 50 MB) is: ~1 us to request x, ~4 us of a stream
+// that runs at 4.6-5.6 TB/s instead of 7.3 while the waves alternate between blocked request phases and matrix work, and ~3 us of tail (the
+// slowest of the eight K-slice waves reaches the partial-tile barrier 2 us after wave 0; merge + epilogue 1.1 us).
 
 __device__ __forceinline__ f4v mfma4(float a, float b, f4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -341,27 +340,19 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
   __builtin_amdgcn_sched_barrier(0);
   MSTAMP(6);
   const float* wp = tile_wptr(wbase, row_lo, nun, 0, c, ks, N, K, a.w_tiled) + (PAIR ? (c >> 3) * 128 : 0);
+  if (PAIR) {
+#pragma unroll
+    for (int i = 0; i < SPWX / 2; ++i) w[i] = ld_nt(wp + min(tbase + 2 * i, last - 1) * wstep);   // host: steps even, SPWX / 2 <= DEP
+  } else {
+#pragma unroll
+    for (int i = 0; i < DEP; ++i) w[i] = ld_nt(wp + min(tbase + i, last) * wstep);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  MSTAMP(7);
+  // what this wave's epilogue (tile `wave`) will need, requested now (behind the first weight loads, used after the last MFMA)
   const bool epi_mine = wave < ntile;
-  TileEpi epi0;
-  // the first weight requests + what this wave's epilogue (tile `wave`) will need (requested behind the weights, used after the last MFMA)
-  auto request_weights = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    if (PAIR) {
-#pragma unroll
-      for (int i = 0; i < SPWX / 2; ++i) w[i] = ld_nt(wp + min(tbase + 2 * i, last - 1) * wstep);   // host: steps even, SPWX / 2 <= DEP
-    } else {
-#pragma unroll
-      for (int i = 0; i < DEP; ++i) w[i] = ld_nt(wp + min(tbase + i, last) * wstep);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    MSTAMP(7);
-    epi0 = tile_epilogue_fetch(a, p.hd, grp, row_lo + wave * 16, epi_mine ? ((2 * wave + 1 < nun) ? 16 : 8) : 0, lane, kvpos);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // round 4's order: x requests, weight requests, then the LayerNorm. `xfirst`: x requests, wait, LayerNorm, THEN the weight requests (see
-  // `xfirst` above: a wave is stuck in the weight-request phase for ~4 us — the CU's request queue is full of x — and the LayerNorm barrier
-  // waits for the slowest of them).
-  if (!p.xfirst) request_weights();
+  const TileEpi epi0 = tile_epilogue_fetch(a, p.hd, grp, row_lo + wave * 16, epi_mine ? ((2 * wave + 1 < nun) ? 16 : 8) : 0, lane, kvpos);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = 0; t < SPWX; ++t) asm volatile("" : "+v"(xr[t].x), "+v"(xr[t].y), "+v"(xr[t].z), "+v"(xr[t].w));
 #pragma unroll
@@ -413,7 +404,6 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
   }
 
   MSTAMP(2);
-  if (p.xfirst) request_weights();
   if (PAIR) {
     f4v aA = {0.f, 0.f, 0.f, 0.f}, aB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -686,8 +676,6 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s) {
     r.steps = a->K / 16;
     r.hd = hd;
     r.units = (a->N + 7) / 8;
-    r.xfirst = 0;                                                                   // measured three ways, no consistent gain (see `xfirst` above): off
-    if (const char* e = getenv("SSRHIP_GEMVM_XFIRST")) r.xfirst = e[0] != '0';      // (A/B knob, read per call)
     const bool xreg = a->K <= 2048 || a->pro == SSRHIP_PRO_LAYERNORM;   // x slice of every wave in registers; else streamed beside W
     const int spwx = a->K <= 2048 ? 16 : 32;             // k-steps of x a wave keeps in registers
     if (xreg) {

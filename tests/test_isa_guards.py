@@ -117,6 +117,14 @@ def test_round5_decode_kernels_keep_their_request_order_in_the_isa(gemv_asm, tmp
     joined = "".join(seq)
     assert joined.startswith("L" * 16 + "w"), joined[:40]            # all K rows in flight before the first wait
     assert "L" * 16 in joined[17:], joined                            # the V rows in one run
+    # 16-row LayerNorm launches: the LayerNorm waits for the x slice ONLY — never for one of the 16 weight requests posted behind it (a
+    # runtime switch around the weight requests made hipcc lose count: `vmcnt(7) .. vmcnt(0)` in front of the LayerNorm, +1 us per launch)
+    mf = _asm(tmp_path_factory, "gemv_mfma")
+    sym = next(k for k in _kernel_meta(mf) if "gemv_rows_xreg_kernelILi1ELi16ELi16ELb0E" in k)
+    body = _whole_body(mf, sym)
+    head = body[:body.index("s_barrier")]
+    waits = [int(m.group(1)) for m in re.finditer(r"s_waitcnt[^\n]*vmcnt\((\d+)\)", head)]
+    assert waits and min(waits) >= 16, waits
 
 
 def test_generic_and_matrix_core_gemv_kernels_do_not_spill(gemv_asm, tmp_path_factory):
