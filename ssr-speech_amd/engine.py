@@ -129,7 +129,7 @@ class LMWeightsArena:
         """The four matrices of every layer as three bf16 planes each ([3][N][K], `ssrhip_split_weights`) for the PREFILL GEMMs: fp32
         operands split exactly, six cross products on the bf16 matrix cores (csrc/gemm_split.hip; +6 bytes per weight = +4.8 GB at 830M,
         built once on first use). `SSRHIP_PREFILL_SPLIT=0` keeps the prefill on the fp32 FMA chain. Returns True when created now."""
-        if getattr(self, "_ws_ready", False) or os.environ.get("SSRHIP_PREFILL_SPLIT", "1") in ("0",):
+        if getattr(self, "_ws_ready", False) or os.environ.get("SSRHIP_PREFILL_SPLIT", "1")[:1] == "0":      # the C side's rule (engine.hip): a value that starts with '0' 
             return False
         lib = _lib.lib()
         for lay in self.layers:

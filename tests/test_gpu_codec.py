@@ -393,3 +393,22 @@ def test_codec_calls_on_concurrent_streams_equal_the_single_stream_results():
         for i in range(3):
             for a, b in zip(alone[i], got[i]):
                 assert torch.equal(a, b), (rnd, i, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("knob", ["SSRHIP_GEMM_SPLIT_DMA=0", "SSRHIP_RESBLOCK_DMA=0", "SSRHIP_EPILOGUE_TM=0"])
+def test_reference_fixtures_under_every_surviving_codec_knob(knob):
+    """The codec keeps three superseded kernel generations behind switches that are read once per process (the 4-wave split GEMM — also the
+    fallback for views beyond the DMA kernel's 32-bit offsets —, the round-3 residual-block kernels, the general epilogue of the
+    transposed convolutions). The suite above runs the DEFAULT path; this runs the reference fixtures (end to end and per SEANet layer) and
+    the large-batch oracle comparison once more in a child process per switch, so that no shipped kernel goes unexecuted."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name, val = knob.split("=")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_codec.py"), "-x", "-q", "-k",
+                          "codec_matches_reference or every_seanet_layer or (large_batch_kernels and 20 and constant and False)"],
+                         env=dict(os.environ, **{name: val}), cwd=root, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-2000:]
+

@@ -100,6 +100,20 @@ def test_per_step_logits_match_reference(golden_dir, name, use_graph):
     print(f"{name}: max |logit diff| over {S} steps = {worst:.2e}")
 
 
+def test_prefill_on_the_fp32_chain_matches_the_reference_too():
+    """The prefill GEMMs run on the bf16 matrix cores with exactly split operands by default (the tests above) and on the fp32 FMA chain with
+    SSRHIP_PREFILL_SPLIT=0 (read once per process): the same per-step logit comparison with the reference (2e-4) and the end-to-end token
+    comparison in a child process with the switch at 0 — so both forms are within 2e-4 of the reference's logits (hence within 4e-4 of each
+    other) and both reproduce its greedy tokens on every golden."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_lm.py"), "-x", "-q", "-k",
+                          "(per_step_logits_match_reference and True) or inference_tokens_match_reference"],
+                         env=dict(os.environ, SSRHIP_PREFILL_SPLIT="0"), cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-2000:]
+
+
 def test_contract_errors():
     args = W.lm_args_tiny()
     m = _model(args, 1)

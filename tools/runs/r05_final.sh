@@ -1,4 +1,4 @@
-# round 5, GPU box: bench lines (1 and 8 utterances per GPU), rocprofv3 kernel traces and PMC passes of the FINAL build. `bash tools/r05_final.sh [bench|prof1|prof16|codec]`
+# round 5, GPU box: bench lines (1 and 8 utterances per GPU), rocprofv3 kernel traces and PMC passes of the FINAL build. `bash tools/runs/r05_final.sh [bench|prof1|prof16|codec]`
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5z; mkdir -p $O
 cd $R
 part=${1:-all}
