@@ -771,6 +771,10 @@ __global__ __launch_bounds__(SEG_TH, (TWO && PRO == SSRHIP_PRO_ATTN_COMBINE) ? 2
 // kernels gain from getting their LayerNorm out of the way of the weight requests (csrc/gemv_mfma.hip), here 16 KB of x per workgroup is no
 // obstacle and the later requests only cost: 0.8196 -> 0.8340 ms/step, 655.1 -> 674.6 us per step's GEMVs
 // (profiles/r05_microbench/decode_ab_ramp.log, gemvm_bench_2_ramp.log). Everything is requested at entry.
+// Also measured and NOT kept (round 5): a LayerNorm without the workgroup barrier — every wave fetches the other segment's x slice too and
+// computes both segments' statistics itself (same bits, one barrier left in the kernel, 149 VGPRs): 0.8047 -> 0.8098 ms/step, 657.6 ->
+// 664.2 us per step's GEMVs (profiles/r05_microbench/decode_ab_lnlocal.log): the second 8 KB per wave and the doubled statistics cost more
+// than the barrier they remove.
 template <int B, int PRO, int NUW, int DEPTH>
 __global__ __launch_bounds__(SEG_TH, 2) void gemv_segu_kernel(const GemvK p) {
   static_assert(PRO == SSRHIP_PRO_NONE || PRO == SSRHIP_PRO_LAYERNORM, "the split-KV merge prologue stays on gemv_seg_kernel");
