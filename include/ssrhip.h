@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSRHIP_VERSION 103
+#define SSRHIP_VERSION 104
 #define SSRHIP_PAGE 128          /* KV-cache page = 128 positions */
 #define SSRHIP_MAX_CODEBOOKS 4
 #define SSRHIP_MAX_SILENCE 8
@@ -97,6 +97,24 @@ typedef struct ssrhip_gemv_args {
 #define SSRHIP_TILED(b, k) ((((size_t)(k) >> 2) * 16 + (size_t)(b)) * 4 + ((k) & 3))
 
 int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream);
+
+/* Two consecutive launches of the 2-row decode step as ONE: `a` = FFN2 (+ bias + residual; models/modules/transformer.py:386-388 linear2
+ * and the residual add at :328-329) and `b` = the LayerNorm + Linear that reads a's output (the next
+ * layer's packed QKV projection — activation.py:86 — or the first Linear of the prediction heads, models/ssr.py:175-179), with the
+ * all-to-all edge between them inside the launch (csrc/gemv.hip gemv_pair_kernel: tagged 8-byte granules, write-through stores, one
+ * gather round trip). Results are bit-identical to ssrhip_gemv(a) followed by ssrhip_gemv(b).
+ *   returns 0 = launched, 1 = this (a, b) does not qualify (nothing launched: call ssrhip_gemv twice), < 0 = error.
+ *   Qualifies: B == 2 rows, a: PRO_NONE / ACT_NONE / EPI_RESIDUAL, K == 8192, N == 2048; b: PRO_LAYERNORM with folded gamma / beta,
+ *   K == 2048, x == a->y, N in {4096, 6144, 8192}, EPI_STORE or EPI_QKV_APPEND; >= 256 CUs; SSRHIP_GEMV_PAIR != 0.
+ *   ws: SSRHIP_PAIR_WS_BYTES of device memory, zeroed once by the caller and then owned by the chain of pair launches: three granule
+ *   buffers + the give-up flag. `buf` is the buffer this launch uses, `buf_next` (!= buf) the one the NEXT pair launch on this workspace
+ *   will use — this launch resets it. Consecutive pair launches must therefore follow each other's buf_next, cyclically.
+ *   The launch needs its 256 workgroups resident together; a workgroup that waits longer than ~1 s for the others gives up, sets the
+ *   flag and the outputs are garbage: ssrhip_gemv_pair_status (synchronises `stream`) returns 1 from then on. */
+#define SSRHIP_PAIR_WS_BYTES (3 * 4096 * 8 + 64)
+int ssrhip_gemv_pair_applicable(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b);
+int ssrhip_gemv_pair(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b, void* ws, int32_t buf, int32_t buf_next, ssrhip_stream_t stream);
+int ssrhip_gemv_pair_status(const void* ws, ssrhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Single-query attention over the paged cache, split over pages (one workgroup per page):
@@ -399,6 +417,9 @@ int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ssrhip_stream
 /* x[b] = embedding of row b's pending input token (next_tok / next_pos) for EVERY row of the engine — the closing step of ssrhip_lm_prefill
  * on its own (rows in mid-decode get exactly what the sampler's fused embedding left there: same function, same inputs). */
 int ssrhip_lm_embed_pending(ssrhip_lm* lm, ssrhip_stream_t stream);
+/* 0 = fine, 1 = a paired GEMV launch of this engine's decode step gave up waiting (ssrhip_gemv_pair): every token since is invalid;
+ * synchronises `stream`. Engines that do not pair (B != 2) always return 0. */
+int ssrhip_lm_pair_status(ssrhip_lm* lm, ssrhip_stream_t stream);
 
 /* run `n_steps` eager decode steps with a hipEvent pair around EVERY kernel launch (bench.py roofline).
  * out_us[i] = average microseconds of launch slot i of a step, out_kind[i] = 0 gemv | 1 attention | 2 sampler | 3 fused attention + out-proj;

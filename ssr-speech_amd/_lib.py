@@ -157,6 +157,9 @@ SYMBOLS = [
     ("ssrhip_sizeof", C.c_int, [C.c_int]),
     ("ssrhip_last_error", C.c_char_p, []),
     ("ssrhip_gemv", C.c_int, [C.POINTER(GemvArgs), C.c_void_p]),
+    ("ssrhip_gemv_pair_applicable", C.c_int, [C.POINTER(GemvArgs), C.POINTER(GemvArgs)]),
+    ("ssrhip_gemv_pair", C.c_int, [C.POINTER(GemvArgs), C.POINTER(GemvArgs), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    ("ssrhip_gemv_pair_status", C.c_int, [C.c_void_p, C.c_void_p]),
     ("ssrhip_attn_decode", C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     ("ssrhip_attn_combine", C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_void_p]),
     ("ssrhip_attn_rows", C.c_int, [C.POINTER(AttnArgs), C.c_void_p, C.c_void_p]),
@@ -180,6 +183,7 @@ SYMBOLS = [
     ("ssrhip_lm_decode", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("ssrhip_lm_prefill", C.c_int, [C.c_void_p, C.POINTER(PrefillArgs), C.c_void_p]),
     ("ssrhip_lm_embed_pending", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("ssrhip_lm_pair_status", C.c_int, [C.c_void_p, C.c_void_p]),
     ("ssrhip_lm_time_steps", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, c_f32p, c_i32p, C.c_int32]),
     ("ssrhip_lm_time_category", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, c_f32p, c_i32p]),
 ]

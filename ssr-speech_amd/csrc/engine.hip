@@ -55,6 +55,7 @@ struct ssrhip_lm {
   hipStream_t cap_stream = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  void* pair_ws = nullptr;      // granules of the paired GEMV launches (2-row step; SSRHIP_PAIR_WS_BYTES, owned)
 };
 
 namespace {
@@ -105,9 +106,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
   const int tiled = B > 4 ? 1 : 0;
   const bool wt = tiled && w.in_proj_wt;      // streaming-order weight copies for the matrix-core GEMV (include/ssrhip.h w_tiled)
 
-  if (tm) tm->slot = 0;
-
-  for (int l = 0; l < d.n_layer; ++l) {
+  auto qkv_args = [&](int l) {
     ssrhip_gemv_args g;
     // LN1 + packed QKV projection, q -> b.q, k/v appended in place into the paged cache
     memset(&g, 0, sizeof(g));
@@ -119,7 +118,57 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.kv = b.kv; g.layer = l; g.kv_pos = b.kv_pos;
     g.x_tiled = tiled;                         // q stays row-major for the attention kernel
     if (wt) { g.W = w.in_proj_wt[l]; g.w_tiled = 1; }
-    STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+    return g;
+  };
+  auto head1_args = [&]() {
+    ssrhip_gemv_args g;
+    // final LayerNorm + first Linear of the K prediction heads (stacked) + GELU
+    memset(&g, 0, sizeof(g));
+    g.W = w.head1_w; g.bias = w.head1_b; g.x = b.x; g.y = b.h;
+    g.B = B; g.N = K * Hh; g.K = D; g.groups = 1; g.x_stride = D; g.y_stride = K * Hh;
+    g.pro = SSRHIP_PRO_LAYERNORM; g.act = SSRHIP_ACT_GELU_ERF; g.epi = SSRHIP_EPI_STORE;
+    if (!d.ln_folded) { g.ln_w = w.lnf_w; g.ln_b = w.lnf_b; }
+    g.ln_eps = 1e-5f;
+    g.x_tiled = tiled; g.y_tiled = tiled;
+    if (wt) { g.W = w.head1_wt; g.w_tiled = 1; }
+    return g;
+  };
+  auto ffn2_args = [&](int l) {
+    ssrhip_gemv_args g;
+    memset(&g, 0, sizeof(g));
+    g.W = w.ffn2_w[l]; g.bias = w.ffn2_b[l]; g.x = b.h; g.y = b.x;
+    g.B = B; g.N = D; g.K = d.d_ffn; g.groups = 1; g.x_stride = d.d_ffn; g.y_stride = D;
+    g.pro = SSRHIP_PRO_NONE; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_RESIDUAL;
+    g.x_tiled = tiled; g.y_tiled = tiled;
+    if (wt) { g.W = w.ffn2_wt[l]; g.w_tiled = 1; }
+    return g;
+  };
+  // 2-row step: FFN2 of layer l and the launch that consumes its output (QKV of layer l + 1; the head MLP after the last layer) run as ONE
+  // launch with the all-to-all edge inside it (csrc/gemv.hip gemv_pair_kernel). The pairs of a step use the three granule buffers of
+  // lm->pair_ws cyclically: pair i uses buffer i % 3 and resets the buffer of pair (i + 1) % n — closed over the step, so that graph
+  // replays (and eager steps) always find their buffer reset by the launch before them; with n % 3 == 1 the last pair takes buffer 1.
+  int n_pairs = 0;
+  bool pair_qkv = false, pair_head = false;
+  if (lm->pair_ws && B == 2) {
+    const ssrhip_gemv_args fa = ffn2_args(0);
+    if (d.n_layer > 1) { const ssrhip_gemv_args qa = qkv_args(1); pair_qkv = ssrhip_gemv_pair_applicable(&fa, &qa) != 0; }
+    { const ssrhip_gemv_args ha = head1_args(); pair_head = ssrhip_gemv_pair_applicable(&fa, &ha) != 0; }
+    n_pairs = (pair_qkv ? d.n_layer - 1 : 0) + (pair_head ? 1 : 0);
+    if (n_pairs < 2) { n_pairs = 0; pair_qkv = pair_head = false; }
+  }
+  auto pair_buf = [&](int i) { return (i == n_pairs - 1 && n_pairs % 3 == 1) ? 1 : i % 3; };
+  int pair_i = 0;
+  bool qkv_done = false;                        // this layer's QKV already ran inside the previous layer's pair launch
+
+  if (tm) tm->slot = 0;
+
+  for (int l = 0; l < d.n_layer; ++l) {
+    ssrhip_gemv_args g;
+    if (!qkv_done) {
+      g = qkv_args(l);
+      STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+    }
+    qkv_done = false;
 
     ssrhip_attn_args at;
     memset(&at, 0, sizeof(at));
@@ -167,27 +216,25 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     if (wt) { g.W = w.ffn1_wt[l]; g.w_tiled = 1; }
     STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
 
-    // FFN2 + residual
-    memset(&g, 0, sizeof(g));
-    g.W = w.ffn2_w[l]; g.bias = w.ffn2_b[l]; g.x = b.h; g.y = b.x;
-    g.B = B; g.N = D; g.K = d.d_ffn; g.groups = 1; g.x_stride = d.d_ffn; g.y_stride = D;
-    g.pro = SSRHIP_PRO_NONE; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_RESIDUAL;
-    g.x_tiled = tiled; g.y_tiled = tiled;
-    if (wt) { g.W = w.ffn2_wt[l]; g.w_tiled = 1; }
-    STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+    // FFN2 + residual — paired with the next launch where that applies
+    g = ffn2_args(l);
+    const bool last = l == d.n_layer - 1;
+    if (last ? pair_head : pair_qkv) {
+      const ssrhip_gemv_args nx = last ? head1_args() : qkv_args(l + 1);
+      const int bufi = pair_buf(pair_i), bufn = pair_buf((pair_i + 1) % n_pairs);
+      STEP_CALL(CAT_GEMV, ssrhip_gemv_pair(&g, &nx, lm->pair_ws, bufi, bufn, (ssrhip_stream_t)s));
+      pair_i += 1;
+      qkv_done = true;                          // (after the last layer: the head MLP's first launch)
+    } else {
+      STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+    }
   }
   {
     ssrhip_gemv_args g;
-    // final LayerNorm + first Linear of the K prediction heads (stacked) + GELU
-    memset(&g, 0, sizeof(g));
-    g.W = w.head1_w; g.bias = w.head1_b; g.x = b.x; g.y = b.h;
-    g.B = B; g.N = K * Hh; g.K = D; g.groups = 1; g.x_stride = D; g.y_stride = K * Hh;
-    g.pro = SSRHIP_PRO_LAYERNORM; g.act = SSRHIP_ACT_GELU_ERF; g.epi = SSRHIP_EPI_STORE;
-    if (!d.ln_folded) { g.ln_w = w.lnf_w; g.ln_b = w.lnf_b; }
-    g.ln_eps = 1e-5f;
-    g.x_tiled = tiled; g.y_tiled = tiled;
-    if (wt) { g.W = w.head1_wt; g.w_tiled = 1; }
-    STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+    if (!qkv_done) {
+      g = head1_args();
+      STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+    }
     // second Linear of each head: K groups
     memset(&g, 0, sizeof(g));
     g.W = w.head2_w; g.bias = w.head2_b; g.x = b.h; g.y = b.logits;
@@ -261,8 +308,22 @@ extern "C" int ssrhip_lm_create(const ssrhip_lm_dims* d, const ssrhip_lm_weights
     }
   }
   { const char* e = getenv("SSRHIP_PREFILL_SPLIT"); lm->prefill_split = has_ws && !(e && e[0] == '0'); }
+  if (b->B == 2) {                              // granules + give-up flag of the paired GEMV launches (zeroed: every tag invalid)
+    if (hipMalloc(&lm->pair_ws, SSRHIP_PAIR_WS_BYTES) != hipSuccess || hipMemset(lm->pair_ws, 0, SSRHIP_PAIR_WS_BYTES) != hipSuccess) {
+      if (lm->pair_ws) hipFree(lm->pair_ws);
+      delete lm;
+      ssrhip_set_error("ssrhip_lm_create: allocating the pair workspace failed");
+      return -1;
+    }
+  }
   *out = lm;
   return 0;
+}
+
+extern "C" int ssrhip_lm_pair_status(ssrhip_lm* lm, ssrhip_stream_t stream) {
+  SSR_REQUIRE(lm, "ssrhip_lm_pair_status: null engine");
+  if (!lm->pair_ws) return 0;
+  return ssrhip_gemv_pair_status(lm->pair_ws, stream);
 }
 
 extern "C" void ssrhip_lm_destroy(ssrhip_lm* lm) {
@@ -270,6 +331,7 @@ extern "C" void ssrhip_lm_destroy(ssrhip_lm* lm) {
   if (lm->exec) hipGraphExecDestroy(lm->exec);
   if (lm->graph) hipGraphDestroy(lm->graph);
   if (lm->cap_stream) hipStreamDestroy(lm->cap_stream);
+  if (lm->pair_ws) hipFree(lm->pair_ws);
   delete lm;
 }
 

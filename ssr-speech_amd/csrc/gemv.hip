@@ -874,6 +874,249 @@ __global__ __launch_bounds__(SEG_TH, 2) void gemv_segu_kernel(const GemvK p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 5: TWO consecutive GEMVs of the 2-row step in ONE launch — `A` = FFN2 (+ bias + residual, K = 8192, N = D = 2048) and `B` = the
+// launch that consumes its output through a LayerNorm (QKV of the next layer, or the head MLP after the last layer) — with the all-to-all
+// edge between them (every CU needs all B x D outputs of A) inside the launch. tools/layer_edge_lab.hip priced 8 forms of that edge on
+// this machine (profiles/r05_microbench/layer_edge_lab.log): two launches 21.3 us; one edge wave gathering alone 22.8; requests of B posted
+// before the publish 23.6 (the publish queues behind 128 KB of requests); ... ; this form 19.7-19.9:
+//   * 256 workgroups (one per CU) x 12 waves. Waves 0-7 stream A's units exactly as gemv_segu_kernel does and park the partial sums.
+//   * barrier; wave 8 finishes the workgroup's 8 rows x 2 outputs, writes them to the residual stream AND publishes them as 8-byte
+//     {value, tag = 1} granules with agent-scope (write-through, sc1) stores; barrier; only now waves 0-7 post their first THREE units of B
+//     (the weights do not depend on the edge; not all four: 128 KB per CU of requests in front of the gather's loads delay it by ~3 us).
+//   * waves 8-11 gather a quarter of the 4096 granules each — 8 x 16-byte sc1 loads per lane, ONE round trip per sweep — until every tag
+//     is valid, and put x' into LDS; barrier; waves 0-7 read their slice from LDS, post the fourth unit, LayerNorm, B's units, B's epilogue.
+//   * tags: three granule buffers; consecutive pair launches of a step use different ones and every launch resets (plain stores, visible
+//     behind the kernel boundary) the buffer the NEXT pair launch will use, so a tag of 1 is always this launch's (the host assigns the
+//     buffers, cyclically closed over the step so that graph replays stay consistent).
+// Every partial sum, every statistic and every epilogue is computed by the same operations in the same order as in the two launches
+// (tests compare bit for bit; tools/layer_edge_lab.hip compared 192 chained edges).
+// The spin is bounded (~1 s): a workgroup that gives up sets ws->gave_up and results are garbage from there on — the host checks the
+// flag (ssrhip_gemv_pair_status) and raises. The launch needs all its 256 workgroups resident at the same time: true on an otherwise
+// idle or ordinarily busy GPU (other kernels finish and make room), NOT when a second pair launch of another stream / process holds
+// half the CUs at the same moment — one decode chain per device, or SSRHIP_GEMV_PAIR=0.
+constexpr int PAIR_D = 2048, PAIR_NE = 4, PAIR_TH = SEG_TH + 64 * PAIR_NE, PAIR_GRAN = 2 * PAIR_D, PAIR_PF = 3, PAIR_DEPTH = 4, PAIR_NUWA = 8;
+constexpr int PAIR_SPINS = 400000;
+struct PairK {
+  GemvK a, b;
+  unsigned long long* gran;        // this launch's granules [PAIR_GRAN]: index n * 2 + row
+  unsigned long long* gran_next;   // the next pair launch's buffer: reset here
+  int* gave_up;
+};
+typedef float pair_v4f __attribute__((ext_vector_type(4)));
+// eight 16-byte agent-scope loads of the sweep, issued together and waited for together; hipcc must not see them (its wait-count
+// bookkeeping would otherwise serialise them against the streaming waves' loads at the join)
+__device__ __forceinline__ void pair_sweep8(const unsigned long long* p, pair_v4f (&g)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:1024 sc1\n\t"
+      "global_load_dwordx4 %2, %8, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:3072 sc1\n\t"
+      "global_load_dwordx4 %4, %9, off sc1\n\tglobal_load_dwordx4 %5, %9, off offset:1024 sc1\n\t"
+      "global_load_dwordx4 %6, %9, off offset:2048 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:3072 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7])
+      : "v"(p), "v"(p + 512)
+      : "memory");
+}
+
+// The two ROLES are the two arms of ONE (wave-uniform) branch and every barrier is written in both arms. A first form — a series of
+// `if (wave < 8)` blocks with joins in between — made hipcc's wait-count pass merge the "block skipped" path into every join: the first use
+// of a unit requested two blocks earlier was guarded by `s_waitcnt vmcnt(4 * PF - 1)` instead of vmcnt(15) (B's phase ran with 8 loads in
+// flight per wave instead of 16), the registers of wave 8's epilogue operands were zeroed on the streaming path behind a vmcnt(0), and the
+// kernel took 150 VGPRs instead of 112 (read off the ISA; tools/layer_edge_lab.hip modes 6 / 7 against 9 / 10).
+template <int NUWB>
+__global__ __launch_bounds__(PAIR_TH, 2) void gemv_pair_kernel(const PairK p) {
+  constexpr int B = 2, DEPTH = PAIR_DEPTH, NUWA = PAIR_NUWA, PF = PAIR_PF;
+  constexpr int RA = 8, SA = 8, SHA = 3;                           // A: 8 rows per workgroup, K = 8192 = 8 segments, wave w owns segment w
+  constexpr int SB = 2, SHB = 1, RB = NUWB * SEG_NW / SB;          // B: K = 2048 = 2 segments, NUWB units per wave
+  __shared__ float partA[RA * SA * B];
+  __shared__ float partB[RB * SB * B];
+  __shared__ float aux[SB * B * 2];
+  __shared__ __attribute__((aligned(16))) float xs[B * PAIR_D];
+  __shared__ size_t kvoff[B * 2];
+  const ssrhip_gemv_args& a = p.a.a;
+  const ssrhip_gemv_args& bb = p.b.a;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int rA0 = (int)blockIdx.x * RA, rB0 = (int)blockIdx.x * RB;
+  if (wave < SEG_NW) {
+    // ================= streaming role: gemv_segu_kernel<2, PRO_NONE, 8, 4> for A, then <2, PRO_LAYERNORM, NUWB, 4> for B, operation for operation
+    const int segB = wave & (SB - 1);
+    const float* WgA = a.W + (size_t)rA0 * a.K + wave * SEG + lane * 4;
+    const float* WgB = bb.W + (size_t)rB0 * bb.K + segB * SEG + lane * 4;
+    // ---- 0. B's epilogue operand of the (row, b) this thread finalises (wave 0's threads do): the wave's oldest load
+    RowEpi efinB = {0.f, 0.f};
+    const int bfin = t % B, rfinB = min(t / B, RB - 1), nfinB = rB0 + rfinB;
+    efinB.bias = bb.bias ? bb.bias[nfinB] : 0.f;
+    // ---- 1. the wave's slice of A's input (L2), then its first DEPTH units (HBM, non-temporal)
+    float4 xr[B][4];
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[b][i] = ld4(a.x + (size_t)b * a.x_stride + wave * SEG + (i * 64 + lane) * 4);
+    float4 w[DEPTH][4];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(WgA + (size_t)((wave + SEG_NW * j) >> SHA) * a.K + i * 256);
+    // ---- 2. A's units
+#pragma unroll
+    for (int j = 0; j < NUWA; ++j) {
+      float4 (&wj)[4] = w[j % DEPTH];
+      float acc[B][2];
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[b][0] = acc[b][1] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[b][i & 1] = dot4(wj[i], xr[b][i], acc[b][i & 1]);
+        if (j + DEPTH < NUWA) {
+          __builtin_amdgcn_sched_barrier(0);
+          wj[i] = ld_nt(WgA + (size_t)((wave + SEG_NW * (j + DEPTH)) >> SHA) * a.K + i * 256);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      float mine = 0.f;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const float sum = wave_sum(acc[b][0] + acc[b][1]);
+        if (lane == b) mine = sum;
+      }
+      if (lane < B) partA[(wave + SEG_NW * j) * B + lane] = mine;
+    }
+    __syncthreads();                                                // (1) A's partial sums are parked
+    __syncthreads();                                                // (1b) wave 8 has issued the publish
+    // ---- 3. B's first units: PF of them now, the rest behind the gather
+#pragma unroll
+    for (int j = 0; j < PF; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(WgB + (size_t)((wave + SEG_NW * j) >> SHB) * bb.K + i * 256);
+    __syncthreads();                                                // (2) x' is in LDS
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[b][i] = *reinterpret_cast<const float4*>(xs + b * PAIR_D + segB * SEG + (i * 64 + lane) * 4);
+#pragma unroll
+    for (int j = PF; j < DEPTH; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(WgB + (size_t)((wave + SEG_NW * j) >> SHB) * bb.K + i * 256);
+    // ---- 4. B's LayerNorm
+    {
+      float m[B], q[B];
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        float s0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s0 += (xr[b][i].x + xr[b][i].y) + (xr[b][i].z + xr[b][i].w);
+        m[b] = wave_sum(s0) * (1.0f / SEG);
+        float q0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float dx = xr[b][i].x - m[b], dy = xr[b][i].y - m[b], dz = xr[b][i].z - m[b], dw = xr[b][i].w - m[b];
+          q0 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        q[b] = wave_sum(q0);
+        if (wave < SB && lane == 0) { aux[(wave * B + b) * 2] = m[b]; aux[(wave * B + b) * 2 + 1] = q[b]; }
+      }
+      __syncthreads();                                              // (3)
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        float mean = 0.f, M2 = 0.f, dev = 0.f;
+        for (int s2 = 0; s2 < SB; ++s2) mean += aux[(s2 * B + b) * 2];
+        mean /= (float)SB;
+        for (int s2 = 0; s2 < SB; ++s2) { const float dm = aux[(s2 * B + b) * 2] - mean; M2 += aux[(s2 * B + b) * 2 + 1]; dev = fmaf(dm, dm, dev); }
+        const float var = (M2 + (float)SEG * dev) / (float)bb.K;
+        const float rstd = 1.0f / sqrtf(var + bb.ln_eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          xr[b][i] = make_float4((xr[b][i].x - mean) * rstd, (xr[b][i].y - mean) * rstd, (xr[b][i].z - mean) * rstd, (xr[b][i].w - mean) * rstd);
+      }
+    }
+    // ---- 5. B's units
+#pragma unroll
+    for (int j = 0; j < NUWB; ++j) {
+      float4 (&wj)[4] = w[j % DEPTH];
+      float acc[B][2];
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[b][0] = acc[b][1] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[b][i & 1] = dot4(wj[i], xr[b][i], acc[b][i & 1]);
+        if (j + DEPTH < NUWB) {
+          __builtin_amdgcn_sched_barrier(0);
+          wj[i] = ld_nt(WgB + (size_t)((wave + SEG_NW * (j + DEPTH)) >> SHB) * bb.K + i * 256);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      float mine = 0.f;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const float sum = wave_sum(acc[b][0] + acc[b][1]);
+        if (lane == b) mine = sum;
+      }
+      if (lane < B) partB[(wave + SEG_NW * j) * B + lane] = mine;
+    }
+    __syncthreads();                                                // (4)
+    if (t < RB * B) {
+      float v = 0.f;
+      for (int s2 = 0; s2 < SB; ++s2) v += partB[(rfinB * SB + s2) * B + bfin];
+      // K / V append addresses: resolved by the edge role (wave 9) while this role streamed — the kv_pos -> page table -> pool chain costs
+      // the streaming waves nothing here (in gemv_segu_kernel it is two scalar round trips per wave under the first units' latency)
+      float* kvb[2] = {bb.kv.pool + kvoff[bfin * 2], bb.kv.pool + kvoff[bfin * 2 + 1]};
+      finalize(p.b, 0, nfinB, bfin, v, efinB, kvb);
+    }
+  } else {
+    // ================= edge role (waves 8-11)
+    const int e = wave - SEG_NW;
+    RowEpi efinA = {0.f, 0.f};
+    if (e == 0 && lane < RA * B) {
+      efinA.bias = a.bias ? a.bias[rA0 + (lane >> 1)] : 0.f;
+      efinA.resid = a.y[(size_t)(lane & 1) * a.y_stride + rA0 + (lane >> 1)];
+      p.gran_next[(size_t)blockIdx.x * (RA * B) + lane] = 0ull;     // reset the NEXT pair launch's granules (this workgroup's 16 of them)
+    }
+    if (bb.epi == SSRHIP_EPI_QKV_APPEND && e == 1 && lane < B) {    // kv_append_bases()'s arithmetic for batch row `lane`, as element offsets
+      const int pos = bb.kv_pos[lane];
+      const int page = bb.kv.table[(size_t)lane * bb.kv.max_pages + (pos / SSRHIP_PAGE)];
+      const size_t k0 = ((((size_t)page * bb.kv.n_layer + bb.layer) * 2 + 0) * bb.kv.n_head) * SSRHIP_PAGE + (pos % SSRHIP_PAGE);
+      const size_t v0 = ((((size_t)page * bb.kv.n_layer + bb.layer) * 2 + 1) * bb.kv.n_head) * SSRHIP_PAGE + (pos % SSRHIP_PAGE);
+      kvoff[lane * 2 + 0] = k0 * bb.kv.head_dim;
+      kvoff[lane * 2 + 1] = v0 * bb.kv.head_dim;
+    }
+    __syncthreads();                                                // (1)
+    if (e == 0 && lane < RA * B) {
+      // A's epilogue — finalize()'s RESIDUAL arm — into the residual stream and, tagged, into this launch's granules
+      const int r = lane >> 1, b = lane & 1, n = rA0 + r;
+      float v = 0.f;
+      for (int s2 = 0; s2 < SA; ++s2) v += partA[(r * SA + s2) * B + b];
+      v += efinA.bias;
+      const float out = efinA.resid + v;
+      a.y[(size_t)b * a.y_stride + n] = out;
+      const unsigned long long gval = ((unsigned long long)1u << 32) | (unsigned long long)__float_as_uint(out);
+      __hip_atomic_store(p.gran + (size_t)n * 2 + b, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                                // (1b)
+    // gather this wave's quarter of the granules: one round trip per sweep, until every tag is this launch's
+    pair_v4f g[8];
+    bool done = false;
+    for (int spin = 0; spin < PAIR_SPINS && !done; ++spin) {
+      bool all = true;
+      pair_sweep8(p.gran + (size_t)e * 1024 + lane * 2, g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        all = all && (__float_as_uint(g[i][1]) == 1u) && (__float_as_uint(g[i][3]) == 1u);
+        const int gi = e * 1024 + (i >> 2) * 512 + (i & 3) * 128 + lane * 2;   // granule index of g[i].xy (row 0 of output gi / 2); .zw: row 1
+        xs[(gi >> 1)] = g[i][0];
+        xs[PAIR_D + (gi >> 1)] = g[i][2];
+      }
+      done = __all(all);
+      if (!done) __builtin_amdgcn_s_sleep(2);
+    }
+    if (!done && lane == 0) *p.gave_up = 1;
+    __syncthreads();                                                // (2)
+    __syncthreads();                                                // (3)
+    __syncthreads();                                                // (4)
+  }
+}
+
 // Round 4 measured the opposite organisation too — ALL of a wave's units requested at kernel entry, one 8-wave workgroup per CU (256 VGPRs):
 // bit-identical results, 12.4 us per launch in the step against 10.5 here (profiles/r04_microbench/decode_ab.log; the lab form of the same
 // idea is tools/gemv_floor_lab.hip mode 4: 10.0 us against 9.2-9.5 for 1-4 units in flight). Removed again.
@@ -976,6 +1219,73 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s);   // gemv
 extern "C" void ssrhip_debug_gemv_prof(void* dev_ptr) { g_gemv_prof = (long long*)dev_ptr; }
 #endif
 
+// Units per wave of B if (a, b) can run as one gemv_pair_kernel launch, 0 otherwise
+static int pair_nuwb(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b, int num_cu) {
+  if (num_cu < 256) return 0;                                       // 256 workgroups must be resident together
+  if (a->B != 2 || b->B != 2 || a->groups != 1 || b->groups != 1) return 0;
+  if (a->x_tiled || a->y_tiled || a->w_tiled || b->x_tiled || b->y_tiled || b->w_tiled) return 0;
+  if (a->pro != SSRHIP_PRO_NONE || a->act != SSRHIP_ACT_NONE || a->epi != SSRHIP_EPI_RESIDUAL || a->K != 8192 || a->N != PAIR_D || !a->x || !a->y || !a->W) return 0;
+  if (b->pro != SSRHIP_PRO_LAYERNORM || b->ln_w || b->ln_b || b->K != PAIR_D || b->x != a->y || b->x_stride != a->y_stride || !b->W || !b->y) return 0;
+  if (b->epi != SSRHIP_EPI_STORE && b->epi != SSRHIP_EPI_QKV_APPEND) return 0;
+  if (b->epi == SSRHIP_EPI_QKV_APPEND && !(b->N == 3 * b->K && b->kv.pool && b->kv.table && b->kv_pos && b->kv.head_dim > 0)) return 0;
+  if (b->N % 256 != 0) return 0;
+  const int nuwb = (b->N / 256) * 2 / SEG_NW;
+  if ((b->N / 256) * 2 % SEG_NW != 0 || (nuwb != 4 && nuwb != 6 && nuwb != 8)) return 0;
+  if (const char* e = getenv("SSRHIP_GEMV_PAIR")) { if (e[0] == '0') return 0; }   // read at every call (A/B inside one process)
+  return nuwb;
+}
+
+static void ensure_num_cu() {
+  if (g_num_cu == 0) {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) g_num_cu = cu;
+    else g_num_cu = 256;
+    if (const char* e = getenv("SSRHIP_GEMV_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 3) g_blocks_per_cu = v; }   // tuning knob
+  }
+}
+
+extern "C" int ssrhip_gemv_pair_applicable(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b) {
+  if (!a || !b) return 0;
+  ensure_num_cu();
+  return pair_nuwb(a, b, g_num_cu) != 0;
+}
+
+extern "C" int ssrhip_gemv_pair(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b, void* ws, int32_t buf, int32_t buf_next, ssrhip_stream_t stream) {
+  SSR_REQUIRE(a && b && ws, "ssrhip_gemv_pair: null argument");
+  SSR_REQUIRE(buf >= 0 && buf < 3 && buf_next >= 0 && buf_next < 3 && buf != buf_next, "ssrhip_gemv_pair: granule buffers %d -> %d (0..2, different)", buf, buf_next);
+  ensure_num_cu();
+  const int nuwb = pair_nuwb(a, b, g_num_cu);
+  if (!nuwb) return 1;
+  PairK p;
+  auto fill = [](GemvK& k, const ssrhip_gemv_args* g, int S) {
+    k.a = *g; k.nslice = S; k.slice_len = SEG; k.nch = 4; k.groups_x = 256; k.hd = (g->kv.head_dim > 0) ? g->kv.head_dim : 1;
+    k.seg_shift = (S == 8) ? 3 : 1; k.rows_max = k.rows_per = g->N / 256; k.rows_rem = 0; k.prof = nullptr;
+  };
+  fill(p.a, a, 8);
+  fill(p.b, b, 2);
+  unsigned long long* gran = (unsigned long long*)ws;
+  p.gran = gran + (size_t)buf * PAIR_GRAN;
+  p.gran_next = gran + (size_t)buf_next * PAIR_GRAN;
+  p.gave_up = (int*)(gran + 3 * (size_t)PAIR_GRAN);
+  hipStream_t s = (hipStream_t)stream;
+  if (nuwb == 4) hipLaunchKernelGGL((gemv_pair_kernel<4>), dim3(256), dim3(PAIR_TH), 0, s, p);
+  else if (nuwb == 6) hipLaunchKernelGGL((gemv_pair_kernel<6>), dim3(256), dim3(PAIR_TH), 0, s, p);
+  else hipLaunchKernelGGL((gemv_pair_kernel<8>), dim3(256), dim3(PAIR_TH), 0, s, p);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ssrhip_gemv_pair_status(const void* ws, ssrhip_stream_t stream) {
+  SSR_REQUIRE(ws, "ssrhip_gemv_pair_status: null workspace");
+  int flag = 0;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { ssrhip_set_error("ssrhip_gemv_pair_status: stream synchronize failed"); return -1; }
+  if (hipMemcpy(&flag, (const char*)ws + 3 * (size_t)PAIR_GRAN * 8, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+    ssrhip_set_error("ssrhip_gemv_pair_status: copy failed");
+    return -1;
+  }
+  return flag ? 1 : 0;
+}
+
 extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && a->W && a->y, "ssrhip_gemv: null argument");
   SSR_REQUIRE(a->N > 0 && a->groups >= 1 && a->K > 0, "ssrhip_gemv: bad N/K/groups");
@@ -985,12 +1295,7 @@ extern "C" int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream) {
   SSR_REQUIRE(a->pro != SSRHIP_PRO_ATTN_COMBINE || (a->kv.head_dim > 0 && a->K <= 2048 && a->B * (a->K / a->kv.head_dim) <= 256), "ssrhip_gemv: combine prologue needs K <= 2048 and B*H <= 256");
   SSR_REQUIRE(a->K > 0 && a->K % 4 == 0 && a->K <= 8192, "ssrhip_gemv: K=%d must be a multiple of 4, <= 8192", a->K);
   SSR_REQUIRE(a->N > 0 && a->groups >= 1, "ssrhip_gemv: bad N/groups");
-  if (g_num_cu == 0) {
-    int dev = 0, cu = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) g_num_cu = cu;
-    else g_num_cu = 256;
-    if (const char* e = getenv("SSRHIP_GEMV_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 3) g_blocks_per_cu = v; }   // tuning knob
-  }
+  ensure_num_cu();
   if (a->pro != SSRHIP_PRO_NONE) {
     SSR_REQUIRE(a->groups == 1 || a->pro == SSRHIP_PRO_LAYERNORM, "ssrhip_gemv: combine prologue needs groups==1");
     if (a->pro == SSRHIP_PRO_LAYERNORM) SSR_REQUIRE(a->x && ((a->ln_w && a->ln_b) || (!a->ln_w && !a->ln_b)), "ssrhip_gemv: LayerNorm prologue needs x and either both or none of ln_w/ln_b");

@@ -736,6 +736,13 @@ class DecodeEngine:
 
     def states(self) -> List[_lib.SamplerState]:
         raw = bytes(self.state_dev.cpu().numpy().tobytes())
+        # the 2-row step pairs FFN2 with the next launch inside one kernel (csrc/gemv.hip gemv_pair_kernel); a workgroup of such a launch that
+        # waited ~1 s for the others (a second decode chain holding half the GPU at the same moment) gives up and flags it: nothing since is valid
+        rc = self.lib.ssrhip_lm_pair_status(self._ctx, _lib.stream_ptr())
+        if rc == 1:
+            raise RuntimeError("a paired GEMV launch of the decode step gave up waiting for its other workgroups (is a second decode chain "
+                               "running on this GPU?): the tokens since the last poll are invalid. Run one chain per device or set SSRHIP_GEMV_PAIR=0.")
+        _lib.check(rc, "ssrhip_lm_pair_status")
         arr = (_lib.SamplerState * self.n_utt).from_buffer_copy(raw)
         return list(arr)
 

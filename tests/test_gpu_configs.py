@@ -59,6 +59,21 @@ def test_config2_830m_sampled_top_k40_top_p08_matches_oracle():
     assert len({tuple(t) for t in ref_tok.tolist()}) > 5            # it really sampled (not one token repeated)
     # the global generator is left where the reference's loop leaves it: exactly `steps` multinomial draws consumed
     assert torch.equal(torch.get_rng_state(), rng_after_ref)
+    # the run above paired FFN2 with the next launch (csrc/gemv.hip gemv_pair_kernel, default on a 256-CU part); the unpaired step
+    # (SSRHIP_GEMV_PAIR=0, read when the step is enqueued) must sample the same tokens from bit-identical logits
+    logits_paired = eng.dbg_logits.clone() if getattr(eng, "dbg_logits", None) is not None else None
+    m._engines.clear()
+    os.environ["SSRHIP_GEMV_PAIR"] = "0"
+    try:
+        torch.manual_seed(4242)
+        m.inference(x.cuda(), torch.LongTensor([L]), x.cuda(), torch.LongTensor([L]), y.cuda(), y.cuda(), mi.cuda(),
+                    uncond_x=unc, max_new_steps=steps, **kw)
+    finally:
+        del os.environ["SSRHIP_GEMV_PAIR"]
+    eng0 = next(iter(m._engines.values()))
+    assert np.array_equal(eng0.generated[0, :steps].cpu().numpy(), ref_tok)
+    if logits_paired is not None and getattr(eng0, "dbg_logits", None) is not None:
+        assert torch.equal(eng0.dbg_logits, logits_paired)
 
 
 def test_config4_830m_sixteen_rows_match_oracle():

@@ -301,6 +301,71 @@ np.savez(sys.argv[1], **out)
             assert np.array_equal(res[knob][key], want), (knob, key, float(np.abs(res[knob][key] - want).max()))
 
 
+def test_gemv_pair_launch_is_bit_identical_to_the_two_launches(L):
+    """Round 5's `gemv_pair_kernel` (csrc/gemv.hip): FFN2 + residual and the LayerNorm + Linear that consumes it as ONE launch, the
+    all-to-all edge between them inside the kernel (tagged granules, write-through stores, gather). For each of the three consumers of
+    the 830M step's shape family — LN + QKV with the K/V append (N = 6144), LN + head-MLP1 + GELU (4096), LN + FFN1 + ReLU (8192) — a
+    chain of 7 pairs (the three granule buffers cycled the way the engine cycles them, closed over the chain and replayed twice: stale
+    tags would show) must leave the residual stream, the consumer's output and the cache BIT-identical to 14 separate ssrhip_gemv calls."""
+    if torch.cuda.get_device_properties(0).multi_processor_count < 256:
+        pytest.skip("the pair launch needs 256 CUs")
+    B, D, F = 2, 2048, 8192
+    ws = torch.zeros(_lib_pair_ws_bytes() // 4, dtype=torch.int32, device="cuda")
+    for name, N, act, epi in [("qkv", 6144, 0, 2), ("head1", 4096, 2, 0), ("ffn1", 8192, 1, 0)]:
+        g = torch.Generator().manual_seed(N)
+        W2 = [(torch.randn(D, F, generator=g) / math.sqrt(F)).cuda() for _ in range(2)]
+        b2 = torch.randn(D, generator=g).cuda()
+        Wn = [(torch.randn(N, D, generator=g) / math.sqrt(D)).cuda() for _ in range(2)]
+        bn = torch.randn(N, generator=g).cuda()
+        h = (torch.randn(B, F, generator=g) * 0.7).cuda()
+        x0 = (torch.randn(B, D, generator=g) * 1.5 + 0.3)
+        H, hd, n_layer, max_pages = 16, 128, 2, 4
+        table = torch.tensor([[5, 2, 7, 1], [0, 6, 3, 4]], dtype=torch.int32, device="cuda")
+        pos = torch.tensor([130, 300], dtype=torch.int32, device="cuda")
+        res = {}
+        for form in ("two", "pair"):
+            x = x0.clone().cuda()
+            y = torch.zeros(B, D if epi == 2 else N, device="cuda")
+            pool = torch.zeros(2 * max_pages + 1, n_layer, 2, H, _lib.PAGE, hd, device="cuda")
+            n_pairs, i_pair = 7, 0
+            buf = lambda i: 1 if (i == n_pairs - 1 and n_pairs % 3 == 1) else i % 3
+            for rep in range(2):
+                for i in range(n_pairs):
+                    a = _lib.GemvArgs()
+                    a.W, a.bias, a.x, a.y = W2[i % 2].data_ptr(), b2.data_ptr(), h.data_ptr(), x.data_ptr()
+                    a.B, a.N, a.K, a.groups, a.x_stride, a.y_stride = B, D, F, 1, F, D
+                    a.pro, a.act, a.epi = 0, 0, 1
+                    b = _lib.GemvArgs()
+                    b.W, b.bias, b.x, b.y = Wn[i % 2].data_ptr(), bn.data_ptr(), x.data_ptr(), y.data_ptr()
+                    b.B, b.N, b.K, b.groups, b.x_stride, b.y_stride = B, N, D, 1, D, (D if epi == 2 else N)
+                    b.pro, b.act, b.epi, b.ln_eps = 1, act, epi, 1e-5
+                    if epi == 2:
+                        b.kv = _lib.KV(pool.data_ptr(), table.data_ptr(), max_pages, n_layer, H, hd)
+                        b.layer, b.kv_pos = i % 2, pos.data_ptr()
+                    assert L.ssrhip_gemv_pair_applicable(C.byref(a), C.byref(b)) == 1
+                    if form == "two":
+                        _lib.check(L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()))
+                        _lib.check(L.ssrhip_gemv(C.byref(b), _lib.stream_ptr()))
+                    else:
+                        rc = L.ssrhip_gemv_pair(C.byref(a), C.byref(b), ws.data_ptr(), buf(i), buf((i + 1) % n_pairs), _lib.stream_ptr())
+                        assert rc == 0, rc
+            torch.cuda.synchronize()
+            res[form] = (x.cpu().numpy(), y.cpu().numpy(), pool.cpu().numpy())
+        assert L.ssrhip_gemv_pair_status(ws.data_ptr(), _lib.stream_ptr()) == 0
+        for k, (got, want) in enumerate(zip(res["pair"], res["two"])):
+            assert np.isfinite(want).all()
+            assert np.array_equal(got, want), (name, k, float(np.abs(got - want).max()))
+        if epi == 2:
+            assert np.abs(res["two"][2]).sum() > 0
+    # shapes that do not qualify are refused, nothing is launched
+    a = _lib.GemvArgs(); b = _lib.GemvArgs()
+    assert L.ssrhip_gemv_pair_applicable(C.byref(a), C.byref(b)) == 0
+
+
+def _lib_pair_ws_bytes():
+    return 3 * 4096 * 8 + 64                                        # include/ssrhip.h SSRHIP_PAIR_WS_BYTES
+
+
 @pytest.mark.parametrize("max_pages", [8, 7, 5, 1])
 @pytest.mark.parametrize("B", [1, 2, 4])
 def test_gemv_seg_combine_and_qkv_append_at_2048(L, B, max_pages):

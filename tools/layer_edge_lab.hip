@@ -308,6 +308,128 @@ __global__ __launch_bounds__(512 + 64 * NE, 2) void fused_kernel(const Args a) {
     a.q[(size_t)b * NQ + rB0 + r] = (partB[(r * 2 + 0) * 2 + b] + partB[(r * 2 + 1) * 2 + b]) + a.bq[rB0 + r];
   }
 }
+// ---- C: mode 6 / 7 again with the two ROLES as the two arms of one branch, every barrier written in both arms. In the form above the
+// streaming waves' code is a series of `if (wave < 8)` blocks with joins between them; hipcc's wait-count pass merges the "block skipped"
+// path into every join, so the first use of a unit requested two blocks earlier is guarded by `s_waitcnt vmcnt(PF * 4 - 1)` instead of
+// vmcnt(15) — the QKV phase runs with 8 (4) loads in flight per wave instead of 16 (read off the ISA). One arm per role: straight-line
+// code for the streaming waves, exact counts.
+__device__ __forceinline__ void ln_stats(const float4 (&xr)[2][4], int wave, int lane, float* aux) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float s0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s0 += (xr[b][i].x + xr[b][i].y) + (xr[b][i].z + xr[b][i].w);
+    const float m = wave_sum(s0) * (1.0f / SEGF);
+    float q0 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dx = xr[b][i].x - m, dy = xr[b][i].y - m, dz = xr[b][i].z - m, dw = xr[b][i].w - m;
+      q0 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    const float q = wave_sum(q0);
+    if (wave < 2 && lane == 0) { aux[(wave * 2 + b) * 2] = m; aux[(wave * 2 + b) * 2 + 1] = q; }
+  }
+}
+__device__ __forceinline__ void ln_apply(float4 (&xr)[2][4], const float* aux) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float mean = (aux[(0 * 2 + b) * 2] + aux[(1 * 2 + b) * 2]) / 2.0f;
+    const float d0 = aux[(0 * 2 + b) * 2] - mean, d1 = aux[(1 * 2 + b) * 2] - mean;
+    const float M2 = aux[(0 * 2 + b) * 2 + 1] + aux[(1 * 2 + b) * 2 + 1];
+    const float dev = fmaf(d1, d1, fmaf(d0, d0, 0.f));
+    const float rstd = 1.0f / sqrtf((M2 + (float)SEGF * dev) / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      xr[b][i] = make_float4((xr[b][i].x - mean) * rstd, (xr[b][i].y - mean) * rstd, (xr[b][i].z - mean) * rstd, (xr[b][i].w - mean) * rstd);
+  }
+}
+template <int PF>
+__global__ __launch_bounds__(768, 2) void roles_kernel(const Args a) {
+  __shared__ float partA[RA * 8 * 2];
+  __shared__ float partB[RB * 2 * 2];
+  __shared__ float aux[8];
+  __shared__ __attribute__((aligned(16))) float xs[2 * D];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (wave < 8) {
+    float4 xr[2][4];
+    float4 w[DEPTH][4];
+    const int r0 = blockIdx.x * RA, segB = wave & 1, rB0 = blockIdx.x * RB;
+    const float* Wg = a.W2 + (size_t)r0 * F + wave * SEGF + lane * 4;
+    const float* WgB = a.Wq + (size_t)rB0 * D + segB * SEGF + lane * 4;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[b][i] = ld4(a.h + (size_t)b * F + wave * SEGF + (i * 64 + lane) * 4);
+    first_units<8, NUA, F>(Wg, wave, w);
+    run_units<8, NUA, F>(Wg, wave, lane, xr, w, partA);
+    __syncthreads();                                                      // (1)
+    __syncthreads();                                                      // (1b)
+    first_units<2, NUB, D, 0, PF>(WgB, wave, w);
+    __syncthreads();                                                      // (2)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[b][i] = *reinterpret_cast<const float4*>(xs + b * D + segB * SEGF + (i * 64 + lane) * 4);
+    if (PF < DEPTH) first_units<2, NUB, D, PF, DEPTH>(WgB, wave, w);
+    ln_stats(xr, wave, lane, aux);
+    __syncthreads();                                                      // (3)
+    ln_apply(xr, aux);
+    run_units<2, NUB, D>(WgB, wave, lane, xr, w, partB);
+    __syncthreads();                                                      // (4)
+    if (t < RB * 2) {
+      const int r = t >> 1, b = t & 1;
+      a.q[(size_t)b * NQ + rB0 + r] = (partB[(r * 2 + 0) * 2 + b] + partB[(r * 2 + 1) * 2 + b]) + a.bq[rB0 + r];
+    }
+  } else {
+    float e_resid = 0.f, e_bias = 0.f;
+    long long t_parked = 0, t_pub = 0;
+    if (wave == 8 && lane < RA * 2) {
+      a.gran_next[(size_t)blockIdx.x * (RA * 2) + lane] = 0ull;
+      e_resid = a.x[(size_t)(lane & 1) * D + blockIdx.x * RA + (lane >> 1)];
+      e_bias = a.b2[blockIdx.x * RA + (lane >> 1)];
+    }
+    __syncthreads();                                                      // (1)
+    if (wave == 8) {
+      if (a.prof && lane == 0) t_parked = wall_clock64();
+      if (lane < RA * 2) {
+        const int r = lane >> 1, b = lane & 1, n = blockIdx.x * RA + r;
+        float v = 0.f;
+        for (int s = 0; s < 8; ++s) v += partA[(r * 8 + s) * 2 + b];
+        const float out = e_resid + (v + e_bias);
+        a.x[(size_t)b * D + n] = out;
+        const unsigned long long gval = ((unsigned long long)1u << 32) | (unsigned long long)__float_as_uint(out);
+        __hip_atomic_store(a.gran + (size_t)n * 2 + b, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (a.prof && lane == 0) t_pub = wall_clock64();
+    }
+    __syncthreads();                                                      // (1b)
+    bool done = false;
+    int sweeps = 0;
+    v4f g[8];
+    for (int spin = 0; spin < 4000 && !done; ++spin) {
+      bool all = true;
+      sweep8(a.gran + (size_t)(wave - 8) * 1024 + lane * 2, g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        all = all && (__float_as_uint(g[i][1]) == 1u) && (__float_as_uint(g[i][3]) == 1u);
+        const int gi = (wave - 8) * 1024 + (i >> 2) * 512 + (i & 3) * 128 + lane * 2;
+        xs[(gi >> 1)] = g[i][0];
+        xs[D + (gi >> 1)] = g[i][2];
+      }
+      ++sweeps;
+      done = __all(all);
+      if (!done) __builtin_amdgcn_s_sleep(2);
+    }
+    if (!done && lane == 0) *a.giveup = 1;
+    __syncthreads();                                                      // (2)
+    if (a.prof && lane == 0 && wave == 8) {
+      long long* pr = a.prof + (size_t)blockIdx.x * 4;
+      pr[0] = t_parked; pr[1] = t_pub; pr[2] = wall_clock64(); pr[3] = sweeps;
+    }
+    __syncthreads();                                                      // (3)
+    __syncthreads();                                                      // (4)
+  }
+}
 typedef void (*fused_fn)(const Args);
 struct Mode { fused_fn fn; int ne; const char* what; };
 static const Mode MODES[] = {
@@ -319,6 +441,10 @@ static const Mode MODES[] = {
     {fused_kernel<1, 4, 4>, 4, "QKV's first 4 units requested behind the publish, four edge waves gather"},
     {fused_kernel<1, 4, 2>, 4, "QKV's first 2 units requested behind the publish (the other 2 behind the gather), four edge waves gather"},
     {fused_kernel<1, 4, 1>, 4, "QKV's first unit requested behind the publish (the other 3 behind the gather), four edge waves gather"},
+    {roles_kernel<4>, 4, "mode 5 with one branch arm per role (exact wait counts in the QKV phase)"},
+    {roles_kernel<2>, 4, "mode 6 with one branch arm per role"},
+    {roles_kernel<1>, 4, "mode 7 with one branch arm per role"},
+    {roles_kernel<3>, 4, "first 3 units behind the publish, one branch arm per role"},
 };
 
 static float time_graph(hipGraphExec_t ex, hipStream_t s, int launches) {
