@@ -36,13 +36,15 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
-# HBM bytes per GEMV launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950
-# corrections of MI355X_MICROARCH.md: FETCH_SIZE x2 for wide coalesced reads), launch-weighted over the 66 GEMV launches of a step.
+# HBM bytes moved by the GEMV launches of ONE step, from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+# command, gfx950 corrections of MI355X_MICROARCH.md: FETCH_SIZE x2 for wide coalesced reads). `traffic` in the JSON line is this figure
+# divided by the step's number of GEMV launches (the paired launches of the 2-row step move the bytes of the two launches they replace).
 # Not re-measured live (counters need rocprofv3): the constants are this round's profiles, named in `traffic_source`.
-#   2 rows : (65.93 x17 + 58.30 x33 + 17.83 x16) / 66 = 50.5 MB read + 0.05 MB written (round 3 passes; the three segment-kernel variants)
-#   16 rows: (59.30 x33 + 71.66 x16 + 18.17 x16 + 36.04) / 66 = 52.0 MB read + 0.3 MB written (x re-read through L2 by the streamed-x kernel)
-TRAFFIC_BYTES_PER_GEMV_LAUNCH = {2: 50.5e6, 16: 52.3e6}
-TRAFFIC_SOURCE = {2: "profiles/r04_pmc_fetch_size.md + profiles/r04_pmc_write_size.md (50.4 MB read + 0.05 MB written per GEMV launch)", 16: "profiles/r02_pmc_fetch_size_16rows.md + profiles/r02_pmc_write_size_16rows.md"}
+#   2 rows : round 5, see TRAFFIC_SOURCE
+#   16 rows: (59.30 x33 + 71.66 x16 + 18.17 x16 + 36.04) = 3,432 MB read + 20 MB written (x re-read through L2 by the streamed-x kernel; round 2)
+TRAFFIC_BYTES_PER_STEP_GEMVS = {2: 66 * 50.46e6, 16: 66 * 52.3e6}
+TRAFFIC_SOURCE = {2: "profiles/r05_pmc_fetch_size.md + profiles/r05_pmc_write_size.md (3,327 MB read + 3 MB written by the GEMV launches of a step)",
+                  16: "profiles/r02_pmc_fetch_size_16rows.md + profiles/r02_pmc_write_size_16rows.md"}
 
 
 def synth_inputs(args_lm, rank, L=130, N=160):
@@ -571,17 +573,34 @@ def main():
         achieved = bytes_per_launch / (gemv_us * 1e-6) / 1e9
         # per-shape view of one layer (slots 0..4 = QKV, attention, out-proj, FFN1, FFN2 of layer 0.., averaged over layers)
         nl = arena.L
-        ns_slots = (len(slots) - 3) // nl                 # launches per layer as the engine enqueued them
-        if 2 * U <= 4:
-            shape_names = ["ln1+qkv", "attn", "combine+out_proj", "ln2+ffn1", "ffn2"]
-        elif ns_slots == 5:                               # > 4 rows, fused walk over the pages (ssrhip_attn_rows): no combine launch
-            shape_names = ["ln1+qkv", "attn_rows", "out_proj", "ln2+ffn1", "ffn2"]
-        else:                                             # > 4 rows, split attention: the combine is its own launch
-            shape_names = ["ln1+qkv", "attn", "combine", "out_proj", "ln2+ffn1", "ffn2"]
-        assert ns_slots == len(shape_names), (ns_slots, shape_names)
-        ns = len(shape_names)
-        per_shape = {shape_names[j]: round(sum(slots[l * ns + j][1] for l in range(nl)) / nl, 3) for j in range(ns)}
-        per_shape.update({"lnf+head1": round(slots[nl * ns][1], 3), "head2": round(slots[nl * ns + 1][1], 3), "sample+embed": round(slots[nl * ns + 2][1], 3)})
+        paired = None
+        if 2 * U == 2 and len(slots) == 1 + 3 * nl + 2:   # 2 rows, both pair forms (csrc/gemv.hip): QKV of layer 0, then per layer attention,
+            paired = "both"                               # [merge + out-proj + LN2 + FFN1], [FFN2 + LN1 + QKV of the next layer | + head MLP]
+            avg = lambda j, ls: round(sum(slots[1 + 3 * l + j][1] for l in ls) / len(ls), 3)
+            per_shape = {"ln1+qkv (layer 0 only)": round(slots[0][1], 3), "attn": avg(0, range(nl)),
+                         "combine+out_proj | ln2+ffn1 (one launch)": avg(1, range(nl)),
+                         "ffn2 | ln1+qkv of the next layer (one launch)": avg(2, range(nl - 1)),
+                         "ffn2 | lnf+head1 (one launch)": round(slots[1 + 3 * (nl - 1) + 2][1], 3),
+                         "head2": round(slots[1 + 3 * nl][1], 3), "sample+embed": round(slots[1 + 3 * nl + 1][1], 3)}
+        elif 2 * U == 2 and len(slots) == 1 + 4 * nl + 2:  # SSRHIP_GEMV_PAIR=1: only FFN2 is paired
+            paired = "ffn2"
+            avg = lambda j, ls: round(sum(slots[1 + 4 * l + j][1] for l in ls) / len(ls), 3)
+            per_shape = {"ln1+qkv (layer 0 only)": round(slots[0][1], 3), "attn": avg(0, range(nl)), "combine+out_proj": avg(1, range(nl)),
+                         "ln2+ffn1": avg(2, range(nl)), "ffn2 | ln1+qkv of the next layer (one launch)": avg(3, range(nl - 1)),
+                         "ffn2 | lnf+head1 (one launch)": round(slots[1 + 4 * (nl - 1) + 3][1], 3),
+                         "head2": round(slots[1 + 4 * nl][1], 3), "sample+embed": round(slots[1 + 4 * nl + 1][1], 3)}
+        else:
+            ns_slots = (len(slots) - 3) // nl                 # launches per layer as the engine enqueued them
+            if 2 * U <= 4:
+                shape_names = ["ln1+qkv", "attn", "combine+out_proj", "ln2+ffn1", "ffn2"]
+            elif ns_slots == 5:                               # > 4 rows, fused walk over the pages (ssrhip_attn_rows): no combine launch
+                shape_names = ["ln1+qkv", "attn_rows", "out_proj", "ln2+ffn1", "ffn2"]
+            else:                                             # > 4 rows, split attention: the combine is its own launch
+                shape_names = ["ln1+qkv", "attn", "combine", "out_proj", "ln2+ffn1", "ffn2"]
+            assert ns_slots == len(shape_names), (ns_slots, shape_names)
+            ns = len(shape_names)
+            per_shape = {shape_names[j]: round(sum(slots[l * ns + j][1] for l in range(nl)) / nl, 3) for j in range(ns)}
+            per_shape.update({"lnf+head1": round(slots[nl * ns][1], 3), "head2": round(slots[nl * ns + 1][1], 3), "sample+embed": round(slots[nl * ns + 2][1], 3)})
         S_mid = L + T0 + a.warmup + a.steps // 2
         kv_bytes = 262144 * 2 * U * S_mid * (arena.L / 16) * (arena.D / 2048)
         step_gbs = (arena.nbytes_per_step() + kv_bytes) / (ms_per_step * 1e-3) / 1e9
@@ -600,9 +619,12 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r04_pmc_*.md), gfx950 x2 correction
                          # for wide reads applied: 50.5 MB read + 0.1 MB written per GEMV launch vs 49.85 MB algorithmic
-                         "traffic": TRAFFIC_BYTES_PER_GEMV_LAUNCH.get(2 * U) if (arena.D == 2048 and arena.L == 16) else None,
+                         "traffic": (round(TRAFFIC_BYTES_PER_STEP_GEMVS[2 * U] / n_gemv) if (2 * U in TRAFFIC_BYTES_PER_STEP_GEMVS and arena.D == 2048 and arena.L == 16) else None),
                          "traffic_source": TRAFFIC_SOURCE.get(2 * U, "not measured for this row count") + " (rocprofv3 --pmc passes of this command, gfx950 x2 FETCH_SIZE correction)",
-                         "kernel": (f"gemv_segu_kernel<2,*> / gemv_seg_kernel<2,*> (fused LN or split-KV merge + GEMV + bias/act/residual), all {n_gemv} GEMV launches of a step"
+                         "kernel": ((f"gemv_pair_merge_kernel (split-KV merge + out-proj + residual | LN + FFN1 + ReLU) and gemv_pair_kernel (FFN2 + residual | LN + QKV + KV append) "
+                                     f"— two GEMVs per launch, the all-to-all edge inside — plus gemv_segu_kernel (QKV of layer 0, head MLP): all {n_gemv} GEMV launches of a step")
+                                    if paired == "both" else
+                                    f"gemv_segu_kernel<2,*> / gemv_seg_kernel<2,*> / gemv_pair_kernel (fused LN or split-KV merge + GEMV + bias/act/residual), all {n_gemv} GEMV launches of a step"
                                     if 2 * U <= 4 else
                                     f"gemv_rows_xreg_kernel / gemv_rows_stream_kernel (matrix-core GEMV, streaming-order weights), all {n_gemv} launches of a step"),
                          "bytes_per_launch": int(bytes_per_launch), "launches_per_step": n_gemv, "us_per_launch": round(gemv_us, 3),

@@ -133,6 +133,29 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     if (wt) { g.W = w.head1_wt; g.w_tiled = 1; }
     return g;
   };
+  auto outproj_args = [&](int l) {               // the <= 4-row form: split-KV merge prologue + out-proj + residual
+    ssrhip_gemv_args g;
+    memset(&g, 0, sizeof(g));
+    g.W = w.out_proj_w[l]; g.bias = w.out_proj_b[l]; g.x = nullptr; g.y = b.x;
+    g.B = B; g.N = D; g.K = D; g.groups = 1; g.x_stride = D; g.y_stride = D;
+    g.pro = SSRHIP_PRO_ATTN_COMBINE; g.act = SSRHIP_ACT_NONE; g.epi = SSRHIP_EPI_RESIDUAL;
+    g.part_o = b.part_o; g.part_ml = b.part_ml; g.max_splits = b.max_splits; g.row_len = b.row_len;
+    g.kv = b.kv;
+    return g;
+  };
+  auto ffn1_args = [&](int l) {
+    ssrhip_gemv_args g;
+    // LN2 + FFN1 + ReLU
+    memset(&g, 0, sizeof(g));
+    g.W = w.ffn1_w[l]; g.bias = w.ffn1_b[l]; g.x = b.x; g.y = b.h;
+    g.B = B; g.N = d.d_ffn; g.K = D; g.groups = 1; g.x_stride = D; g.y_stride = d.d_ffn;
+    g.pro = SSRHIP_PRO_LAYERNORM; g.act = SSRHIP_ACT_RELU; g.epi = SSRHIP_EPI_STORE;
+    if (!d.ln_folded) { g.ln_w = w.ln2_w[l]; g.ln_b = w.ln2_b[l]; }
+    g.ln_eps = 1e-5f;
+    g.x_tiled = tiled; g.y_tiled = tiled;
+    if (wt) { g.W = w.ffn1_wt[l]; g.w_tiled = 1; }
+    return g;
+  };
   auto ffn2_args = [&](int l) {
     ssrhip_gemv_args g;
     memset(&g, 0, sizeof(g));
@@ -144,17 +167,19 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     return g;
   };
   // 2-row step: FFN2 of layer l and the launch that consumes its output (QKV of layer l + 1; the head MLP after the last layer) run as ONE
-  // launch with the all-to-all edge inside it (csrc/gemv.hip gemv_pair_kernel). The pairs of a step use the three granule buffers of
+  // launch with the all-to-all edge inside it (csrc/gemv.hip gemv_pair_kernel), and so do the out-projection (with its split-KV merge
+  // prologue) and FFN1 (gemv_pair_merge_kernel): attention, pair, pair per layer. The pairs of a step use the three granule buffers of
   // lm->pair_ws cyclically: pair i uses buffer i % 3 and resets the buffer of pair (i + 1) % n — closed over the step, so that graph
   // replays (and eager steps) always find their buffer reset by the launch before them; with n % 3 == 1 the last pair takes buffer 1.
   int n_pairs = 0;
-  bool pair_qkv = false, pair_head = false;
+  bool pair_qkv = false, pair_head = false, pair_ffn1 = false;
   if (lm->pair_ws && B == 2) {
     const ssrhip_gemv_args fa = ffn2_args(0);
     if (d.n_layer > 1) { const ssrhip_gemv_args qa = qkv_args(1); pair_qkv = ssrhip_gemv_pair_applicable(&fa, &qa) != 0; }
     { const ssrhip_gemv_args ha = head1_args(); pair_head = ssrhip_gemv_pair_applicable(&fa, &ha) != 0; }
-    n_pairs = (pair_qkv ? d.n_layer - 1 : 0) + (pair_head ? 1 : 0);
-    if (n_pairs < 2) { n_pairs = 0; pair_qkv = pair_head = false; }
+    { const ssrhip_gemv_args oa = outproj_args(0), f1 = ffn1_args(0); pair_ffn1 = ssrhip_gemv_pair_applicable(&oa, &f1) != 0; }
+    n_pairs = (pair_qkv ? d.n_layer - 1 : 0) + (pair_head ? 1 : 0) + (pair_ffn1 ? d.n_layer : 0);
+    if (n_pairs < 2) { n_pairs = 0; pair_qkv = pair_head = pair_ffn1 = false; }
   }
   auto pair_buf = [&](int i) { return (i == n_pairs - 1 && n_pairs % 3 == 1) ? 1 : i % 3; };
   int pair_i = 0;
@@ -203,18 +228,16 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
       g.pro = SSRHIP_PRO_NONE; g.x_tiled = 1; g.y_tiled = 1;
       if (wt) { g.W = w.out_proj_wt[l]; g.w_tiled = 1; }
     }
-    STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
-
-    // LN2 + FFN1 + ReLU
-    memset(&g, 0, sizeof(g));
-    g.W = w.ffn1_w[l]; g.bias = w.ffn1_b[l]; g.x = b.x; g.y = b.h;
-    g.B = B; g.N = d.d_ffn; g.K = D; g.groups = 1; g.x_stride = D; g.y_stride = d.d_ffn;
-    g.pro = SSRHIP_PRO_LAYERNORM; g.act = SSRHIP_ACT_RELU; g.epi = SSRHIP_EPI_STORE;
-    if (!d.ln_folded) { g.ln_w = w.ln2_w[l]; g.ln_b = w.ln2_b[l]; }
-    g.ln_eps = 1e-5f;
-    g.x_tiled = tiled; g.y_tiled = tiled;
-    if (wt) { g.W = w.ffn1_wt[l]; g.w_tiled = 1; }
-    STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+    if (pair_ffn1) {                              // out-projection + FFN1 as one launch (2 rows)
+      const ssrhip_gemv_args f1 = ffn1_args(l);
+      const int bufi = pair_buf(pair_i), bufn = pair_buf((pair_i + 1) % n_pairs);
+      STEP_CALL(CAT_GEMV, ssrhip_gemv_pair(&g, &f1, lm->pair_ws, bufi, bufn, (ssrhip_stream_t)s));
+      pair_i += 1;
+    } else {
+      STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+      g = ffn1_args(l);
+      STEP_CALL(CAT_GEMV, ssrhip_gemv(&g, s));
+    }
 
     // FFN2 + residual — paired with the next launch where that applies
     g = ffn2_args(l);

@@ -918,34 +918,181 @@ __device__ __forceinline__ void pair_sweep8(const unsigned long long* p, pair_v4
       : "memory");
 }
 
+// ---- the streaming role from barrier (1) on: B = LayerNorm + Linear on x' (gemv_segu_kernel<2, PRO_LAYERNORM, NUWB, 4>, operation for operation)
+template <int NUWB>
+__device__ __forceinline__ void pair_stream_b(const PairK& p, int t, int lane, int wave, float4 (&xr)[2][4], float4 (&w)[PAIR_DEPTH][4],
+                                              const RowEpi& efinB, float* partB, float* aux, const float* xs, const size_t* kvoff) {
+  constexpr int B = 2, DEPTH = PAIR_DEPTH, PF = PAIR_PF, SB = 2, SHB = 1, RB = NUWB * SEG_NW / SB;
+  const ssrhip_gemv_args& bb = p.b.a;
+  const int rB0 = (int)blockIdx.x * RB, segB = wave & (SB - 1);
+  const int bfin = t % B, rfinB = min(t / B, RB - 1), nfinB = rB0 + rfinB;
+  const float* WgB = bb.W + (size_t)rB0 * bb.K + segB * SEG + lane * 4;
+  __syncthreads();                                                  // (1b) wave 8 has issued the publish
+  // B's first units: PF of them now, the rest behind the gather
+#pragma unroll
+  for (int j = 0; j < PF; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(WgB + (size_t)((wave + SEG_NW * j) >> SHB) * bb.K + i * 256);
+  __syncthreads();                                                  // (2) x' is in LDS
+#pragma unroll
+  for (int b = 0; b < B; ++b)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xr[b][i] = *reinterpret_cast<const float4*>(xs + b * PAIR_D + segB * SEG + (i * 64 + lane) * 4);
+#pragma unroll
+  for (int j = PF; j < DEPTH; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(WgB + (size_t)((wave + SEG_NW * j) >> SHB) * bb.K + i * 256);
+  // LayerNorm
+  {
+    float m[B], q[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      float s0 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s0 += (xr[b][i].x + xr[b][i].y) + (xr[b][i].z + xr[b][i].w);
+      m[b] = wave_sum(s0) * (1.0f / SEG);
+      float q0 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dx = xr[b][i].x - m[b], dy = xr[b][i].y - m[b], dz = xr[b][i].z - m[b], dw = xr[b][i].w - m[b];
+        q0 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+      q[b] = wave_sum(q0);
+      if (wave < SB && lane == 0) { aux[(wave * B + b) * 2] = m[b]; aux[(wave * B + b) * 2 + 1] = q[b]; }
+    }
+    __syncthreads();                                                // (3)
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      float mean = 0.f, M2 = 0.f, dev = 0.f;
+      for (int s2 = 0; s2 < SB; ++s2) mean += aux[(s2 * B + b) * 2];
+      mean /= (float)SB;
+      for (int s2 = 0; s2 < SB; ++s2) { const float dm = aux[(s2 * B + b) * 2] - mean; M2 += aux[(s2 * B + b) * 2 + 1]; dev = fmaf(dm, dm, dev); }
+      const float var = (M2 + (float)SEG * dev) / (float)bb.K;
+      const float rstd = 1.0f / sqrtf(var + bb.ln_eps);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        xr[b][i] = make_float4((xr[b][i].x - mean) * rstd, (xr[b][i].y - mean) * rstd, (xr[b][i].z - mean) * rstd, (xr[b][i].w - mean) * rstd);
+    }
+  }
+  // units
+#pragma unroll
+  for (int j = 0; j < NUWB; ++j) {
+    float4 (&wj)[4] = w[j % DEPTH];
+    float acc[B][2];
+#pragma unroll
+    for (int b = 0; b < B; ++b) acc[b][0] = acc[b][1] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) acc[b][i & 1] = dot4(wj[i], xr[b][i], acc[b][i & 1]);
+      if (j + DEPTH < NUWB) {
+        __builtin_amdgcn_sched_barrier(0);
+        wj[i] = ld_nt(WgB + (size_t)((wave + SEG_NW * (j + DEPTH)) >> SHB) * bb.K + i * 256);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const float sum = wave_sum(acc[b][0] + acc[b][1]);
+      if (lane == b) mine = sum;
+    }
+    if (lane < B) partB[(wave + SEG_NW * j) * B + lane] = mine;
+  }
+  __syncthreads();                                                  // (4)
+  if (t < RB * B) {
+    float v = 0.f;
+    for (int s2 = 0; s2 < SB; ++s2) v += partB[(rfinB * SB + s2) * B + bfin];
+    // K / V append addresses: resolved by the edge role (wave 9) while this role streamed — the kv_pos -> page table -> pool chain costs
+    // the streaming waves nothing here (in gemv_segu_kernel it is two scalar round trips per wave under the first units' latency)
+    float* kvb[2] = {bb.kv.pool + kvoff[bfin * 2], bb.kv.pool + kvoff[bfin * 2 + 1]};
+    finalize(p.b, 0, nfinB, bfin, v, efinB, kvb);
+  }
+}
+
+// ---- the edge role (waves 8-11). SA = segments per row of A (partial sums to add), NPRE = barriers of A's prologue to keep company
+template <int SA, int NPRE>
+__device__ __forceinline__ void pair_edge_role(const PairK& p, int e, int lane, const float* partA, float* xs, size_t* kvoff) {
+  constexpr int B = 2, RA = 8;
+  const ssrhip_gemv_args& a = p.a.a;
+  const ssrhip_gemv_args& bb = p.b.a;
+  const int rA0 = (int)blockIdx.x * RA;
+  RowEpi efinA = {0.f, 0.f};
+  if (e == 0 && lane < RA * B) {
+    efinA.bias = a.bias ? a.bias[rA0 + (lane >> 1)] : 0.f;
+    efinA.resid = a.y[(size_t)(lane & 1) * a.y_stride + rA0 + (lane >> 1)];
+    p.gran_next[(size_t)blockIdx.x * (RA * B) + lane] = 0ull;       // reset the NEXT pair launch's granules (this workgroup's 16 of them)
+  }
+  if (bb.epi == SSRHIP_EPI_QKV_APPEND && e == 1 && lane < B) {      // kv_append_bases()'s arithmetic for batch row `lane`, as element offsets
+    const int pos = bb.kv_pos[lane];
+    const int page = bb.kv.table[(size_t)lane * bb.kv.max_pages + (pos / SSRHIP_PAGE)];
+    const size_t k0 = ((((size_t)page * bb.kv.n_layer + bb.layer) * 2 + 0) * bb.kv.n_head) * SSRHIP_PAGE + (pos % SSRHIP_PAGE);
+    const size_t v0 = ((((size_t)page * bb.kv.n_layer + bb.layer) * 2 + 1) * bb.kv.n_head) * SSRHIP_PAGE + (pos % SSRHIP_PAGE);
+    kvoff[lane * 2 + 0] = k0 * bb.kv.head_dim;
+    kvoff[lane * 2 + 1] = v0 * bb.kv.head_dim;
+  }
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) __syncthreads();
+  __syncthreads();                                                  // (1)
+  if (e == 0 && lane < RA * B) {
+    // A's epilogue — finalize()'s RESIDUAL arm — into the residual stream and, tagged, into this launch's granules
+    const int r = lane >> 1, b = lane & 1, n = rA0 + r;
+    float v = 0.f;
+    for (int s2 = 0; s2 < SA; ++s2) v += partA[(r * SA + s2) * B + b];
+    v += efinA.bias;
+    const float out = efinA.resid + v;
+    a.y[(size_t)b * a.y_stride + n] = out;
+    const unsigned long long gval = ((unsigned long long)1u << 32) | (unsigned long long)__float_as_uint(out);
+    __hip_atomic_store(p.gran + (size_t)n * 2 + b, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();                                                  // (1b)
+  // gather this wave's quarter of the granules: one round trip per sweep, until every tag is this launch's
+  pair_v4f g[8];
+  bool done = false;
+  for (int spin = 0; spin < PAIR_SPINS && !done; ++spin) {
+    bool all = true;
+    pair_sweep8(p.gran + (size_t)e * 1024 + lane * 2, g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      all = all && (__float_as_uint(g[i][1]) == 1u) && (__float_as_uint(g[i][3]) == 1u);
+      const int gi = e * 1024 + (i >> 2) * 512 + (i & 3) * 128 + lane * 2;   // granule index of g[i].xy (row 0 of output gi / 2); .zw: row 1
+      xs[(gi >> 1)] = g[i][0];
+      xs[PAIR_D + (gi >> 1)] = g[i][2];
+    }
+    done = __all(all);
+    if (!done) __builtin_amdgcn_s_sleep(2);
+  }
+  if (!done && lane == 0) *p.gave_up = 1;
+  __syncthreads();                                                  // (2)
+  __syncthreads();                                                  // (3)
+  __syncthreads();                                                  // (4)
+}
+
 // The two ROLES are the two arms of ONE (wave-uniform) branch and every barrier is written in both arms. A first form — a series of
 // `if (wave < 8)` blocks with joins in between — made hipcc's wait-count pass merge the "block skipped" path into every join: the first use
 // of a unit requested two blocks earlier was guarded by `s_waitcnt vmcnt(4 * PF - 1)` instead of vmcnt(15) (B's phase ran with 8 loads in
 // flight per wave instead of 16), the registers of wave 8's epilogue operands were zeroed on the streaming path behind a vmcnt(0), and the
 // kernel took 150 VGPRs instead of 112 (read off the ISA; tools/layer_edge_lab.hip modes 6 / 7 against 9 / 10).
+// A = FFN2 + residual (K = 8192): gemv_segu_kernel<2, PRO_NONE, 8, 4>
 template <int NUWB>
 __global__ __launch_bounds__(PAIR_TH, 2) void gemv_pair_kernel(const PairK p) {
-  constexpr int B = 2, DEPTH = PAIR_DEPTH, NUWA = PAIR_NUWA, PF = PAIR_PF;
+  constexpr int B = 2, DEPTH = PAIR_DEPTH, NUWA = PAIR_NUWA;
   constexpr int RA = 8, SA = 8, SHA = 3;                           // A: 8 rows per workgroup, K = 8192 = 8 segments, wave w owns segment w
-  constexpr int SB = 2, SHB = 1, RB = NUWB * SEG_NW / SB;          // B: K = 2048 = 2 segments, NUWB units per wave
+  constexpr int RB = NUWB * SEG_NW / 2;
   __shared__ float partA[RA * SA * B];
-  __shared__ float partB[RB * SB * B];
-  __shared__ float aux[SB * B * 2];
+  __shared__ float partB[RB * 2 * B];
+  __shared__ float aux[2 * B * 2];
   __shared__ __attribute__((aligned(16))) float xs[B * PAIR_D];
   __shared__ size_t kvoff[B * 2];
   const ssrhip_gemv_args& a = p.a.a;
   const ssrhip_gemv_args& bb = p.b.a;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int rA0 = (int)blockIdx.x * RA, rB0 = (int)blockIdx.x * RB;
   if (wave < SEG_NW) {
-    // ================= streaming role: gemv_segu_kernel<2, PRO_NONE, 8, 4> for A, then <2, PRO_LAYERNORM, NUWB, 4> for B, operation for operation
-    const int segB = wave & (SB - 1);
+    const int rA0 = (int)blockIdx.x * RA;
     const float* WgA = a.W + (size_t)rA0 * a.K + wave * SEG + lane * 4;
-    const float* WgB = bb.W + (size_t)rB0 * bb.K + segB * SEG + lane * 4;
     // ---- 0. B's epilogue operand of the (row, b) this thread finalises (wave 0's threads do): the wave's oldest load
     RowEpi efinB = {0.f, 0.f};
-    const int bfin = t % B, rfinB = min(t / B, RB - 1), nfinB = rB0 + rfinB;
-    efinB.bias = bb.bias ? bb.bias[nfinB] : 0.f;
+    efinB.bias = bb.bias ? bb.bias[(int)blockIdx.x * RB + min(t / B, RB - 1)] : 0.f;
     // ---- 1. the wave's slice of A's input (L2), then its first DEPTH units (HBM, non-temporal)
     float4 xr[B][4];
 #pragma unroll
@@ -983,137 +1130,140 @@ __global__ __launch_bounds__(PAIR_TH, 2) void gemv_pair_kernel(const PairK p) {
       if (lane < B) partA[(wave + SEG_NW * j) * B + lane] = mine;
     }
     __syncthreads();                                                // (1) A's partial sums are parked
-    __syncthreads();                                                // (1b) wave 8 has issued the publish
-    // ---- 3. B's first units: PF of them now, the rest behind the gather
+    pair_stream_b<NUWB>(p, t, lane, wave, xr, w, efinB, partB, aux, xs, kvoff);
+  } else {
+    pair_edge_role<SA, 0>(p, wave - SEG_NW, lane, partA, xs, kvoff);
+  }
+}
+
+// A = split-KV merge + out-projection + residual (K = 2048): gemv_seg_kernel<2, PRO_ATTN_COMBINE, TWO = true> at one workgroup per CU,
+// operation for operation — thread t owns float4 column t * 4 of both rows in the merge, wave w the units w and w + 8 (both requested at
+// entry). The merged rows pass through the LDS buffer that later receives x' (its A-phase use ends before barrier (1)).
+template <int NUWB>
+__global__ __launch_bounds__(PAIR_TH, 2) void gemv_pair_merge_kernel(const PairK p) {
+  constexpr int B = 2, DEPTH = PAIR_DEPTH, SEG_CS = SegCS<B>::v;
+  constexpr int RA = 8, SA = 2, SHA = 1;                           // A: 8 rows per workgroup, K = 2048 = 2 segments, 16 units = 2 per wave
+  constexpr int RB = NUWB * SEG_NW / 2;
+  extern __shared__ __attribute__((aligned(16))) float wtab[];     // [B * H][max_splits] merge weights
+  __shared__ float partA[RA * SA * B];
+  __shared__ float partB[RB * 2 * B];
+  __shared__ float aux[2 * B * 2];
+  __shared__ __attribute__((aligned(16))) float xs[B * PAIR_D];
+  __shared__ size_t kvoff[B * 2];
+  const ssrhip_gemv_args& a = p.a.a;
+  const ssrhip_gemv_args& bb = p.b.a;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (wave >= SEG_NW) {
+    pair_edge_role<SA, 2>(p, wave - SEG_NW, lane, partA, xs, kvoff);
+  } else {
+    const int K = a.K, rA0 = (int)blockIdx.x * RA, seg = wave & (SA - 1);
+    const float* WgA = a.W + (size_t)rA0 * K + seg * SEG + lane * 4;
+    RowEpi efinB = {0.f, 0.f};
+    efinB.bias = bb.bias ? bb.bias[(int)blockIdx.x * RB + min(t / B, RB - 1)] : 0.f;
+    // ---- 1. the attention partials this thread merges (L2): (m, l) of its (row, head), the first SEG_CS pages of its column
+    const int hd = p.a.hd, H = K / hd, MS = a.max_splits;
+    float4 co[B][SEG_CS];
+    float2 cml[SEG_CS];
+    int ns[B];
 #pragma unroll
-    for (int j = 0; j < PF; ++j)
+    for (int b = 0; b < B; ++b) ns[b] = (a.row_len[b] + SSRHIP_PAGE - 1) / SSRHIP_PAGE;
+    {
+      const int tt = t % (B * H);
+      const float* ml = a.part_ml + (size_t)tt * MS * 2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(WgB + (size_t)((wave + SEG_NW * j) >> SHB) * bb.K + i * 256);
-    __syncthreads();                                                // (2) x' is in LDS
+      for (int i = 0; i < SEG_CS; ++i) cml[i] = *reinterpret_cast<const float2*>(ml + 2 * min(i, MS - 1));
+      const int e = t * 4, h = e / hd, d = e % hd;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const float* po = a.part_o + (((size_t)b * H + h) * MS) * hd + d;
+#pragma unroll
+        for (int s2 = 0; s2 < SEG_CS; ++s2) co[b][s2] = ld4(po + (size_t)min(s2, MS - 1) * hd);
+      }
+    }
+    // ---- 2. the wave's two units of A, both now
+    float4 w[DEPTH][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(WgA + (size_t)((wave + SEG_NW * j) >> SHA) * K + i * 256);
+    // ---- 3. merge, under the latency of the units. EVERY thread computes the softmax-merge weights of (row, head) = t % (B * H), threads
+    // 0 .. B * H - 1 store them: inside an `if (t < B * H)` hipcc sinks the (m, l) loads into the branch, behind the weight requests, and
+    // their first use drains the whole queue (read off the ISA; in gemv_seg_kernel the same source keeps them in front)
+    {
+      const int tt = t % (B * H);
+      const bool keep = t < B * H;
+      const int n = ns[tt / H];
+      const float* ml = a.part_ml + (size_t)tt * MS * 2;
+      float M = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < SEG_CS; ++i)
+        if (i < n) M = fmaxf(M, cml[i].x);
+      for (int s2 = SEG_CS; s2 < n; ++s2) M = fmaxf(M, ld2_late(ml + 2 * s2).x);
+      float den = 0.f;
+#pragma unroll
+      for (int i = 0; i < SEG_CS; ++i)
+        if (i < n) den = fmaf(expf(cml[i].x - M), cml[i].y, den);
+      for (int s2 = SEG_CS; s2 < n; ++s2) { const float2 v = ld2_late(ml + 2 * s2); den = fmaf(expf(v.x - M), v.y, den); }
+      const float inv = 1.0f / den;
+#pragma unroll
+      for (int i = 0; i < SEG_CS; ++i)
+        if (keep && i < n) wtab[tt * MS + i] = expf(cml[i].x - M) * inv;
+      for (int s2 = SEG_CS; s2 < n; ++s2) { const float wv = expf(ld2_late(ml + 2 * s2).x - M) * inv; if (keep) wtab[tt * MS + s2] = wv; }
+    }
+    __syncthreads();                                                // (A1)
+    {
+      const int e = t * 4, h = e / hd, d = e % hd;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const float* wt = wtab + (b * H + h) * MS;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s2 = 0; s2 < SEG_CS; ++s2) {
+          const bool in = s2 < ns[b];
+          const float ws = in ? wt[s2] : 0.f;
+          acc.x = fmaf(ws, in ? co[b][s2].x : 0.f, acc.x);
+          acc.y = fmaf(ws, in ? co[b][s2].y : 0.f, acc.y);
+          acc.z = fmaf(ws, in ? co[b][s2].z : 0.f, acc.z);
+          acc.w = fmaf(ws, in ? co[b][s2].w : 0.f, acc.w);
+        }
+        const float* po = a.part_o + (((size_t)b * H + h) * MS) * hd + d;
+        for (int s2 = SEG_CS; s2 < ns[b]; ++s2) {
+          const float ws = wt[s2];
+          const float4 o = ld4_late(po + (size_t)s2 * hd);
+          acc.x = fmaf(ws, o.x, acc.x);
+          acc.y = fmaf(ws, o.y, acc.y);
+          acc.z = fmaf(ws, o.z, acc.z);
+          acc.w = fmaf(ws, o.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(xs + b * K + e) = acc;
+      }
+    }
+    __syncthreads();                                                // (A2)
+    float4 xr[B][4];
 #pragma unroll
     for (int b = 0; b < B; ++b)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xr[b][i] = *reinterpret_cast<const float4*>(xs + b * PAIR_D + segB * SEG + (i * 64 + lane) * 4);
+      for (int i = 0; i < 4; ++i) xr[b][i] = *reinterpret_cast<const float4*>(xs + b * K + seg * SEG + (i * 64 + lane) * 4);
+    // ---- 4. A's two units
 #pragma unroll
-    for (int j = PF; j < DEPTH; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(WgB + (size_t)((wave + SEG_NW * j) >> SHB) * bb.K + i * 256);
-    // ---- 4. B's LayerNorm
-    {
-      float m[B], q[B];
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-        float s0 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s0 += (xr[b][i].x + xr[b][i].y) + (xr[b][i].z + xr[b][i].w);
-        m[b] = wave_sum(s0) * (1.0f / SEG);
-        float q0 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float dx = xr[b][i].x - m[b], dy = xr[b][i].y - m[b], dz = xr[b][i].z - m[b], dw = xr[b][i].w - m[b];
-          q0 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-        }
-        q[b] = wave_sum(q0);
-        if (wave < SB && lane == 0) { aux[(wave * B + b) * 2] = m[b]; aux[(wave * B + b) * 2 + 1] = q[b]; }
-      }
-      __syncthreads();                                              // (3)
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-        float mean = 0.f, M2 = 0.f, dev = 0.f;
-        for (int s2 = 0; s2 < SB; ++s2) mean += aux[(s2 * B + b) * 2];
-        mean /= (float)SB;
-        for (int s2 = 0; s2 < SB; ++s2) { const float dm = aux[(s2 * B + b) * 2] - mean; M2 += aux[(s2 * B + b) * 2 + 1]; dev = fmaf(dm, dm, dev); }
-        const float var = (M2 + (float)SEG * dev) / (float)bb.K;
-        const float rstd = 1.0f / sqrtf(var + bb.ln_eps);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          xr[b][i] = make_float4((xr[b][i].x - mean) * rstd, (xr[b][i].y - mean) * rstd, (xr[b][i].z - mean) * rstd, (xr[b][i].w - mean) * rstd);
-      }
-    }
-    // ---- 5. B's units
-#pragma unroll
-    for (int j = 0; j < NUWB; ++j) {
-      float4 (&wj)[4] = w[j % DEPTH];
+    for (int j = 0; j < 2; ++j) {
       float acc[B][2];
 #pragma unroll
       for (int b = 0; b < B; ++b) acc[b][0] = acc[b][1] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int b = 0; b < B; ++b) acc[b][i & 1] = dot4(wj[i], xr[b][i], acc[b][i & 1]);
-        if (j + DEPTH < NUWB) {
-          __builtin_amdgcn_sched_barrier(0);
-          wj[i] = ld_nt(WgB + (size_t)((wave + SEG_NW * (j + DEPTH)) >> SHB) * bb.K + i * 256);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+        for (int b = 0; b < B; ++b) acc[b][i & 1] = dot4(w[j][i], xr[b][i], acc[b][i & 1]);
       float mine = 0.f;
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         const float sum = wave_sum(acc[b][0] + acc[b][1]);
         if (lane == b) mine = sum;
       }
-      if (lane < B) partB[(wave + SEG_NW * j) * B + lane] = mine;
+      if (lane < B) partA[(wave + SEG_NW * j) * B + lane] = mine;
     }
-    __syncthreads();                                                // (4)
-    if (t < RB * B) {
-      float v = 0.f;
-      for (int s2 = 0; s2 < SB; ++s2) v += partB[(rfinB * SB + s2) * B + bfin];
-      // K / V append addresses: resolved by the edge role (wave 9) while this role streamed — the kv_pos -> page table -> pool chain costs
-      // the streaming waves nothing here (in gemv_segu_kernel it is two scalar round trips per wave under the first units' latency)
-      float* kvb[2] = {bb.kv.pool + kvoff[bfin * 2], bb.kv.pool + kvoff[bfin * 2 + 1]};
-      finalize(p.b, 0, nfinB, bfin, v, efinB, kvb);
-    }
-  } else {
-    // ================= edge role (waves 8-11)
-    const int e = wave - SEG_NW;
-    RowEpi efinA = {0.f, 0.f};
-    if (e == 0 && lane < RA * B) {
-      efinA.bias = a.bias ? a.bias[rA0 + (lane >> 1)] : 0.f;
-      efinA.resid = a.y[(size_t)(lane & 1) * a.y_stride + rA0 + (lane >> 1)];
-      p.gran_next[(size_t)blockIdx.x * (RA * B) + lane] = 0ull;     // reset the NEXT pair launch's granules (this workgroup's 16 of them)
-    }
-    if (bb.epi == SSRHIP_EPI_QKV_APPEND && e == 1 && lane < B) {    // kv_append_bases()'s arithmetic for batch row `lane`, as element offsets
-      const int pos = bb.kv_pos[lane];
-      const int page = bb.kv.table[(size_t)lane * bb.kv.max_pages + (pos / SSRHIP_PAGE)];
-      const size_t k0 = ((((size_t)page * bb.kv.n_layer + bb.layer) * 2 + 0) * bb.kv.n_head) * SSRHIP_PAGE + (pos % SSRHIP_PAGE);
-      const size_t v0 = ((((size_t)page * bb.kv.n_layer + bb.layer) * 2 + 1) * bb.kv.n_head) * SSRHIP_PAGE + (pos % SSRHIP_PAGE);
-      kvoff[lane * 2 + 0] = k0 * bb.kv.head_dim;
-      kvoff[lane * 2 + 1] = v0 * bb.kv.head_dim;
-    }
-    __syncthreads();                                                // (1)
-    if (e == 0 && lane < RA * B) {
-      // A's epilogue — finalize()'s RESIDUAL arm — into the residual stream and, tagged, into this launch's granules
-      const int r = lane >> 1, b = lane & 1, n = rA0 + r;
-      float v = 0.f;
-      for (int s2 = 0; s2 < SA; ++s2) v += partA[(r * SA + s2) * B + b];
-      v += efinA.bias;
-      const float out = efinA.resid + v;
-      a.y[(size_t)b * a.y_stride + n] = out;
-      const unsigned long long gval = ((unsigned long long)1u << 32) | (unsigned long long)__float_as_uint(out);
-      __hip_atomic_store(p.gran + (size_t)n * 2 + b, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();                                                // (1b)
-    // gather this wave's quarter of the granules: one round trip per sweep, until every tag is this launch's
-    pair_v4f g[8];
-    bool done = false;
-    for (int spin = 0; spin < PAIR_SPINS && !done; ++spin) {
-      bool all = true;
-      pair_sweep8(p.gran + (size_t)e * 1024 + lane * 2, g);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        all = all && (__float_as_uint(g[i][1]) == 1u) && (__float_as_uint(g[i][3]) == 1u);
-        const int gi = e * 1024 + (i >> 2) * 512 + (i & 3) * 128 + lane * 2;   // granule index of g[i].xy (row 0 of output gi / 2); .zw: row 1
-        xs[(gi >> 1)] = g[i][0];
-        xs[PAIR_D + (gi >> 1)] = g[i][2];
-      }
-      done = __all(all);
-      if (!done) __builtin_amdgcn_s_sleep(2);
-    }
-    if (!done && lane == 0) *p.gave_up = 1;
-    __syncthreads();                                                // (2)
-    __syncthreads();                                                // (3)
-    __syncthreads();                                                // (4)
+    __syncthreads();                                                // (1) A's partial sums are parked
+    pair_stream_b<NUWB>(p, t, lane, wave, xr, w, efinB, partB, aux, xs, kvoff);
   }
 }
 
@@ -1219,19 +1369,35 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s);   // gemv
 extern "C" void ssrhip_debug_gemv_prof(void* dev_ptr) { g_gemv_prof = (long long*)dev_ptr; }
 #endif
 
-// Units per wave of B if (a, b) can run as one gemv_pair_kernel launch, 0 otherwise
-static int pair_nuwb(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b, int num_cu) {
+// Units per wave of B if (a, b) can run as one pair launch, 0 otherwise; *merge = A is the out-projection with the split-KV merge prologue
+// SSRHIP_GEMV_PAIR (read at every call: A/B inside one process): 0 = never, 1 = only FFN2 -> {QKV, head MLP}, unset / other = both forms
+static int pair_nuwb(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b, int num_cu, bool* merge) {
+  *merge = false;
   if (num_cu < 256) return 0;                                       // 256 workgroups must be resident together
   if (a->B != 2 || b->B != 2 || a->groups != 1 || b->groups != 1) return 0;
   if (a->x_tiled || a->y_tiled || a->w_tiled || b->x_tiled || b->y_tiled || b->w_tiled) return 0;
-  if (a->pro != SSRHIP_PRO_NONE || a->act != SSRHIP_ACT_NONE || a->epi != SSRHIP_EPI_RESIDUAL || a->K != 8192 || a->N != PAIR_D || !a->x || !a->y || !a->W) return 0;
+  if (a->act != SSRHIP_ACT_NONE || a->epi != SSRHIP_EPI_RESIDUAL || a->N != PAIR_D || !a->y || !a->W) return 0;
+  int mode = 2;
+  if (const char* e = getenv("SSRHIP_GEMV_PAIR")) mode = (e[0] == '0') ? 0 : (e[0] == '1') ? 1 : 2;
+  if (mode == 0) return 0;
+  if (a->pro == SSRHIP_PRO_NONE) {
+    if (a->K != 8192 || !a->x) return 0;
+  } else if (a->pro == SSRHIP_PRO_ATTN_COMBINE) {
+    if (mode < 2) return 0;
+    const int hd = a->kv.head_dim;
+    if (a->K != 2048 || !a->part_o || !a->part_ml || !a->row_len || a->max_splits < 1 || hd <= 0 || hd % 4 != 0 || a->K % hd != 0 || 2 * (a->K / hd) > SEG_TH) return 0;
+    if ((size_t)2 * (a->K / hd) * a->max_splits * sizeof(float) > 16 * 1024) return 0;   // merge weights in LDS next to the 17 KB of static buffers
+    *merge = true;
+  } else {
+    return 0;
+  }
   if (b->pro != SSRHIP_PRO_LAYERNORM || b->ln_w || b->ln_b || b->K != PAIR_D || b->x != a->y || b->x_stride != a->y_stride || !b->W || !b->y) return 0;
   if (b->epi != SSRHIP_EPI_STORE && b->epi != SSRHIP_EPI_QKV_APPEND) return 0;
   if (b->epi == SSRHIP_EPI_QKV_APPEND && !(b->N == 3 * b->K && b->kv.pool && b->kv.table && b->kv_pos && b->kv.head_dim > 0)) return 0;
   if (b->N % 256 != 0) return 0;
   const int nuwb = (b->N / 256) * 2 / SEG_NW;
   if ((b->N / 256) * 2 % SEG_NW != 0 || (nuwb != 4 && nuwb != 6 && nuwb != 8)) return 0;
-  if (const char* e = getenv("SSRHIP_GEMV_PAIR")) { if (e[0] == '0') return 0; }   // read at every call (A/B inside one process)
+  if (*merge && nuwb != 8) return 0;                                // the merge form is instantiated for FFN1 only
   return nuwb;
 }
 
@@ -1247,28 +1413,33 @@ static void ensure_num_cu() {
 extern "C" int ssrhip_gemv_pair_applicable(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b) {
   if (!a || !b) return 0;
   ensure_num_cu();
-  return pair_nuwb(a, b, g_num_cu) != 0;
+  bool merge;
+  return pair_nuwb(a, b, g_num_cu, &merge) != 0;
 }
 
 extern "C" int ssrhip_gemv_pair(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b, void* ws, int32_t buf, int32_t buf_next, ssrhip_stream_t stream) {
   SSR_REQUIRE(a && b && ws, "ssrhip_gemv_pair: null argument");
   SSR_REQUIRE(buf >= 0 && buf < 3 && buf_next >= 0 && buf_next < 3 && buf != buf_next, "ssrhip_gemv_pair: granule buffers %d -> %d (0..2, different)", buf, buf_next);
   ensure_num_cu();
-  const int nuwb = pair_nuwb(a, b, g_num_cu);
+  bool merge = false;
+  const int nuwb = pair_nuwb(a, b, g_num_cu, &merge);
   if (!nuwb) return 1;
   PairK p;
   auto fill = [](GemvK& k, const ssrhip_gemv_args* g, int S) {
     k.a = *g; k.nslice = S; k.slice_len = SEG; k.nch = 4; k.groups_x = 256; k.hd = (g->kv.head_dim > 0) ? g->kv.head_dim : 1;
     k.seg_shift = (S == 8) ? 3 : 1; k.rows_max = k.rows_per = g->N / 256; k.rows_rem = 0; k.prof = nullptr;
   };
-  fill(p.a, a, 8);
+  fill(p.a, a, merge ? 2 : 8);
   fill(p.b, b, 2);
   unsigned long long* gran = (unsigned long long*)ws;
   p.gran = gran + (size_t)buf * PAIR_GRAN;
   p.gran_next = gran + (size_t)buf_next * PAIR_GRAN;
   p.gave_up = (int*)(gran + 3 * (size_t)PAIR_GRAN);
   hipStream_t s = (hipStream_t)stream;
-  if (nuwb == 4) hipLaunchKernelGGL((gemv_pair_kernel<4>), dim3(256), dim3(PAIR_TH), 0, s, p);
+  if (merge) {
+    const size_t sm = ((size_t)2 * (a->K / a->kv.head_dim) * a->max_splits * sizeof(float) + 15) / 16 * 16;
+    hipLaunchKernelGGL((gemv_pair_merge_kernel<8>), dim3(256), dim3(PAIR_TH), sm, s, p);
+  } else if (nuwb == 4) hipLaunchKernelGGL((gemv_pair_kernel<4>), dim3(256), dim3(PAIR_TH), 0, s, p);
   else if (nuwb == 6) hipLaunchKernelGGL((gemv_pair_kernel<6>), dim3(256), dim3(PAIR_TH), 0, s, p);
   else hipLaunchKernelGGL((gemv_pair_kernel<8>), dim3(256), dim3(PAIR_TH), 0, s, p);
   SSR_LAUNCH_CHECK();

@@ -357,6 +357,54 @@ def test_gemv_pair_launch_is_bit_identical_to_the_two_launches(L):
             assert np.array_equal(got, want), (name, k, float(np.abs(got - want).max()))
         if epi == 2:
             assert np.abs(res["two"][2]).sum() > 0
+    # ---- the other pair of the step: split-KV merge + out-projection + residual, then LN + FFN1 + ReLU (gemv_pair_merge_kernel); contexts of
+    # 8 / 2 pages (beyond the 6 prefetched ones / short) and 3 / 5 pages, odd max_splits too
+    H, hd = 16, 128
+    for MS, lens in ((8, [1000, 129]), (8, [300, 640]), (7, [7 * _lib.PAGE, 1])):
+        g = torch.Generator().manual_seed(MS + lens[0])
+        Wo = [(torch.randn(D, D, generator=g) / math.sqrt(D)).cuda() for _ in range(2)]
+        bo = torch.randn(D, generator=g).cuda()
+        W1 = [(torch.randn(F, D, generator=g) / math.sqrt(D)).cuda() for _ in range(2)]
+        b1 = torch.randn(F, generator=g).cuda()
+        part_o = torch.randn(B, H, MS, hd, generator=g).cuda()
+        part_ml = torch.stack([torch.randn(B, H, MS, generator=g) * 2, torch.rand(B, H, MS, generator=g) + 0.5], dim=-1).contiguous().cuda()
+        for b_ in range(B):                                          # beyond the row's pages the buffers hold garbage the kernel must not use
+            n = (lens[b_] + _lib.PAGE - 1) // _lib.PAGE
+            part_o[b_, :, n:] = float("nan")
+            part_ml[b_, :, n:] = float("nan")
+        dlen = torch.tensor(lens, dtype=torch.int32, device="cuda")
+        x0 = (torch.randn(B, D, generator=g) * 1.5 + 0.3)
+        res = {}
+        for form in ("two", "pair"):
+            x = x0.clone().cuda()
+            y = torch.zeros(B, F, device="cuda")
+            n_pairs = 5
+            buf = lambda i: 1 if (i == n_pairs - 1 and n_pairs % 3 == 1) else i % 3
+            for rep in range(2):
+                for i in range(n_pairs):
+                    a = _lib.GemvArgs()
+                    a.W, a.bias, a.y = Wo[i % 2].data_ptr(), bo.data_ptr(), x.data_ptr()
+                    a.B, a.N, a.K, a.groups, a.x_stride, a.y_stride = B, D, D, 1, D, D
+                    a.pro, a.act, a.epi = _lib.PRO_ATTN_COMBINE, 0, _lib.EPI_RESIDUAL
+                    a.part_o, a.part_ml, a.max_splits, a.row_len = part_o.data_ptr(), part_ml.data_ptr(), MS, dlen.data_ptr()
+                    a.kv = _lib.KV(0, 0, MS, 1, H, hd)
+                    b = _lib.GemvArgs()
+                    b.W, b.bias, b.x, b.y = W1[i % 2].data_ptr(), b1.data_ptr(), x.data_ptr(), y.data_ptr()
+                    b.B, b.N, b.K, b.groups, b.x_stride, b.y_stride = B, F, D, 1, D, F
+                    b.pro, b.act, b.epi, b.ln_eps = 1, 1, 0, 1e-5
+                    assert L.ssrhip_gemv_pair_applicable(C.byref(a), C.byref(b)) == 1
+                    if form == "two":
+                        _lib.check(L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()))
+                        _lib.check(L.ssrhip_gemv(C.byref(b), _lib.stream_ptr()))
+                    else:
+                        rc = L.ssrhip_gemv_pair(C.byref(a), C.byref(b), ws.data_ptr(), buf(i), buf((i + 1) % n_pairs), _lib.stream_ptr())
+                        assert rc == 0, rc
+            torch.cuda.synchronize()
+            res[form] = (x.cpu().numpy(), y.cpu().numpy())
+        assert L.ssrhip_gemv_pair_status(ws.data_ptr(), _lib.stream_ptr()) == 0
+        for k, (got, want) in enumerate(zip(res["pair"], res["two"])):
+            assert np.isfinite(want).all()
+            assert np.array_equal(got, want), ("merge", MS, lens, k, float(np.abs(got - want).max()))
     # shapes that do not qualify are refused, nothing is launched
     a = _lib.GemvArgs(); b = _lib.GemvArgs()
     assert L.ssrhip_gemv_pair_applicable(C.byref(a), C.byref(b)) == 0
