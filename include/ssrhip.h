@@ -98,14 +98,17 @@ typedef struct ssrhip_gemv_args {
 
 int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream);
 
-/* Two consecutive launches of the 2-row decode step as ONE: `a` = FFN2 (+ bias + residual; models/modules/transformer.py:386-388 linear2
- * and the residual add at :328-329) and `b` = the LayerNorm + Linear that reads a's output (the next
- * layer's packed QKV projection — activation.py:86 — or the first Linear of the prediction heads, models/ssr.py:175-179), with the
- * all-to-all edge between them inside the launch (csrc/gemv.hip gemv_pair_kernel: tagged 8-byte granules, write-through stores, one
- * gather round trip). Results are bit-identical to ssrhip_gemv(a) followed by ssrhip_gemv(b).
+/* Two consecutive launches of the 2-row decode step as ONE: `a` = a GEMV with the residual epilogue and `b` = the LayerNorm + Linear that
+ * reads a's output, with the all-to-all edge between them inside the launch (csrc/gemv.hip gemv_pair_kernel / gemv_pair_merge_kernel:
+ * tagged 8-byte granules, write-through stores, one gather round trip). Two forms:
+ *   a = FFN2 (models/modules/transformer.py:386-388 linear2 + the residual add at :328-329), b = the next layer's packed QKV projection
+ *       (activation.py:86, with the KV append) or the first Linear of the prediction heads (models/ssr.py:175-179);
+ *   a = split-KV merge + out-projection (activation.py:637) + residual, b = LayerNorm + linear1 + ReLU (transformer.py:386-388).
+ * Results are bit-identical to ssrhip_gemv(a) followed by ssrhip_gemv(b).
  *   returns 0 = launched, 1 = this (a, b) does not qualify (nothing launched: call ssrhip_gemv twice), < 0 = error.
- *   Qualifies: B == 2 rows, a: PRO_NONE / ACT_NONE / EPI_RESIDUAL, K == 8192, N == 2048; b: PRO_LAYERNORM with folded gamma / beta,
- *   K == 2048, x == a->y, N in {4096, 6144, 8192}, EPI_STORE or EPI_QKV_APPEND; >= 256 CUs; SSRHIP_GEMV_PAIR != 0.
+ *   Qualifies: B == 2 rows; a: ACT_NONE / EPI_RESIDUAL, N == 2048, and either PRO_NONE with K == 8192 or PRO_ATTN_COMBINE with K == 2048;
+ *   b: PRO_LAYERNORM with folded gamma / beta, K == 2048, x == a->y, EPI_STORE or EPI_QKV_APPEND, N in {4096, 6144, 8192} (8192 only
+ *   behind the merge form); >= 256 CUs; SSRHIP_GEMV_PAIR (0 = never, 1 = only the FFN2 form).
  *   ws: SSRHIP_PAIR_WS_BYTES of device memory, zeroed once by the caller and then owned by the chain of pair launches: three granule
  *   buffers + the give-up flag. `buf` is the buffer this launch uses, `buf_next` (!= buf) the one the NEXT pair launch on this workspace
  *   will use — this launch resets it. Consecutive pair launches must therefore follow each other's buf_next, cyclically.

@@ -127,6 +127,42 @@ def test_round5_decode_kernels_keep_their_request_order_in_the_isa(gemv_asm, tmp
     assert waits and min(waits) >= 16, waits
 
 
+def test_pair_kernels_keep_exact_wait_counts_and_the_scalar_path(gemv_asm):
+    """The paired launches of the 2-row step (gemv_pair_kernel<4|6|8>, gemv_pair_merge_kernel<8>) run 12 waves per workgroup — three per
+    SIMD, 168 VGPRs at most — as two branch arms, one per role. Read off the ISA while building them, each easy to lose again:
+      * written as a series of `if (wave < 8)` blocks the streaming role's units were guarded by vmcnt(4 PF - 1) instead of vmcnt(15) (the
+        wait-count pass merges the "block skipped" path into every join): with one arm per role every re-request sits behind
+        `s_waitcnt vmcnt(15)` — (NUW - 4) x 4 of them per phase plus the first of the tail — and the kernel drains exactly twice;
+      * with the edge role's arm laid out FIRST its stores made the streaming arm's uniform loads (row_len of the merge; the kv_pos chain)
+        "possibly clobbered": vector loads behind vmcnt(0) in front of the first weight request. The streaming arm comes first (its first
+        branch is taken by the edge waves), row_len is an s_load, the KV-append chain lives in the edge arm;
+      * inside `if (t < B * H)` the merge's (m, l) loads were sunk behind the weight requests and their first use drained the queue: the six
+        global_load_dwordx2 precede the first non-temporal load."""
+    meta = _kernel_meta(gemv_asm)
+    pairs = sorted(k for k in meta if "gemv_pair" in k)
+    assert len(pairs) == 4, pairs
+    for sym in pairs:
+        vgpr, scratch = meta[sym]
+        assert vgpr <= 168 and scratch == 0, (sym, vgpr, scratch)
+        body = _whole_body(gemv_asm, sym)
+        merge = "gemv_pair_merge" in sym
+        nuwb = int(re.search(r"kernelILi(\d)E", sym).group(1))
+        # the streaming arm: from the first non-temporal load to the end of the function or the edge arm's sweep, whichever the layout puts last
+        first_nt = body.index(" nt\n")
+        stream = body[:body.index("sc1")] if body.index("sc1") > first_nt else body[first_nt:]
+        # per phase: (units - 4) x 4 re-requests + the first wait of the tail; the merge walks its prefetched partials 19, 19, 18, 18 .. down
+        want15 = (2 if merge else (8 - 4) * 4 + 1) + (nuwb - 4) * 4 + 1
+        assert stream.count("s_waitcnt vmcnt(15)") == want15, (sym, stream.count("s_waitcnt vmcnt(15)"), want15)
+        if merge:
+            assert body.index("sc1") > first_nt, "the edge role's arm precedes the streaming arm again"
+            head = body[:first_nt]
+            assert len(re.findall(r"global_load_dwordx2 ", head)) >= 6, "the (m, l) loads are behind the weight requests again"
+            assert not re.search(r"s_waitcnt[^\n]*vmcnt", head), "a vector-memory wait in front of the first weight request (row_len off the scalar path?)"
+        else:
+            hot = re.sub(r";;#ASMSTART.*?;;#ASMEND", "", stream, flags=re.S)
+            assert hot.count("vmcnt(0)") <= 2 + (1 if nuwb == 4 else 0), (sym, hot.count("vmcnt(0)"))
+
+
 def test_generic_and_matrix_core_gemv_kernels_do_not_spill(gemv_asm, tmp_path_factory):
     assert not [k for k in _kernel_meta(gemv_asm) if "gemv_fast_kernel" in k]          # the intermediate generation is gone (round 3)
     generic = {k: v for k, v in _kernel_meta(gemv_asm).items() if "gemv_kernel" in k and "ILi2E" in k}
