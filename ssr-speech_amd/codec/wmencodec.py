@@ -27,6 +27,21 @@ def _extra_padding(length: int, k: int, s: int, pt: int) -> int:
     return (math.ceil(n_frames) - 1) * s + (k - pt) - length
 
 
+def _empty(*shape, dtype, device):
+    """torch.empty for the activation / state workspaces. SSRHIP_POISON_ALLOC=1 (debug; tools/poison_check.py, read at every call) fills them
+    with NaN (float) / 0x7FC0 = bf16 NaN (int16) / a huge index (int32) instead: a kernel that READS a location no producer wrote turns its
+    outputs NaN, where with plain torch.empty the result silently depends on what the allocator's block held before."""
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    if os.environ.get("SSRHIP_POISON_ALLOC", "0") not in ("", "0"):
+        if dtype == torch.float32:
+            t.fill_(float("nan"))
+        elif dtype == torch.int16:
+            t.fill_(0x7FC0)
+        else:
+            t.fill_(0x3FFFFFFF)
+    return t
+
+
 class TM:
     """Time-major activation buffer with halo rows."""
 
@@ -38,7 +53,7 @@ class TM:
         # every producer writes the whole interior; only the halo rows need a defined value before the consumer reads them
         # (zero for constant / structural padding; reflect padding overwrites them). A torch.zeros of the whole buffer was 24
         # full-size memsets per encode+decode (6.7 ms at 32 clips x 30 s).
-        self.data = torch.empty(B, self.rows, Cc, dtype=torch.float32, device=device)
+        self.data = _empty(B, self.rows, Cc, dtype=torch.float32, device=device)
         if padL:
             self.data[:, :padL].zero_()
         if padR:
@@ -455,13 +470,13 @@ class WMEncodecModel:
         assert x.padL == 0 and x.padR == 0 and not x.elu
         nl = len(L.layers)
         rows = (B + 15) // 16 * 16                                     # include/ssrhip.h ssrhip_lstm_args
-        gins = [torch.empty(B, T, 4 * Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
-        hbufs = [torch.empty(2, rows, Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
-        cbufs = [torch.empty(B, Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
+        gins = [_empty(B, T, 4 * Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
+        hbufs = [_empty(2, rows, Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
+        cbufs = [_empty(B, Cc, dtype=torch.float32, device=dev) for _ in range(nl)]
         outs = [self._alloc_for(B, T, Cc, nxt, x.lens) if l == nl - 1 else TM(B, T, Cc, 0, 0, dev) for l in range(nl)]
         # h of the split-operand path: two buffers of bf16 planes in fragment order (zeroed by the library at t = 0)
         use_split = self.lstm_split and B >= self.lstm_split_min_b and not (B <= 4 and Cc in (256, 512, 1024, 2048))
-        hsplits = [torch.empty(2 * ((B + 63) // 64) * 64 * Cc * 3, dtype=torch.int16, device=dev) if (use_split and L.split[l] is not None) else None
+        hsplits = [_empty(2 * ((B + 63) // 64) * 64 * Cc * 3, dtype=torch.int16, device=dev) if (use_split and L.split[l] is not None) else None
                    for l in range(nl)]
 
         def in_gemm(l, t0, t1):                                        # gin_l[:, t0:t1] = in_l[:, t0:t1] W_ih^T + b
@@ -590,7 +605,7 @@ class WMEncodecModel:
             inp = self._input_tm(x[lo:hi], self.encoder.nodes[0])
             emb = self._run(self.encoder.nodes, inp)
             B, T, D = emb.B, emb.T, emb.C
-            codes = torch.empty(B, self.cfg.n_q, T, dtype=torch.int32, device=self.device)
+            codes = _empty(B, self.cfg.n_q, T, dtype=torch.int32, device=self.device)
             _lib.check(self.lib.ssrhip_rvq_encode(emb.interior, self.codebooks.data_ptr(), self.e2.data_ptr(), codes.data_ptr(), B, T, D,
                                                   self.cfg.n_q, self.cfg.bins, emb.bstride, self._s()), "ssrhip_rvq_encode")
             return codes.to(torch.int64), emb.interior_view().transpose(1, 2).contiguous()

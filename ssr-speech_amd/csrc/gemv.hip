@@ -875,11 +875,14 @@ __global__ __launch_bounds__(SEG_TH, 2) void gemv_segu_kernel(const GemvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Round 5: TWO consecutive GEMVs of the 2-row step in ONE launch — `A` = FFN2 (+ bias + residual, K = 8192, N = D = 2048) and `B` = the
-// launch that consumes its output through a LayerNorm (QKV of the next layer, or the head MLP after the last layer) — with the all-to-all
-// edge between them (every CU needs all B x D outputs of A) inside the launch. tools/layer_edge_lab.hip priced 8 forms of that edge on
-// this machine (profiles/r05_microbench/layer_edge_lab.log): two launches 21.3 us; one edge wave gathering alone 22.8; requests of B posted
-// before the publish 23.6 (the publish queues behind 128 KB of requests); ... ; this form 19.7-19.9:
+// Round 5: TWO consecutive GEMVs of the 2-row step in ONE launch — `A` = a GEMV with the residual epilogue (N = D = 2048) and `B` = the
+// launch that consumes its output through a LayerNorm — with the all-to-all edge between them (every CU needs all B x D outputs of A)
+// inside the launch. Two forms: A = FFN2 (K = 8192) with B = QKV of the next layer or the head MLP after the last layer
+// (gemv_pair_kernel), and A = split-KV merge + out-projection (K = 2048) with B = FFN1 (gemv_pair_merge_kernel); the step is then QKV of
+// layer 0 and, per layer, attention + two pair launches: 51 launches instead of 83, 0.7926 -> 0.7338 ms/step in a same-box A/B
+// (profiles/r05_microbench/decode_ab_pair2.log). tools/layer_edge_lab.hip priced 12 forms of the edge on this machine
+// (profiles/r05_microbench/layer_edge_lab.log): two launches 21.3 us; one edge wave gathering alone 22.8; requests of B posted before the
+// publish 23.6 (the publish queues behind 128 KB of requests); ... ; this form 19.7-19.9:
 //   * 256 workgroups (one per CU) x 12 waves. Waves 0-7 stream A's units exactly as gemv_segu_kernel does and park the partial sums.
 //   * barrier; wave 8 finishes the workgroup's 8 rows x 2 outputs, writes them to the residual stream AND publishes them as 8-byte
 //     {value, tag = 1} granules with agent-scope (write-through, sc1) stores; barrier; only now waves 0-7 post their first THREE units of B

@@ -391,8 +391,12 @@ def test_codec_calls_on_concurrent_streams_equal_the_single_stream_results():
             torch.cuda.current_stream().wait_stream(st)
         torch.cuda.synchronize()
         for i in range(3):
-            for a, b in zip(alone[i], got[i]):
-                assert torch.equal(a, b), (rnd, i, float((a.float() - b.float()).abs().max()))
+            for k, (a, b) in enumerate(zip(alone[i], got[i])):
+                if not torch.equal(a, b):
+                    bad = (a != b).nonzero()
+                    raise AssertionError(f"round {rnd}, caller {i} (batch {Bs[i]}), output {k} of (codes, emb, dec, wm, mark), shape {tuple(a.shape)}: "
+                                         f"{bad.shape[0]} elements differ, max |diff| {float((a.float() - b.float()).abs().max()):.3g}, "
+                                         f"first at {bad[0].tolist()}, last at {bad[-1].tolist()}")
 
 
 @pytest.mark.parametrize("knob", ["SSRHIP_GEMM_SPLIT_DMA=0", "SSRHIP_RESBLOCK_DMA=0", "SSRHIP_EPILOGUE_TM=0"])
