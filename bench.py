@@ -40,10 +40,11 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # command, gfx950 corrections of MI355X_MICROARCH.md: FETCH_SIZE x2 for wide coalesced reads). `traffic` in the JSON line is this figure
 # divided by the step's number of GEMV launches (the paired launches of the 2-row step move the bytes of the two launches they replace).
 # Not re-measured live (counters need rocprofv3): the constants are this round's profiles, named in `traffic_source`.
-#   2 rows : round 5, see TRAFFIC_SOURCE
+#   2 rows : round 5, final build: 118.57 x15 (FFN2 | QKV) + 101.75 (FFN2 | head-MLP1) + 85.31 x16 (out-proj | FFN1) + 50.65 (QKV of layer 0)
+#             + 34.09 (head-MLP2) = 3,330.0 MB read + 4.6 MB written per step; algorithmic 3,290.2 MB: ratio 1.0135
 #   16 rows: (59.30 x33 + 71.66 x16 + 18.17 x16 + 36.04) = 3,432 MB read + 20 MB written (x re-read through L2 by the streamed-x kernel; round 2)
-TRAFFIC_BYTES_PER_STEP_GEMVS = {2: 66 * 50.46e6, 16: 66 * 52.3e6}
-TRAFFIC_SOURCE = {2: "profiles/r05_pmc_fetch_size.md + profiles/r05_pmc_write_size.md (3,327 MB read + 3 MB written by the GEMV launches of a step)",
+TRAFFIC_BYTES_PER_STEP_GEMVS = {2: 3334.6e6, 16: 66 * 52.3e6}
+TRAFFIC_SOURCE = {2: "profiles/r05_pmc_fetch_size.md + profiles/r05_pmc_write_size.md (3,330.0 MB read + 4.6 MB written by the 34 GEMV launches of a step)",
                   16: "profiles/r02_pmc_fetch_size_16rows.md + profiles/r02_pmc_write_size_16rows.md"}
 
 
@@ -617,8 +618,8 @@ def main():
             "decode_rtf_10s": round((500 * ms_per_step / 1000) / 10.0, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r04_pmc_*.md), gfx950 x2 correction
-                         # for wide reads applied: 50.5 MB read + 0.1 MB written per GEMV launch vs 49.85 MB algorithmic
+                         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r05_pmc_*.md), gfx950 x2 correction
+                         # for wide reads applied: per step 3,330.0 MB read + 4.6 MB written vs 3,290.2 MB algorithmic (divided by the step's GEMV launch count)
                          "traffic": (round(TRAFFIC_BYTES_PER_STEP_GEMVS[2 * U] / n_gemv) if (2 * U in TRAFFIC_BYTES_PER_STEP_GEMVS and arena.D == 2048 and arena.L == 16) else None),
                          "traffic_source": TRAFFIC_SOURCE.get(2 * U, "not measured for this row count") + " (rocprofv3 --pmc passes of this command, gfx950 x2 FETCH_SIZE correction)",
                          "kernel": ((f"gemv_pair_merge_kernel (split-KV merge + out-proj + residual | LN + FFN1 + ReLU) and gemv_pair_kernel (FFN2 + residual | LN + QKV + KV append) "

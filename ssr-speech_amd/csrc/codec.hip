@@ -114,6 +114,71 @@ __global__ __launch_bounds__(256) void conv_few_out_kernel(const float* __restri
   }
 }
 
+// The same layer on the matrix core (round 5; VERDICT r4: "conv_few_out <= 8 ms"): the kernel above spends 224 LDS reads per output (its
+// 448-float window and the 448 weights, both through LDS) — 13.3 ms per config-5 decode pass against 6.3 ms of HBM time for the 31.5 GB it
+// reads. Here a lane never re-reads an input element: for C_out == 1 the layer is P[r][kk] = x[r][:] . w[kk][:] (a [rows x C_in] x
+// [C_in x k] GEMM, k <= 16 columns of a 16 x 16 tile) followed by the diagonal sum out[t] = sum_kk P[t + kk][kk]. A wave takes 16 input
+// rows at a time straight from global memory into v_mfma_f32_16x16x4_f32's A operand — lane (c = l & 15, g = l >> 4) loads the four
+// float4 x[row c][16 q + 4 g ..] (64 contiguous bytes per row and instruction; ELU on load) — against the weights held as the B operand in
+// C_in / 4 registers (column c = tap c, zero beyond k; the k index of MFMA (q, comp) is 16 q + 4 g + comp on both sides), parks the k
+// useful columns of the tile in LDS (rows padded to 17 floats: the diagonal reads are conflict-free) and, behind one barrier, thread t adds
+// its diagonal in tap order. fp32 MFMA = an fmaf chain (MI355X_MICROARCH.md); the summation ORDER differs from the kernel above (channels
+// in MFMA order, then taps), so results agree with it to rounding, not bit for bit.
+template <int CQ, bool ELU>
+__global__ __launch_bounds__(256) void conv_one_out_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                float* __restrict__ out, int T_out, int k, long x_bstride, long out_bstride) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  constexpr int Cin = 16 * CQ, TT = 256, LDP = 17, MAXT = 5;       // 256 outputs + k - 1 <= 271 rows = 17 tiles of 16 over 4 waves
+  __shared__ float P[(TT + 16) * LDP];
+  const float* xb = x + (size_t)blockIdx.y * x_bstride;
+  float* ob = out + (size_t)blockIdx.y * out_bstride;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), c = lane & 15, g = lane >> 4;
+  const int t0 = blockIdx.x * TT, nt = min(TT, T_out - t0);
+  const int rows = nt + k - 1, ntiles = (rows + 15) >> 4, last_row = T_out + k - 2;        // the input has T_out + k - 1 rows
+  float4 wq[CQ];                                                   // the weights first (L2 hits): the waits in front of the tiles then count down through the x loads
+#pragma unroll
+  for (int q = 0; q < CQ; ++q) {                                   // unconditional (clamped) loads, zeroed by selects: no branch, no drain
+    const float4 v = ld4(w + (size_t)min(c, k - 1) * Cin + 16 * q + 4 * g);
+    wq[q] = make_float4(c < k ? v.x : 0.f, c < k ? v.y : 0.f, c < k ? v.z : 0.f, c < k ? v.w : 0.f);
+  }
+  float4 xa[MAXT][CQ];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int tile = wave + 4 * i;
+    if (tile < ntiles) {
+      const float* xr = xb + (size_t)min(t0 + tile * 16 + c, last_row) * Cin + 4 * g;
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) xa[i][q] = ld4(xr + 16 * q);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int tile = wave + 4 * i;
+    if (tile < ntiles) {
+      f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) {
+        float4 v = xa[i][q];
+        if (ELU) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, wq[q].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, wq[q].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, wq[q].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, wq[q].w, acc, 0, 0, 0);
+      }
+      if (c < k) {                                                 // D[row 4 g + r][tap c]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[(tile * 16 + 4 * g + r) * LDP + c] = acc[r];
+      }
+    }
+  }
+  __syncthreads();
+  if (t < nt) {
+    float s = P[t * LDP];
+    for (int kk = 1; kk < k; ++kk) s += P[(t + kk) * LDP + kk];
+    ob[(size_t)(t0 + t)] = s + bias[0];
+  }
+}
+
 // Reflect padding with the reference's small-input rule (audiocraft/modules/conv.py:71-88): an input no longer than the larger
 // pad is first zero-extended on the right by `extra = max_pad - T + 1` samples, reflected, and the last `extra` samples of
 // the result are dropped again. x' = [x, 0 * extra], T' = T + extra; a halo row takes x'[i] (zero when i >= T).
@@ -613,6 +678,15 @@ extern "C" int ssrhip_conv_few_out(const float* x, const float* w, const float* 
   SSR_REQUIRE(x && w && bias && out && B > 0 && T_out > 0 && k > 0 && Cin > 0 && Cout > 0, "ssrhip_conv_few_out: bad argument");
   SSR_REQUIRE(Cin % 8 == 0 && Cout <= 4 && B <= 65535, "ssrhip_conv_few_out: needs C_in %% 8 == 0 and C_out <= 4");
   SSR_REQUIRE(act_in == SSRHIP_ACT_NONE || act_in == SSRHIP_ACT_ELU, "ssrhip_conv_few_out: act_in must be NONE or ELU");
+  // one output channel, 64 input channels, at most 16 taps (SEANet's last layer): the matrix-core form (SSRHIP_CONV_FEW_MFMA=0: the LDS form)
+  static const bool mfma_off = getenv("SSRHIP_CONV_FEW_MFMA") && getenv("SSRHIP_CONV_FEW_MFMA")[0] == '0';
+  if (!mfma_off && Cout == 1 && Cin == 64 && k <= 16) {
+    dim3 grid((T_out + 255) / 256, B);
+    if (act_in == SSRHIP_ACT_ELU) hipLaunchKernelGGL((conv_one_out_mfma_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, T_out, k, (long)x_bstride, (long)out_bstride);
+    else hipLaunchKernelGGL((conv_one_out_mfma_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, T_out, k, (long)x_bstride, (long)out_bstride);
+    SSR_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t wbytes = (size_t)Cout * k * Cin * sizeof(float);
   int TT = 256;
   while (TT > 32 && (size_t)(TT + k - 1) * (Cin + 4) * sizeof(float) + wbytes > 78 * 1024) TT >>= 1;     // two workgroups per CU

@@ -163,6 +163,34 @@ def test_pair_kernels_keep_exact_wait_counts_and_the_scalar_path(gemv_asm):
             assert hot.count("vmcnt(0)") <= 2 + (1 if nuwb == 4 else 0), (sym, hot.count("vmcnt(0)"))
 
 
+def test_residual_block_dma_wait_counts_the_loads_the_compiler_really_issued(tmp_path_factory):
+    """`resblock_split_dma_kernel` completes its weight-tile DMA (inline asm, invisible to hipcc's wait-count pass) through a
+    hand-counted `s_waitcnt vmcnt(CNT * tiles_after(u) + NEL)`; at tap 1 the count assumes that exactly NEL = 5 compiler-issued loads of
+    the next ELU(x) tile are YOUNGER than the tile being waited for. If hipcc merged, sank or dropped one of them the wait would be one
+    too loose and a stale weight tile would be consumed silently. The shipped ring depth is 2: the tap-1 wait is `vmcnt(5)`; between the
+    workgroup barrier in front of the DMA requests and that wait there must be the DMA instructions followed by exactly five
+    `global_load_dwordx4` and nothing else that counts."""
+    asm = _asm(tmp_path_factory, "resblock_split")
+    syms = [k for k in _kernel_meta(asm) if "resblock_split_dma_kernel" in k and "ELi2ELi0E" in k]
+    assert len(syms) == 2, syms                                      # 64 and 128 channels, ring of 2
+    for sym in syms:
+        body = _whole_body(asm, sym)
+        waits = [m.start() for m in re.finditer(r"s_waitcnt vmcnt\(5\)", body)]
+        assert waits, sym
+        seen = 0
+        for w in waits:
+            seg = body[body.rindex("s_barrier", 0, w):w]
+            ops = re.findall(r"(buffer_load_dwordx4[^\n]*lds|global_load_dword\S*|global_store\S*|buffer_store\S*)", seg)
+            dma = [o for o in ops if o.startswith("buffer_load")]
+            if not dma:
+                continue                                              # a vmcnt(5) of an epilogue's descending sequence
+            seen += 1
+            rest = [o for o in ops if not o.startswith("buffer_load")]
+            assert ops[:len(dma)] == dma, (sym, ops)                  # the DMA requests first ...
+            assert rest == ["global_load_dwordx4"] * 5, (sym, rest)    # ... then exactly NEL loads of the next ELU(x) tile
+        assert seen >= 1, sym
+
+
 def test_generic_and_matrix_core_gemv_kernels_do_not_spill(gemv_asm, tmp_path_factory):
     assert not [k for k in _kernel_meta(gemv_asm) if "gemv_fast_kernel" in k]          # the intermediate generation is gone (round 3)
     generic = {k: v for k, v in _kernel_meta(gemv_asm).items() if "gemv_kernel" in k and "ILi2E" in k}
