@@ -8,7 +8,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("resblock_split_dma_kernel", "lstm_step_split_kernel", "gemv_pair_merge_kernel", "gemv_pair_kernel", "gemv_segu_kernel", "gemv_rows_xreg_kernel", "gemv_rows_stream_kernel", "attn_rows_kernel", "attn_prefill_kernel", "conv_few_out_kernel", "conv_cin1_vec_kernel",
+    for k in ("resblock_split_dma_kernel", "lstm_step_split_kernel", "gemv_pair_merge_kernel", "gemv_pair_kernel", "gemv_segu_kernel", "gemv_rows_xreg_kernel", "gemv_rows_stream_kernel", "attn_rows_kernel", "attn_prefill_kernel", "conv_one_out_mfma_kernel", "conv_few_out_kernel", "conv_cin1_vec_kernel",
               "resblock64_kernel", "resblock_chain_split_kernel", "resblock_chain_kernel", "lstm_step_wide_kernel",
               "gemv_seg_kernel", "gemv_fast_kernel", "gemv_mfma_kernel", "gemv_kernel", "attn_decode_kernel", "attn_combine_kernel", "sample_kernel", "gemm_split_dma_kernel", "gemm_split_kernel", "gemm_kernel",
               "lstm_step_mfma_kernel", "lstm_step_kernel", "rvq_encode_mfma_kernel", "rvq_encode_kernel"):

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("resblock_split_dma_kernel", "lstm_step_split_kernel", "gemv_pair_merge_kernel", "gemv_pair_kernel", "gemv_segu_kernel", "gemv_rows_xreg_kernel", "gemv_rows_stream_kernel", "attn_rows_kernel", "conv_few_out_kernel", "conv_cin1_vec_kernel", "lstm_step_wide_kernel", "resblock_chain_split_kernel", "resblock_chain_kernel", "attn_prefill_kernel", "gemv_seg_kernel", "gemv_fast_kernel", "gemv_mfma_kernel", "gemv_kernel", "resblock64_kernel", "lstm_step_mfma_kernel", "lstm_step_kernel", "rvq_encode_mfma_kernel", "conv_cin1_kernel", "attn_decode_kernel", "attn_combine_kernel", "sample_kernel", "embed_kernel", "gemm_split_dma_kernel", "gemm_split_kernel", "gemm_kernel", "layernorm_kernel", "kv_scatter_kernel"):
+    for k in ("resblock_split_dma_kernel", "lstm_step_split_kernel", "gemv_pair_merge_kernel", "gemv_pair_kernel", "gemv_segu_kernel", "gemv_rows_xreg_kernel", "gemv_rows_stream_kernel", "attn_rows_kernel", "conv_one_out_mfma_kernel", "conv_few_out_kernel", "conv_cin1_vec_kernel", "lstm_step_wide_kernel", "resblock_chain_split_kernel", "resblock_chain_kernel", "attn_prefill_kernel", "gemv_seg_kernel", "gemv_fast_kernel", "gemv_mfma_kernel", "gemv_kernel", "resblock64_kernel", "lstm_step_mfma_kernel", "lstm_step_kernel", "rvq_encode_mfma_kernel", "conv_cin1_kernel", "attn_decode_kernel", "attn_combine_kernel", "sample_kernel", "embed_kernel", "gemm_split_dma_kernel", "gemm_split_kernel", "gemm_kernel", "layernorm_kernel", "kv_scatter_kernel"):
         if k in name:
             return k + (name[name.index(k) + len(k):].split("(")[0] if "<" in name else "")
     return "torch:" + name.split("<")[0].split("(")[0][-40:]
