@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSRHIP_VERSION 104
+#define SSRHIP_VERSION 105
 #define SSRHIP_PAGE 128          /* KV-cache page = 128 positions */
 #define SSRHIP_MAX_CODEBOOKS 4
 #define SSRHIP_MAX_SILENCE 8
@@ -115,6 +115,7 @@ int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream);
  *   The launch needs its 256 workgroups resident together; a workgroup that waits longer than ~1 s for the others gives up, sets the
  *   flag and the outputs are garbage: ssrhip_gemv_pair_status (synchronises `stream`) returns 1 from then on. */
 #define SSRHIP_PAIR_WS_BYTES (3 * 4096 * 8 + 64)
+int ssrhip_pair_buffer(int32_t i, int32_t n);   /* granule buffer (0..2) of the i-th of n cyclically consecutive pair launches; -1: bad i / n < 2 */
 int ssrhip_gemv_pair_applicable(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b);
 int ssrhip_gemv_pair(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b, void* ws, int32_t buf, int32_t buf_next, ssrhip_stream_t stream);
 int ssrhip_gemv_pair_status(const void* ws, ssrhip_stream_t stream);

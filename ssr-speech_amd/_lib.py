@@ -157,6 +157,7 @@ SYMBOLS = [
     ("ssrhip_sizeof", C.c_int, [C.c_int]),
     ("ssrhip_last_error", C.c_char_p, []),
     ("ssrhip_gemv", C.c_int, [C.POINTER(GemvArgs), C.c_void_p]),
+    ("ssrhip_pair_buffer", C.c_int, [C.c_int32, C.c_int32]),
     ("ssrhip_gemv_pair_applicable", C.c_int, [C.POINTER(GemvArgs), C.POINTER(GemvArgs)]),
     ("ssrhip_gemv_pair", C.c_int, [C.POINTER(GemvArgs), C.POINTER(GemvArgs), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("ssrhip_gemv_pair_status", C.c_int, [C.c_void_p, C.c_void_p]),

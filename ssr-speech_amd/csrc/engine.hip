@@ -181,7 +181,7 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     n_pairs = (pair_qkv ? d.n_layer - 1 : 0) + (pair_head ? 1 : 0) + (pair_ffn1 ? d.n_layer : 0);
     if (n_pairs < 2) { n_pairs = 0; pair_qkv = pair_head = pair_ffn1 = false; }
   }
-  auto pair_buf = [&](int i) { return (i == n_pairs - 1 && n_pairs % 3 == 1) ? 1 : i % 3; };
+  auto pair_buf = [&](int i) { return ssrhip_pair_buffer(i, n_pairs); };
   int pair_i = 0;
   bool qkv_done = false;                        // this layer's QKV already ran inside the previous layer's pair launch
 

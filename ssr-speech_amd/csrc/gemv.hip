@@ -1413,6 +1413,14 @@ static void ensure_num_cu() {
   }
 }
 
+// Granule buffer of the i-th of n pair launches that follow each other cyclically (a decode step's pairs, replayed step after step):
+// i % 3, except that the last launch takes buffer 1 when n % 3 == 1 (it would otherwise share buffer 0 with launch 0 of the next cycle).
+// Any two cyclically consecutive launches use different buffers for every n >= 2 (tests/test_capi.py checks 2..200).
+extern "C" int ssrhip_pair_buffer(int32_t i, int32_t n) {
+  if (n < 2 || i < 0 || i >= n) return -1;
+  return (i == n - 1 && n % 3 == 1) ? 1 : i % 3;
+}
+
 extern "C" int ssrhip_gemv_pair_applicable(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b) {
   if (!a || !b) return 0;
   ensure_num_cu();

@@ -31,8 +31,21 @@ def test_header_symbols_are_exported(built):
 
 def test_version_and_error_string(built):
     L = _lib.lib()
-    assert L.ssrhip_version() == 104
+    assert L.ssrhip_version() == 105
     assert isinstance(L.ssrhip_last_error(), bytes)
+
+
+def test_pair_launches_never_share_a_granule_buffer_with_their_neighbour(built):
+    """The paired GEMV launches of the 2-row decode step (csrc/gemv.hip gemv_pair_kernel) publish their outputs as tagged granules; a
+    launch resets the buffer the NEXT pair launch will use, so two launches that follow each other — cyclically: the last of a step is
+    followed by the first of the next step, graph replay after graph replay — must never use the same one of the three buffers. Host
+    logic, no GPU: the rule engine.hip applies (ssrhip_pair_buffer) for every count of pairs per step."""
+    L = _lib.lib()
+    for n in range(2, 201):
+        bufs = [L.ssrhip_pair_buffer(i, n) for i in range(n)]
+        assert all(b in (0, 1, 2) for b in bufs), (n, bufs)
+        assert all(bufs[i] != bufs[(i + 1) % n] for i in range(n)), (n, bufs)
+    assert L.ssrhip_pair_buffer(0, 1) == -1 and L.ssrhip_pair_buffer(3, 3) == -1 and L.ssrhip_pair_buffer(-1, 5) == -1
 
 
 def test_argument_validation_needs_no_gpu(built):
