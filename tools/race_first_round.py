@@ -24,6 +24,24 @@ if len(sys.argv) > 1 and sys.argv[1] == "nopipe":
     m.LSTM_CHUNK = 10 ** 9
 
 
+# every layer output of the DETECTOR pass (wm_encoder) is kept, for the calls alone and for the concurrent round: if `mark` differs, the
+# first layer whose output differs names the kernel (the buffers are only referenced, not copied: no extra launches)
+orig_run = m._run
+rec = None
+
+
+def run_rec(nodes, x, after=None):
+    if nodes is not m.wm_encoder.nodes or rec is None:
+        return orig_run(nodes, x, after)
+    for idx in range(len(nodes)):
+        x = orig_run(nodes[idx: idx + 1], x, after=(nodes[idx + 1] if idx + 1 < len(nodes) else after))
+        rec.append((nodes[idx][1], x))
+    return x
+
+
+m._run = run_rec
+
+
 def call(i):
     codes, _, emb = m.encode(wavs[i])
     dec = m.decode(codes)
@@ -31,14 +49,23 @@ def call(i):
     return codes, emb, dec, wm, mark
 
 
-alone = [call(i) for i in range(3)]
+alone, layers_alone = [], []
+for i in range(3):
+    rec = []
+    alone.append(call(i))
+    layers_alone.append(rec)
+rec = None
 torch.cuda.synchronize()
 streams = [torch.cuda.Stream() for _ in range(3)]
 got = [None] * 3
+layers_got = []
 for i in (0, 1, 2):
     streams[i].wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(streams[i]):
+        rec = []
         got[i] = call(i)
+        layers_got.append(rec)
+rec = None
 for st in streams:
     torch.cuda.current_stream().wait_stream(st)
 torch.cuda.synchronize()
@@ -55,4 +82,20 @@ for i in range(3):
                     nz = (per_t > 0).nonzero().flatten().tolist()
                     print(f"    item {bi}: frames differing {len(nz)} of {per_t.numel()}, first {nz[0] if nz else None}, last {nz[-1] if nz else None}, "
                           f"max at t={int(per_t.argmax())} ({float(per_t.max()):.3g}); per-frame max (x1e4): {' '.join(f'{v * 1e4:.0f}' for v in per_t.tolist())}")
+if not ok:
+    for i in range(3):
+        for li, ((kind, a), (_, b)) in enumerate(zip(layers_alone[i], layers_got[i])):
+            da, db = a.data, b.data
+            if da.shape == db.shape and not torch.equal(da, db):
+                w = (da != db).nonzero()
+                rows = w[:, 1] - a.padL
+                print(f"    caller {i}: FIRST differing detector layer = #{li} ({kind}), output [{a.B}][{a.T}][{a.C}]: {w.shape[0]} values differ, max "
+                      f"{float((da - db).abs().max()):.3g}; items {sorted(set(w[:, 0].tolist()))}, rows {int(rows.min())}..{int(rows.max())}, channels {int(w[:, 2].min())}..{int(w[:, 2].max())}; "
+                      f"layers before it: {[k for k, _ in layers_alone[i][:li]]}")
+                seen = {}
+                for it, r, ch in w.tolist():
+                    seen.setdefault((it, r), []).append(ch)
+                for (it, r), chs in list(seen.items())[:5]:
+                    print(f"        item {it} row {r - a.padL}: channels {chs}; alone {[round(float(da[it, r, c_]), 4) for c_ in chs[:6]]} concurrent {[round(float(db[it, r, c_]), 4) for c_ in chs[:6]]}")
+                break
 print("first concurrent round:", "identical" if ok else "DIFFERENT")
