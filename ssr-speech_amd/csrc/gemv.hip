@@ -1049,10 +1049,13 @@ __device__ __forceinline__ void pair_edge_role(const PairK& p, int e, int lane, 
     __hip_atomic_store(p.gran + (size_t)n * 2 + b, gval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();                                                  // (1b)
-  // gather this wave's quarter of the granules: one round trip per sweep, until every tag is this launch's
+  // gather this wave's quarter of the granules: one round trip per sweep, until every tag is this launch's. Once ANY launch on this
+  // workspace has given up (results are garbage from there on and the host will raise at its next poll) the later launches do not wait
+  // ~half a second each any more: a chain that cannot get its workgroups resident together costs one long stall, not one per launch
   pair_v4f g[8];
   bool done = false;
-  for (int spin = 0; spin < PAIR_SPINS && !done; ++spin) {
+  const int max_spins = (*p.gave_up != 0) ? 64 : PAIR_SPINS;
+  for (int spin = 0; spin < max_spins && !done; ++spin) {
     bool all = true;
     pair_sweep8(p.gran + (size_t)e * 1024 + lane * 2, g);
 #pragma unroll
