@@ -613,7 +613,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"English-830M-shape zero-shot TTS decode, cfg_stride=5, top_k=40/top_p=0.8 sampling, batch={U} ({2 * U} CFG rows) per GPU; "
                                    f"L={L} phonemes, {N}-frame prompt, context {L + T0 + a.warmup}..{L + T0 + total}",
-                       "utterances_per_gpu": U, "rows": 2 * U, "graph": not a.no_graph, "steps_completed": int(st.n_steps)},
+                       "utterances_per_gpu": U, "rows": 2 * U, "graph": not a.no_graph, "steps_completed": int(st.n_steps),
+                       "pair_launches": bool(eng.pairing), "pair_launches_why": eng.pairing_why},
             "per_gpu_value": round(value / world, 1),
             "decode_rtf_10s": round((500 * ms_per_step / 1000) / 10.0, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -643,6 +644,7 @@ def main():
     # ---- extras (every rank takes part: dp64 ends in a collective). None of them feeds `value`.
     extras = {}
     if not a.no_extras and U == 1:
+        eng.close()                              # gives the device's pairing slot back (csrc/engine.hip): the API model's engine takes it next
         del eng
         torch.cuda.empty_cache()
         import tempfile

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSRHIP_VERSION 105
+#define SSRHIP_VERSION 106
 #define SSRHIP_PAGE 128          /* KV-cache page = 128 positions */
 #define SSRHIP_MAX_CODEBOOKS 4
 #define SSRHIP_MAX_SILENCE 8
@@ -112,8 +112,11 @@ int ssrhip_gemv(const ssrhip_gemv_args* a, ssrhip_stream_t stream);
  *   ws: SSRHIP_PAIR_WS_BYTES of device memory, zeroed once by the caller and then owned by the chain of pair launches: three granule
  *   buffers + the give-up flag. `buf` is the buffer this launch uses, `buf_next` (!= buf) the one the NEXT pair launch on this workspace
  *   will use — this launch resets it. Consecutive pair launches must therefore follow each other's buf_next, cyclically.
- *   The launch needs its 256 workgroups resident together; a workgroup that waits longer than ~1 s for the others gives up, sets the
- *   flag and the outputs are garbage: ssrhip_gemv_pair_status (synchronises `stream`) returns 1 from then on. */
+ *   The launch needs its 256 workgroups resident together (ssrhip_gemv_pair_applicable also asks the occupancy calculator that each pair
+ *   kernel fits a CU and refuses when a CU mask is set in the environment); a workgroup that waits longer than ~1 s for the others
+ *   gives up, sets the flag and the outputs are garbage: ssrhip_gemv_pair_status (synchronises `stream`) returns 1 ONCE and re-zeroes the
+ *   workspace (tags and flag), so the chain can be started again from its first launch. Who may pair at all on a device is decided one
+ *   level up, per decode engine: ssrhip_lm_create below. */
 #define SSRHIP_PAIR_WS_BYTES (3 * 4096 * 8 + 64)
 int ssrhip_pair_buffer(int32_t i, int32_t n);   /* granule buffer (0..2) of the i-th of n cyclically consecutive pair launches; -1: bad i / n < 2 */
 int ssrhip_gemv_pair_applicable(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b);
@@ -383,6 +386,8 @@ typedef struct ssrhip_lm_dims {
 
 typedef struct ssrhip_lm_buffers {      /* caller-allocated device workspaces */
   int32_t B, n_utt, max_splits;
+  int32_t pair_mode;   /* 2-row engines: 0 = pair launches if this engine may hold the device's pairing slot (ssrhip_lm_create), 1 = never,
+                          2 = always (tests of the give-up path: no slot taken, no guard) */
   float* x;        /* [B][D] residual stream */
   float* q;        /* [B][D] */
   float* h;        /* [B][max(d_ffn, K*Hh)] */
@@ -397,7 +402,16 @@ typedef struct ssrhip_lm_buffers {      /* caller-allocated device workspaces */
 
 typedef struct ssrhip_lm ssrhip_lm;     /* opaque host-side object (graph + launch descriptors) */
 
+/* A 2-row engine (one utterance x CFG) runs its step with pair launches (ssrhip_gemv_pair) only while it holds the PAIRING SLOT of its
+ * device: two pair chains on one GPU can starve each other of CUs (each launch spins until all 256 of its workgroups are resident).
+ * The slot is taken here and given back by ssrhip_lm_destroy: at most one live engine per process and device (a table in the library)
+ * and at most one process per device (an exclusive flock on /dev/shm/ssrhip_pair_<pci bus id>.lock, released by the kernel when the
+ * process dies). An engine that does not get the slot — or finds a CU mask in the environment, fewer than 256 CUs, a pair kernel that
+ * does not fit a CU, SSRHIP_GEMV_PAIR=0, pair_mode 1 — steps with the ordinary launches (same tokens, bit for bit) and says why once
+ * on stderr; ssrhip_lm_pairing reports it. */
 int ssrhip_lm_create(const ssrhip_lm_dims* d, const ssrhip_lm_weights* w, const ssrhip_lm_buffers* b, ssrhip_lm** out);
+/* 1 = this engine's decode step uses pair launches, 0 = it does not; `why` (may be NULL) receives the reason as text */
+int ssrhip_lm_pairing(const ssrhip_lm* lm, char* why, int32_t why_len);
 void ssrhip_lm_destroy(ssrhip_lm* lm);
 /* enqueue `n_steps` decode steps (graph replays when use_graph!=0) */
 int ssrhip_lm_decode(ssrhip_lm* lm, int32_t n_steps, int32_t use_graph, ssrhip_stream_t stream);
@@ -421,17 +435,23 @@ int ssrhip_lm_prefill(ssrhip_lm* lm, const ssrhip_prefill_args* p, ssrhip_stream
 /* x[b] = embedding of row b's pending input token (next_tok / next_pos) for EVERY row of the engine — the closing step of ssrhip_lm_prefill
  * on its own (rows in mid-decode get exactly what the sampler's fused embedding left there: same function, same inputs). */
 int ssrhip_lm_embed_pending(ssrhip_lm* lm, ssrhip_stream_t stream);
-/* 0 = fine, 1 = a paired GEMV launch of this engine's decode step gave up waiting (ssrhip_gemv_pair): every token since is invalid;
- * synchronises `stream`. Engines that do not pair (B != 2) always return 0. */
+/* 0 = fine, 1 = a paired GEMV launch of this engine's decode step gave up waiting (ssrhip_gemv_pair): every token since the last call
+ * that returned 0 is invalid and so are the KV cache and the residual stream of the rows in flight; reported ONCE (the workspace is
+ * re-zeroed: after a new prefill the engine decodes correctly again). Synchronises `stream`. Engines that do not pair always return 0
+ * without touching the stream. */
 int ssrhip_lm_pair_status(ssrhip_lm* lm, ssrhip_stream_t stream);
 
+/* Test hook (tests/test_gpu_lm.py: the pair launches' give-up path): `n_wg` workgroups that each hold `lds_bytes` of LDS (<= 160 KB) and
+ * spin for `ms` milliseconds of the constant 100 MHz clock — a foreign kernel that keeps CUs away from everybody else. */
+int ssrhip_debug_occupy(int32_t n_wg, int32_t lds_bytes, float ms, ssrhip_stream_t stream);
+
 /* run `n_steps` eager decode steps with a hipEvent pair around EVERY kernel launch (bench.py roofline).
- * out_us[i] = average microseconds of launch slot i of a step, out_kind[i] = 0 gemv | 1 attention | 2 sampler | 3 fused attention + out-proj;
+ * out_us[i] = average microseconds of launch slot i of a step, out_kind[i] = 0 gemv | 1 attention | 2 sampler;
  * returns the number of slots (<= n_out) or a negative error. */
 int ssrhip_lm_time_steps(ssrhip_lm* lm, int32_t n_steps, ssrhip_stream_t stream, float* out_us, int32_t* out_kind, int32_t n_out);
 
 /* Launch duration of ONE kernel category inside a decode step, measured the way the product runs it: the launches of
- * `category` (0 gemv | 1 attention | 2 sampler | 3 fused attention + out-projection) of one step are captured into a hipGraph (the others are left out), the
+ * `category` (0 gemv | 1 attention | 2 sampler) of one step are captured into a hipGraph (the others are left out), the
  * graph is replayed `n_replays` times between one hipEvent pair on `stream`, and the elapsed time is divided by the number
  * of launches. No per-launch event overhead, so the figure agrees with rocprofv3's kernel durations (+ the ~0.1 us
  * in-graph gap). The decode state is NOT advanced and the hidden-state buffers are left with garbage: call

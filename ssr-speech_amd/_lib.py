@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libssrhip.so")
 
+ABI_VERSION = 106          # include/ssrhip.h SSRHIP_VERSION
 PAGE = 128
 MAX_CODEBOOKS = 4
 MAX_SILENCE = 8
@@ -133,7 +134,7 @@ class LMDims(C.Structure):
 
 
 class LMBuffers(C.Structure):
-    _fields_ = [("B", C.c_int32), ("n_utt", C.c_int32), ("max_splits", C.c_int32),
+    _fields_ = [("B", C.c_int32), ("n_utt", C.c_int32), ("max_splits", C.c_int32), ("pair_mode", C.c_int32),
                 ("x", C.c_void_p), ("q", C.c_void_p), ("h", C.c_void_p), ("logits", C.c_void_p),
                 ("part_o", C.c_void_p), ("part_ml", C.c_void_p),
                 ("next_tok", C.c_void_p), ("next_pos", C.c_void_p), ("kv_pos", C.c_void_p), ("row_len", C.c_void_p),
@@ -184,7 +185,9 @@ SYMBOLS = [
     ("ssrhip_lm_decode", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("ssrhip_lm_prefill", C.c_int, [C.c_void_p, C.POINTER(PrefillArgs), C.c_void_p]),
     ("ssrhip_lm_embed_pending", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("ssrhip_lm_pairing", C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     ("ssrhip_lm_pair_status", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("ssrhip_debug_occupy", C.c_int, [C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     ("ssrhip_lm_time_steps", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, c_f32p, c_i32p, C.c_int32]),
     ("ssrhip_lm_time_category", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, c_f32p, c_i32p]),
 ]
@@ -222,6 +225,8 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    if L.ssrhip_version() != ABI_VERSION:
+        raise SsrHipUnavailable(f"{LIB_PATH} has ABI {L.ssrhip_version()}, this package was written against {ABI_VERSION}: rebuild it (make -C {CSRC})")
     for i, st in enumerate(ABI_STRUCTS):
         if L.ssrhip_sizeof(i) != C.sizeof(st):
             raise SsrHipUnavailable(f"ABI mismatch: sizeof({st.__name__}) = {C.sizeof(st)} but the library says {L.ssrhip_sizeof(i)}")

@@ -7,6 +7,7 @@
 #define SSR_WAVE 64
 
 void ssrhip_set_error(const char* fmt, ...);
+const char* ssrhip_gemv_pair_why();      // gemv.hip: why the last pair-applicability question on this thread was answered with no
 
 #define SSR_REQUIRE(cond, ...)            \
   do {                                    \

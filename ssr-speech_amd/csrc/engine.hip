@@ -13,6 +13,12 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <mutex>
 #include <vector>
 #include "common.h"
 
@@ -56,11 +62,70 @@ struct ssrhip_lm {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   void* pair_ws = nullptr;      // granules of the paired GEMV launches (2-row step; SSRHIP_PAIR_WS_BYTES, owned)
+  int pair_dev = -1;            // >= 0: this engine holds the pairing slot of that device (released in ssrhip_lm_destroy)
+  char pair_why[200] = "";      // why the step pairs / does not pair (ssrhip_lm_pairing)
 };
 
 namespace {
 
 enum { CAT_GEMV = 0, CAT_ATTN = 1, CAT_SAMPLE = 2 };
+
+// ---- the pairing slot: ONE chain of pair launches per device (include/ssrhip.h ssrhip_lm_create). A pair launch spins until its 256
+// workgroups are resident together; two such chains at once (two engines on two streams, two processes) can each hold half the CUs and
+// wait for the other half — bounded (~1 s), flagged, but garbage. So the right to pair is a resource: a per-process table (one live
+// engine per device) plus an exclusive flock on a file named after the GPU's PCI address (one process per device; the kernel drops the
+// lock when the process dies, however it dies).
+constexpr int PAIR_MAX_DEV = 64;
+std::mutex g_pair_mu;
+struct PairSlot { int live = 0; int fd = -1; };
+PairSlot g_pair_slot[PAIR_MAX_DEV];
+
+// true: slot taken (give it back with pair_slot_release); false: `why` says who has it / what went wrong
+bool pair_slot_acquire(int dev, char* why, size_t why_len) {
+  std::lock_guard<std::mutex> lk(g_pair_mu);
+  if (dev < 0 || dev >= PAIR_MAX_DEV) { snprintf(why, why_len, "device index %d outside the pairing table", dev); return false; }
+  PairSlot& sl = g_pair_slot[dev];
+  if (sl.live > 0) { snprintf(why, why_len, "another decode engine of this process already runs pair launches on device %d", dev); return false; }
+  char bus[64] = "";
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) != hipSuccess || !bus[0]) snprintf(bus, sizeof(bus), "dev%d", dev);
+  for (char* c = bus; *c; ++c) if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+  const char* dirs[2] = {"/dev/shm", "/tmp"};
+  int fd = -1;
+  char path[160] = "";
+  for (int i = 0; i < 2 && fd < 0; ++i) {
+    snprintf(path, sizeof(path), "%s/ssrhip_pair_%s.lock", dirs[i], bus);
+    fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+    if (fd >= 0) fchmod(fd, 0666);                                  // the next user's process must be able to open it too (umask)
+    else fd = open(path, O_RDONLY | O_CLOEXEC);                     // someone else's file: a shared descriptor is enough for flock
+  }
+  if (fd < 0) { snprintf(why, why_len, "cannot create the pair-launch lock file (%s: %s)", path, strerror(errno)); return false; }
+  if (flock(fd, LOCK_EX | LOCK_NB) != 0) {
+    snprintf(why, why_len, "another process holds the pair-launch lock of this GPU (%s)", path);
+    close(fd);
+    return false;
+  }
+  sl.fd = fd;
+  sl.live = 1;
+  return true;
+}
+
+void pair_slot_release(int dev) {
+  std::lock_guard<std::mutex> lk(g_pair_mu);
+  if (dev < 0 || dev >= PAIR_MAX_DEV) return;
+  PairSlot& sl = g_pair_slot[dev];
+  if (sl.live > 0) sl.live = 0;
+  if (sl.fd >= 0) { flock(sl.fd, LOCK_UN); close(sl.fd); sl.fd = -1; }
+}
+
+__global__ void occupy_kernel(long long ticks, int lds_floats) {
+  extern __shared__ float occ[];
+  for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) occ[i] = (float)i;
+  __syncthreads();
+  const long long t0 = wall_clock64();
+  float acc = 0.f;
+  while (wall_clock64() - t0 < ticks) { acc += occ[(threadIdx.x * 7) % (lds_floats > 0 ? lds_floats : 1)]; __builtin_amdgcn_s_sleep(32); }
+  if (acc == -1.f) occ[0] = acc;
+}
 
 bool getenv_flag(const char* name) {      // tuning / A-B knobs, read once per process
   const char* e = getenv(name);
@@ -96,17 +161,18 @@ struct Timer {   // optional per-launch event timing: one accumulator per launch
     }                                                           \
   } while (0)
 
-int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
-  const ssrhip_lm_dims& d = lm->d;
-  const ssrhip_lm_weights& w = lm->w;
-  const ssrhip_lm_buffers& b = lm->b;
-  const int D = d.d_model, B = b.B, K = d.n_codebooks, Hh = d.head_hidden;
-  // 5..16 rows: the residual stream x, the combined attention output and the hidden h live in the 16-column tiled layout
-  // (include/ssrhip.h SSRHIP_TILED) so that the matrix-core GEMV's operand loads are contiguous KiBs
-  const int tiled = B > 4 ? 1 : 0;
-  const bool wt = tiled && w.in_proj_wt;      // streaming-order weight copies for the matrix-core GEMV (include/ssrhip.h w_tiled)
-
-  auto qkv_args = [&](int l) {
+// Launch descriptors of the five GEMVs of a decode step (shared by enqueue_step and by ssrhip_lm_create's "would this engine pair?")
+struct StepShapes {
+  const ssrhip_lm_dims& d;
+  const ssrhip_lm_weights& w;
+  const ssrhip_lm_buffers& b;
+  const int D, B, K, Hh;
+  const int tiled;     // 5..16 rows: x, the combined attention output and h live in the 16-column tiled layout (SSRHIP_TILED)
+  const bool wt;       // streaming-order weight copies for the matrix-core GEMV (include/ssrhip.h w_tiled)
+  explicit StepShapes(const ssrhip_lm* lm)
+      : d(lm->d), w(lm->w), b(lm->b), D(lm->d.d_model), B(lm->b.B), K(lm->d.n_codebooks), Hh(lm->d.head_hidden), tiled(lm->b.B > 4 ? 1 : 0),
+        wt(lm->b.B > 4 && lm->w.in_proj_wt) {}
+  ssrhip_gemv_args qkv_args(int l) const {
     ssrhip_gemv_args g;
     // LN1 + packed QKV projection, q -> b.q, k/v appended in place into the paged cache
     memset(&g, 0, sizeof(g));
@@ -119,8 +185,8 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.x_tiled = tiled;                         // q stays row-major for the attention kernel
     if (wt) { g.W = w.in_proj_wt[l]; g.w_tiled = 1; }
     return g;
-  };
-  auto head1_args = [&]() {
+  }
+  ssrhip_gemv_args head1_args() const {
     ssrhip_gemv_args g;
     // final LayerNorm + first Linear of the K prediction heads (stacked) + GELU
     memset(&g, 0, sizeof(g));
@@ -132,8 +198,8 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.x_tiled = tiled; g.y_tiled = tiled;
     if (wt) { g.W = w.head1_wt; g.w_tiled = 1; }
     return g;
-  };
-  auto outproj_args = [&](int l) {               // the <= 4-row form: split-KV merge prologue + out-proj + residual
+  }
+  ssrhip_gemv_args outproj_args(int l) const {               // the <= 4-row form: split-KV merge prologue + out-proj + residual
     ssrhip_gemv_args g;
     memset(&g, 0, sizeof(g));
     g.W = w.out_proj_w[l]; g.bias = w.out_proj_b[l]; g.x = nullptr; g.y = b.x;
@@ -142,8 +208,8 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.part_o = b.part_o; g.part_ml = b.part_ml; g.max_splits = b.max_splits; g.row_len = b.row_len;
     g.kv = b.kv;
     return g;
-  };
-  auto ffn1_args = [&](int l) {
+  }
+  ssrhip_gemv_args ffn1_args(int l) const {
     ssrhip_gemv_args g;
     // LN2 + FFN1 + ReLU
     memset(&g, 0, sizeof(g));
@@ -155,8 +221,8 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.x_tiled = tiled; g.y_tiled = tiled;
     if (wt) { g.W = w.ffn1_wt[l]; g.w_tiled = 1; }
     return g;
-  };
-  auto ffn2_args = [&](int l) {
+  }
+  ssrhip_gemv_args ffn2_args(int l) const {
     ssrhip_gemv_args g;
     memset(&g, 0, sizeof(g));
     g.W = w.ffn2_w[l]; g.bias = w.ffn2_b[l]; g.x = b.h; g.y = b.x;
@@ -165,22 +231,43 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     g.x_tiled = tiled; g.y_tiled = tiled;
     if (wt) { g.W = w.ffn2_wt[l]; g.w_tiled = 1; }
     return g;
-  };
+  }
+  // which launches of the 2-row step qualify for the pair forms, and how many pair launches a step then has (0: fewer than 2 -> none)
+  int pair_plan(bool* qkv, bool* head, bool* ffn1) const {
+    *qkv = *head = *ffn1 = false;
+    if (B != 2) return 0;
+    const ssrhip_gemv_args fa = ffn2_args(0);
+    if (d.n_layer > 1) { const ssrhip_gemv_args qa = qkv_args(1); *qkv = ssrhip_gemv_pair_applicable(&fa, &qa) != 0; }
+    { const ssrhip_gemv_args ha = head1_args(); *head = ssrhip_gemv_pair_applicable(&fa, &ha) != 0; }
+    { const ssrhip_gemv_args oa = outproj_args(0), f1 = ffn1_args(0); *ffn1 = ssrhip_gemv_pair_applicable(&oa, &f1) != 0; }
+    const int n = (*qkv ? d.n_layer - 1 : 0) + (*head ? 1 : 0) + (*ffn1 ? d.n_layer : 0);
+    if (n < 2) { *qkv = *head = *ffn1 = false; return 0; }
+    return n;
+  }
+};
+
+int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
+  const ssrhip_lm_dims& d = lm->d;
+  const ssrhip_lm_weights& w = lm->w;
+  const ssrhip_lm_buffers& b = lm->b;
+  const int D = d.d_model, B = b.B, K = d.n_codebooks, Hh = d.head_hidden;
+  // 5..16 rows: the residual stream x, the combined attention output and the hidden h live in the 16-column tiled layout
+  // (include/ssrhip.h SSRHIP_TILED) so that the matrix-core GEMV's operand loads are contiguous KiBs
+  const int tiled = B > 4 ? 1 : 0;
+  const bool wt = tiled && w.in_proj_wt;      // streaming-order weight copies for the matrix-core GEMV (include/ssrhip.h w_tiled)
+
+  const StepShapes sh(lm);
+  auto qkv_args = [&](int l) { return sh.qkv_args(l); };
+  auto head1_args = [&]() { return sh.head1_args(); };
+  auto ffn1_args = [&](int l) { return sh.ffn1_args(l); };
+  auto ffn2_args = [&](int l) { return sh.ffn2_args(l); };
   // 2-row step: FFN2 of layer l and the launch that consumes its output (QKV of layer l + 1; the head MLP after the last layer) run as ONE
   // launch with the all-to-all edge inside it (csrc/gemv.hip gemv_pair_kernel), and so do the out-projection (with its split-KV merge
   // prologue) and FFN1 (gemv_pair_merge_kernel): attention, pair, pair per layer. The pairs of a step use the three granule buffers of
   // lm->pair_ws cyclically: pair i uses buffer i % 3 and resets the buffer of pair (i + 1) % n — closed over the step, so that graph
   // replays (and eager steps) always find their buffer reset by the launch before them; with n % 3 == 1 the last pair takes buffer 1.
-  int n_pairs = 0;
   bool pair_qkv = false, pair_head = false, pair_ffn1 = false;
-  if (lm->pair_ws && B == 2) {
-    const ssrhip_gemv_args fa = ffn2_args(0);
-    if (d.n_layer > 1) { const ssrhip_gemv_args qa = qkv_args(1); pair_qkv = ssrhip_gemv_pair_applicable(&fa, &qa) != 0; }
-    { const ssrhip_gemv_args ha = head1_args(); pair_head = ssrhip_gemv_pair_applicable(&fa, &ha) != 0; }
-    { const ssrhip_gemv_args oa = outproj_args(0), f1 = ffn1_args(0); pair_ffn1 = ssrhip_gemv_pair_applicable(&oa, &f1) != 0; }
-    n_pairs = (pair_qkv ? d.n_layer - 1 : 0) + (pair_head ? 1 : 0) + (pair_ffn1 ? d.n_layer : 0);
-    if (n_pairs < 2) { n_pairs = 0; pair_qkv = pair_head = pair_ffn1 = false; }
-  }
+  const int n_pairs = lm->pair_ws ? sh.pair_plan(&pair_qkv, &pair_head, &pair_ffn1) : 0;
   auto pair_buf = [&](int i) { return ssrhip_pair_buffer(i, n_pairs); };
   int pair_i = 0;
   bool qkv_done = false;                        // this layer's QKV already ran inside the previous layer's pair launch
@@ -331,16 +418,48 @@ extern "C" int ssrhip_lm_create(const ssrhip_lm_dims* d, const ssrhip_lm_weights
     }
   }
   { const char* e = getenv("SSRHIP_PREFILL_SPLIT"); lm->prefill_split = has_ws && !(e && e[0] == '0'); }
-  if (b->B == 2) {                              // granules + give-up flag of the paired GEMV launches (zeroed: every tag invalid)
-    if (hipMalloc(&lm->pair_ws, SSRHIP_PAIR_WS_BYTES) != hipSuccess || hipMemset(lm->pair_ws, 0, SSRHIP_PAIR_WS_BYTES) != hipSuccess) {
-      if (lm->pair_ws) hipFree(lm->pair_ws);
-      delete lm;
-      ssrhip_set_error("ssrhip_lm_create: allocating the pair workspace failed");
-      return -1;
+  if (b->B != 2) {
+    snprintf(lm->pair_why, sizeof(lm->pair_why), "pair launches exist for the 2-row step only (this engine has %d rows)", b->B);
+  } else {
+    // does the 2-row step pair at all (shapes, CU count, occupancy, CU mask, SSRHIP_GEMV_PAIR), and may THIS engine do it?
+    bool want = b->pair_mode != 1;
+    bool loud = false;                                              // a refusal the user did not ask for: say it once on stderr
+    if (!want) snprintf(lm->pair_why, sizeof(lm->pair_why), "switched off by the caller (pair_mode 1)");
+    if (want) {
+      bool pq, ph, pf;
+      if (StepShapes(lm).pair_plan(&pq, &ph, &pf) == 0) {
+        want = false;
+        snprintf(lm->pair_why, sizeof(lm->pair_why), "%s", ssrhip_gemv_pair_why());
+      }
+    }
+    if (want && b->pair_mode != 2) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+      if (pair_slot_acquire(dev, lm->pair_why, sizeof(lm->pair_why))) lm->pair_dev = dev;
+      else { want = false; loud = true; }
+    }
+    if (want) {                                   // granules + give-up flag of the paired GEMV launches (zeroed: every tag invalid)
+      if (hipMalloc(&lm->pair_ws, SSRHIP_PAIR_WS_BYTES) != hipSuccess || hipMemset(lm->pair_ws, 0, SSRHIP_PAIR_WS_BYTES) != hipSuccess) {
+        if (lm->pair_ws) hipFree(lm->pair_ws);
+        if (lm->pair_dev >= 0) pair_slot_release(lm->pair_dev);
+        delete lm;
+        ssrhip_set_error("ssrhip_lm_create: allocating the pair workspace failed");
+        return -1;
+      }
+      snprintf(lm->pair_why, sizeof(lm->pair_why), b->pair_mode == 2 ? "forced on by the caller (pair_mode 2: no slot, no guard)"
+                                                                     : "this engine holds the pairing slot of its device");
+    } else if (loud) {
+      fprintf(stderr, "ssrhip: this 2-row decode engine steps WITHOUT pair launches (same tokens, ~5 %% slower): %s\n", lm->pair_why);
     }
   }
   *out = lm;
   return 0;
+}
+
+extern "C" int ssrhip_lm_pairing(const ssrhip_lm* lm, char* why, int32_t why_len) {
+  if (!lm) return 0;
+  if (why && why_len > 0) snprintf(why, (size_t)why_len, "%s", lm->pair_why);
+  return lm->pair_ws ? 1 : 0;
 }
 
 extern "C" int ssrhip_lm_pair_status(ssrhip_lm* lm, ssrhip_stream_t stream) {
@@ -349,12 +468,22 @@ extern "C" int ssrhip_lm_pair_status(ssrhip_lm* lm, ssrhip_stream_t stream) {
   return ssrhip_gemv_pair_status(lm->pair_ws, stream);
 }
 
+extern "C" int ssrhip_debug_occupy(int32_t n_wg, int32_t lds_bytes, float ms, ssrhip_stream_t stream) {
+  SSR_REQUIRE(n_wg > 0 && n_wg <= 65535 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && ms >= 0.f && ms <= 20000.f, "ssrhip_debug_occupy: bad argument");
+  if (lds_bytes > 64 * 1024)
+    SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  hipLaunchKernelGGL(occupy_kernel, dim3(n_wg), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, (long long)(ms * 100000.0f), lds_bytes / 4);
+  SSR_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" void ssrhip_lm_destroy(ssrhip_lm* lm) {
   if (!lm) return;
   if (lm->exec) hipGraphExecDestroy(lm->exec);
   if (lm->graph) hipGraphDestroy(lm->graph);
   if (lm->cap_stream) hipStreamDestroy(lm->cap_stream);
   if (lm->pair_ws) hipFree(lm->pair_ws);
+  if (lm->pair_dev >= 0) pair_slot_release(lm->pair_dev);
   delete lm;
 }
 

@@ -1377,33 +1377,65 @@ extern "C" void ssrhip_debug_gemv_prof(void* dev_ptr) { g_gemv_prof = (long long
 
 // Units per wave of B if (a, b) can run as one pair launch, 0 otherwise; *merge = A is the out-projection with the split-KV merge prologue
 // SSRHIP_GEMV_PAIR (read at every call: A/B inside one process): 0 = never, 1 = only FFN2 -> {QKV, head MLP}, unset / other = both forms
+static thread_local char g_pair_why[200] = "";
+const char* ssrhip_gemv_pair_why() { return g_pair_why; }          // why the last pair_nuwb on this thread said no (engine.hip reports it)
+
+// Can a pair kernel keep 256 workgroups resident on THIS device at all? (the CU count alone ignores CU masks and occupancy.)
+// Asked once per process: the occupancy calculator must place at least one workgroup of every pair instantiation on a CU (12 waves,
+// their registers and LDS), the device must report >= 256 CUs and no CU mask may be set in the environment (the attribute counts
+// masked CUs too). Partition modes show up in the CU count.
+static const char* pair_device_refusal(int num_cu) {
+  static const char* verdict = nullptr;
+  static bool asked = false;
+  if (asked) return verdict;
+  asked = true;
+  static char buf[200];
+  if (num_cu < 256) { snprintf(buf, sizeof(buf), "the device reports %d CUs (a pair launch needs its 256 workgroups resident together)", num_cu); return verdict = buf; }
+  for (const char* name : {"ROC_GLOBAL_CU_MASK", "HSA_CU_MASK", "HSA_CU_MASK_SKIP_INIT"}) {
+    const char* e = getenv(name);
+    if (e && e[0]) { snprintf(buf, sizeof(buf), "%s is set: fewer CUs than the device reports may be usable", name); return verdict = buf; }
+  }
+  int nb[4] = {0, 0, 0, 0};
+  hipError_t e0 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[0], gemv_pair_kernel<4>, PAIR_TH, 0);
+  hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[1], gemv_pair_kernel<6>, PAIR_TH, 0);
+  hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[2], gemv_pair_kernel<8>, PAIR_TH, 0);
+  hipError_t e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[3], gemv_pair_merge_kernel<8>, PAIR_TH, 16 * 1024);
+  if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || nb[0] < 1 || nb[1] < 1 || nb[2] < 1 || nb[3] < 1) {
+    snprintf(buf, sizeof(buf), "the occupancy calculator places %d / %d / %d / %d workgroups of the pair kernels on a CU (need >= 1 each)", nb[0], nb[1], nb[2], nb[3]);
+    return verdict = buf;
+  }
+  return verdict = nullptr;
+}
+
 static int pair_nuwb(const ssrhip_gemv_args* a, const ssrhip_gemv_args* b, int num_cu, bool* merge) {
   *merge = false;
-  if (num_cu < 256) return 0;                                       // 256 workgroups must be resident together
-  if (a->B != 2 || b->B != 2 || a->groups != 1 || b->groups != 1) return 0;
-  if (a->x_tiled || a->y_tiled || a->w_tiled || b->x_tiled || b->y_tiled || b->w_tiled) return 0;
-  if (a->act != SSRHIP_ACT_NONE || a->epi != SSRHIP_EPI_RESIDUAL || a->N != PAIR_D || !a->y || !a->W) return 0;
+  auto no = [](const char* why) { snprintf(g_pair_why, sizeof(g_pair_why), "%s", why); return 0; };
   int mode = 2;
   if (const char* e = getenv("SSRHIP_GEMV_PAIR")) mode = (e[0] == '0') ? 0 : (e[0] == '1') ? 1 : 2;
-  if (mode == 0) return 0;
+  if (mode == 0) return no("SSRHIP_GEMV_PAIR=0");
+  if (const char* why = pair_device_refusal(num_cu)) return no(why);
+  if (a->B != 2 || b->B != 2 || a->groups != 1 || b->groups != 1) return no("not a 2-row, single-group launch");
+  if (a->x_tiled || a->y_tiled || a->w_tiled || b->x_tiled || b->y_tiled || b->w_tiled) return no("tiled layouts");
+  if (a->act != SSRHIP_ACT_NONE || a->epi != SSRHIP_EPI_RESIDUAL || a->N != PAIR_D || !a->y || !a->W) return no("the first launch is not a residual GEMV with N = 2048 (the pair kernels are built for d_model 2048)");
   if (a->pro == SSRHIP_PRO_NONE) {
-    if (a->K != 8192 || !a->x) return 0;
+    if (a->K != 8192 || !a->x) return no("FFN2 form needs K = 8192");
   } else if (a->pro == SSRHIP_PRO_ATTN_COMBINE) {
-    if (mode < 2) return 0;
+    if (mode < 2) return no("SSRHIP_GEMV_PAIR=1: the merge form is off");
     const int hd = a->kv.head_dim;
-    if (a->K != 2048 || !a->part_o || !a->part_ml || !a->row_len || a->max_splits < 1 || hd <= 0 || hd % 4 != 0 || a->K % hd != 0 || 2 * (a->K / hd) > SEG_TH) return 0;
-    if ((size_t)2 * (a->K / hd) * a->max_splits * sizeof(float) > 16 * 1024) return 0;   // merge weights in LDS next to the 17 KB of static buffers
+    if (a->K != 2048 || !a->part_o || !a->part_ml || !a->row_len || a->max_splits < 1 || hd <= 0 || hd % 4 != 0 || a->K % hd != 0 || 2 * (a->K / hd) > SEG_TH) return no("merge form needs K = 2048 and split-KV partials");
+    if ((size_t)2 * (a->K / hd) * a->max_splits * sizeof(float) > 16 * 1024) return no("merge weights exceed 16 KB of LDS (context too long for the merge form)");   // merge weights in LDS next to the 17 KB of static buffers
     *merge = true;
   } else {
-    return 0;
+    return no("the first launch has a LayerNorm prologue");
   }
-  if (b->pro != SSRHIP_PRO_LAYERNORM || b->ln_w || b->ln_b || b->K != PAIR_D || b->x != a->y || b->x_stride != a->y_stride || !b->W || !b->y) return 0;
-  if (b->epi != SSRHIP_EPI_STORE && b->epi != SSRHIP_EPI_QKV_APPEND) return 0;
-  if (b->epi == SSRHIP_EPI_QKV_APPEND && !(b->N == 3 * b->K && b->kv.pool && b->kv.table && b->kv_pos && b->kv.head_dim > 0)) return 0;
-  if (b->N % 256 != 0) return 0;
+  if (b->pro != SSRHIP_PRO_LAYERNORM || b->ln_w || b->ln_b || b->K != PAIR_D || b->x != a->y || b->x_stride != a->y_stride || !b->W || !b->y) return no("the second launch is not LayerNorm (folded) + Linear on the first one's output");
+  if (b->epi != SSRHIP_EPI_STORE && b->epi != SSRHIP_EPI_QKV_APPEND) return no("second launch: epilogue");
+  if (b->epi == SSRHIP_EPI_QKV_APPEND && !(b->N == 3 * b->K && b->kv.pool && b->kv.table && b->kv_pos && b->kv.head_dim > 0)) return no("second launch: QKV append without a cache");
+  if (b->N % 256 != 0) return no("second launch: N not a multiple of 256");
   const int nuwb = (b->N / 256) * 2 / SEG_NW;
-  if ((b->N / 256) * 2 % SEG_NW != 0 || (nuwb != 4 && nuwb != 6 && nuwb != 8)) return 0;
-  if (*merge && nuwb != 8) return 0;                                // the merge form is instantiated for FFN1 only
+  if ((b->N / 256) * 2 % SEG_NW != 0 || (nuwb != 4 && nuwb != 6 && nuwb != 8)) return no("second launch: N not in {4096, 6144, 8192}");
+  if (*merge && nuwb != 8) return no("the merge form is instantiated for FFN1 only");                                // the merge form is instantiated for FFN1 only
+  g_pair_why[0] = 0;
   return nuwb;
 }
 
@@ -1467,6 +1499,11 @@ extern "C" int ssrhip_gemv_pair_status(const void* ws, ssrhip_stream_t stream) {
   if (hipMemcpy(&flag, (const char*)ws + 3 * (size_t)PAIR_GRAN * 8, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
     ssrhip_set_error("ssrhip_gemv_pair_status: copy failed");
     return -1;
+  }
+  if (flag) {
+    // reported once; tags and flag back to "nothing published" so that a chain restarted from its first launch (after a new prefill) is
+    // valid again (the stream is idle: it was synchronised above)
+    if (hipMemset(const_cast<void*>(ws), 0, SSRHIP_PAIR_WS_BYTES) != hipSuccess) { ssrhip_set_error("ssrhip_gemv_pair_status: re-zeroing the workspace failed"); return -1; }
   }
   return flag ? 1 : 0;
 }

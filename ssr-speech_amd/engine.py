@@ -312,10 +312,11 @@ class DecodeEngine:
     """B rows (= n_utt x (2 if CFG else 1)) decoded in lock-step; one captured hipGraph per engine."""
 
     def __init__(self, arena: LMWeightsArena, n_utt: int, use_cfg: bool, max_seq: int, max_steps: int, debug_logits: bool = False,
-                 pool_pages: Optional[int] = None, page_order: Optional[Sequence[int]] = None):
+                 pool_pages: Optional[int] = None, page_order: Optional[Sequence[int]] = None, pair_mode: int = 0):
         """max_seq: longest sequence (text + audio positions) any ONE row may reach; pool_pages: physical KV pages shared by all
         rows (default rows x pages-per-row, the no-sharing worst case; a batch of short and long utterances needs only the sum
-        of their own page counts)."""
+        of their own page counts). pair_mode (2-row engines; include/ssrhip.h ssrhip_lm_buffers): 0 = pair launches if this engine
+        gets its device's pairing slot, 1 = never, 2 = always (tests of the give-up path)."""
         self.lib = _lib.lib()
         self.a = arena
         dev = arena.device
@@ -384,6 +385,9 @@ class DecodeEngine:
         self.dbg_logits = torch.zeros(n_utt, K, arena.card, **f32) if debug_logits else None
         self._w = arena.c_struct()
         self._ctx = None
+        self.pair_mode = int(pair_mode)
+        self.pairing = False                      # set by _create_ctx: does this engine's step run the pair launches?
+        self.pairing_why = ""
 
     # ------------------------------------------------------------------ C structs
     def kv_struct(self):
@@ -394,7 +398,7 @@ class DecodeEngine:
             self.lib.ssrhip_lm_destroy(self._ctx)
             self._ctx = None
         b = _lib.LMBuffers()
-        b.B, b.n_utt, b.max_splits = self.B, self.n_utt, self.max_pages
+        b.B, b.n_utt, b.max_splits, b.pair_mode = self.B, self.n_utt, self.max_pages, self.pair_mode
         b.x, b.q, b.h, b.logits = self.x.data_ptr(), self.q.data_ptr(), self.h.data_ptr(), self.logits.data_ptr()
         b.part_o, b.part_ml = self.part_o.data_ptr(), self.part_ml.data_ptr()
         b.next_tok, b.next_pos = self.next_tok.data_ptr(), self.next_pos.data_ptr()
@@ -408,6 +412,9 @@ class DecodeEngine:
         ctx = C.c_void_p()
         _lib.check(self.lib.ssrhip_lm_create(C.byref(d), C.byref(self._w), C.byref(b), C.byref(ctx)), "ssrhip_lm_create")
         self._ctx = ctx
+        why = C.create_string_buffer(256)
+        self.pairing = bool(self.lib.ssrhip_lm_pairing(ctx, why, 256))
+        self.pairing_why = why.value.decode(errors="replace")
 
     def close(self):
         if self._ctx is not None:
@@ -734,17 +741,34 @@ class DecodeEngine:
         self._grow_pages(self._steps_enqueued)
         _lib.check(self.lib.ssrhip_lm_decode(self._ctx, int(n_steps), int(use_graph), _lib.stream_ptr()), "ssrhip_lm_decode")
 
-    def states(self) -> List[_lib.SamplerState]:
-        raw = bytes(self.state_dev.cpu().numpy().tobytes())
-        # the 2-row step pairs FFN2 with the next launch inside one kernel (csrc/gemv.hip gemv_pair_kernel); a workgroup of such a launch that
-        # waited ~1 s for the others (a second decode chain holding half the GPU at the same moment) gives up and flags it: nothing since is valid
+    def check_pairs(self) -> None:
+        """Raise if a pair launch of this engine's step gave up (csrc/gemv.hip gemv_pair_kernel: a workgroup that waited ~1 s for the other
+        255 — something else held CUs for that long — flags it and the step's results are garbage from there on). EVERY way a token
+        leaves the engine goes through here first (`states`, `tokens`). The library hands the pairing slot to one engine per device
+        (ssrhip_lm_create), so this needs a foreign kernel that squats on CUs; when it happens the engine recreates its context WITHOUT
+        pair launches — the utterances in flight are lost (their KV cache is garbage), the next `start` / `run_queue` is correct."""
+        if not self.pairing:
+            return
         rc = self.lib.ssrhip_lm_pair_status(self._ctx, _lib.stream_ptr())
         if rc == 1:
-            raise RuntimeError("a paired GEMV launch of the decode step gave up waiting for its other workgroups (is a second decode chain "
-                               "running on this GPU?): the tokens since the last poll are invalid. Run one chain per device or set SSRHIP_GEMV_PAIR=0.")
+            self.pair_mode = 1
+            self._create_ctx()                    # destroys the context (gives the slot back), new one steps with the ordinary launches
+            raise RuntimeError("a paired GEMV launch of the decode step gave up waiting for its other workgroups (another kernel held CUs "
+                               "for about a second): every token since the last poll is invalid and the utterances in flight must be "
+                               "submitted again. This engine now steps without pair launches (same tokens, ~5 % slower).")
         _lib.check(rc, "ssrhip_lm_pair_status")
+
+    def states(self) -> List[_lib.SamplerState]:
+        raw = bytes(self.state_dev.cpu().numpy().tobytes())
+        self.check_pairs()
         arr = (_lib.SamplerState * self.n_utt).from_buffer_copy(raw)
         return list(arr)
+
+    def tokens(self, u: int, n: int) -> np.ndarray:
+        """The first n generated steps of slot u as int64 [n, K] — after the pair-launch check (never read `generated` directly)."""
+        out = self.generated[u, :n].cpu().numpy().astype(np.int64)
+        self.check_pairs()
+        return out
 
     def run_to_completion(self, chunk: int = 16, use_graph: bool = True, max_total: Optional[int] = None,
                           feed: Optional[TorchCpuNoiseFeed] = None):
@@ -959,7 +983,7 @@ class DecodeEngine:
                         # poll sees it. The fixed-group path bounded every member by the group's cap; here the bound is per utterance, and a
                         # result longer than its cap is the same failure as not finishing (the caller raises on done != 1).
                         st.done = 2
-                    gen = self.generated[u, :n].cpu().numpy().astype(np.int64)
+                    gen = self.tokens(u, n)
                     snap = _lib.SamplerState.from_buffer_copy(bytes(st))
                     results[j] = (snap, gen)
                     if sampling:

@@ -232,7 +232,7 @@ class SSR_Speech(nn.Module):
             eng.start(text_rows, [cated], [knobs])
         states = eng.run_to_completion(chunk=16, use_graph=use_graph, max_total=cap, feed=feed)
         st = states[0]
-        gen = eng.generated[0, : st.n_steps].cpu().numpy().astype(np.int64)
+        gen = eng.tokens(0, int(st.n_steps))
         self.last_run = dict(steps=st.n_steps, done=st.done, span_end=list(st.span_end), prefill_rows=(L + T0) * (2 if aug_text else 1),
                              t_start=t_call, t_first_chunk=eng.t_first_chunk, t_end=time.perf_counter())
         if st.done != 1:

@@ -1,5 +1,13 @@
 """Round 5: one process = the calls alone, then ONE concurrent round (the only round the stress test ever failed in), with a map of where
-`mark` differs if it does. Run many processes: `for i in $(seq 12); do python tools/race_first_round.py; done`."""
+`mark` differs if it does. Run many processes: `for i in $(seq 12); do python tools/race_first_round.py; done`, or, round 6, through
+`tools/race_trials.py` (arms x trials, failures / trials with a Wilson interval). Round-6 switches (each names ONE suspected trigger):
+  prewarm-queues=N   create N streams, run a kernel on each and synchronize BEFORE any codec work: every hardware queue HIP will ever
+                     give this process exists before the first codec kernel runs (no run-list rebuild under load)
+  early-streams      create the three caller streams and the model's side streams (and touch them) before the calls made alone
+  warm-alloc         before the concurrent round, allocate and free on every caller stream what a call allocates (no kernels):
+                     the round runs without a single hipMalloc
+  nopipe             the LSTM layers on ONE stream (no side stream)
+  nolayers           do not keep the detector's layer outputs (the plain stress test's memory picture)"""
 import os
 import sys
 
@@ -11,8 +19,23 @@ import ssr_speech_amd  # noqa: E402,F401
 from ssr_speech_amd import weights as W  # noqa: E402
 from ssr_speech_amd.codec.wmencodec import WMEncodecModel  # noqa: E402
 
+opts = {a.split("=")[0]: (a.split("=") + ["1"])[1] for a in sys.argv[1:]}
+_held = []
+if "prewarm-queues" in opts:
+    for _ in range(int(opts["prewarm-queues"])):
+        s_ = torch.cuda.Stream()
+        with torch.cuda.stream(s_):
+            _held.append((s_, torch.zeros(64, device="cuda") + 1))
+    torch.cuda.synchronize()
 cfg = W.codec_config_full()
-m = WMEncodecModel(cfg, W.codec_state_dict(cfg, seed=21), "cuda")
+_sd_path = "/dev/shm/ssr_race_codec_sd21.pt"               # 144 M parameters take 6 s to generate: once per box, not once per trial
+if os.path.exists(_sd_path):
+    _sd = torch.load(_sd_path, mmap=True)
+else:
+    _sd = W.codec_state_dict(cfg, seed=21)
+    torch.save(_sd, _sd_path + f".{os.getpid()}")
+    os.replace(_sd_path + f".{os.getpid()}", _sd_path)
+m = WMEncodecModel(cfg, _sd, "cuda")
 g = torch.Generator().manual_seed(19)
 n = cfg.hop * 70 + 11
 Bs = (9, 7, 9)
@@ -20,8 +43,17 @@ wavs = [(torch.randn(b, 1, n, generator=g) * 0.2).cuda() for b in Bs]
 labels = [torch.randint(0, 2, (b, 71), generator=g).cuda() for b in Bs]
 tracks = [torch.nn.functional.pad(w, (0, 71 * cfg.hop - n)) for w in wavs]
 names = ("codes", "emb", "dec", "wm", "mark")
-if len(sys.argv) > 1 and sys.argv[1] == "nopipe":
+if "nopipe" in opts:
     m.LSTM_CHUNK = 10 ** 9
+streams = [torch.cuda.Stream() for _ in range(3)]
+if "early-streams" in opts:
+    for st in streams:
+        with torch.cuda.stream(st):
+            _held.append(torch.zeros(64, device="cuda") + 1)
+            sd_ = m._side_stream()
+            with torch.cuda.stream(sd_):
+                _held.append(torch.zeros(64, device="cuda") + 1)
+    torch.cuda.synchronize()
 
 
 # every layer output of the DETECTOR pass (wm_encoder) is kept, for the calls alone and for the concurrent round: if `mark` differs, the
@@ -31,7 +63,7 @@ rec = None
 
 
 def run_rec(nodes, x, after=None):
-    if nodes is not m.wm_encoder.nodes or rec is None:
+    if nodes is not m.wm_encoder.nodes or rec is None or "nolayers" in opts:
         return orig_run(nodes, x, after)
     for idx in range(len(nodes)):
         x = orig_run(nodes[idx: idx + 1], x, after=(nodes[idx + 1] if idx + 1 < len(nodes) else after))
@@ -56,7 +88,17 @@ for i in range(3):
     layers_alone.append(rec)
 rec = None
 torch.cuda.synchronize()
-streams = [torch.cuda.Stream() for _ in range(3)]
+if "warm-alloc" in opts:
+    # what one call allocates, on every caller stream (and its side stream's pool is never allocated from: wmencodec._lstm allocates on
+    # the caller's stream only): a generous superset, then freed into that stream's pool
+    for st in streams:
+        with torch.cuda.stream(st):
+            big = [torch.empty(64 << 20, dtype=torch.uint8, device="cuda") for _ in range(40)]
+            mid = [torch.empty(8 << 20, dtype=torch.uint8, device="cuda") for _ in range(40)]
+            small = [torch.empty(256 << 10, dtype=torch.uint8, device="cuda") for _ in range(64)]
+            del big, mid, small
+    torch.cuda.synchronize()
+n_malloc0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
 got = [None] * 3
 layers_got = []
 for i in (0, 1, 2):
@@ -98,4 +140,6 @@ if not ok:
                 for (it, r), chs in list(seen.items())[:5]:
                     print(f"        item {it} row {r - a.padL}: channels {chs}; alone {[round(float(da[it, r, c_]), 4) for c_ in chs[:6]]} concurrent {[round(float(db[it, r, c_]), 4) for c_ in chs[:6]]}")
                 break
+print(f"device mallocs during the round: {torch.cuda.memory_stats().get('num_device_alloc', 0) - n_malloc0}")
 print("first concurrent round:", "identical" if ok else "DIFFERENT")
+sys.exit(0 if ok else 3)
