@@ -48,11 +48,34 @@ TRAFFIC_SOURCE = {2: "profiles/r05_pmc_fetch_size.md + profiles/r05_pmc_write_si
                   16: "profiles/r02_pmc_fetch_size_16rows.md + profiles/r02_pmc_write_size_16rows.md"}
 
 
-def synth_inputs(args_lm, rank, L=130, N=160):
+DEMO_PROMPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "demo_5895_34622_000026_000002_160f.wav")
+
+
+def demo_prompt_codes(dev):
+    """Prompt of BASELINE configs 1-2: the first 160 frames (3.2 s) of the reference's demo/5895_34622_000026_000002.wav (a data fixture,
+    oracle/make_golden_demo.py), tokenised by wmencodec with the bench's synthetic codec weights -> int64 [1, 160, 4] on the CPU; None if
+    the fixture is not there (then the prompt codes are random, as before round 6). Untimed set-up."""
+    if not os.path.exists(DEMO_PROMPT):
+        return None
+    from ssr_speech_amd import weights as W
+    from ssr_speech_amd.data.tokenizer import AudioTokenizer, tokenize_audio
+    ccfg = W.codec_config_full()
+    tok = AudioTokenizer(device=dev, config=ccfg, state_dict=W.codec_state_dict(ccfg, seed=0))
+    codes, _, _ = tokenize_audio(tok, DEMO_PROMPT)
+    y = codes.transpose(2, 1).cpu().contiguous()
+    assert tuple(y.shape) == (1, 160, 4), y.shape
+    del tok
+    torch.cuda.empty_cache()
+    return y
+
+
+def synth_inputs(args_lm, rank, L=130, N=160, prompt_codes=None):
     g = torch.Generator().manual_seed(2024 + rank)
     x = torch.randint(0, 100, (1, L), generator=g)
     y = torch.randint(0, 2048, (1, N, 4), generator=g)
     unc = torch.randint(0, 101, (1, L), generator=g)
+    if prompt_codes is not None and prompt_codes.shape[1] == N:
+        y = prompt_codes.clone()                 # same draws from `g` either way: the text ids do not depend on the prompt's source
     return x, y, unc
 
 
@@ -192,7 +215,11 @@ def rtf_leg(model, args_lm, dev, tmpdir):
     g = torch.Generator().manual_seed(7)
     n_prompt = 160
     fn = os.path.join(tmpdir, "bench_prompt.wav")
-    write_wav(fn, torch.randn(1, n_prompt * 320, generator=g) * 0.1, 16000)
+    noise_prompt = torch.randn(1, n_prompt * 320, generator=g) * 0.1          # (drawn either way: the texts below keep their values)
+    if os.path.exists(DEMO_PROMPT):
+        fn = DEMO_PROMPT                            # the prompt BASELINE configs 1-2 name, first 160 frames
+    else:
+        write_wav(fn, noise_prompt, 16000)
     symbols = [chr(ord("a") + i) for i in range(26)] + [chr(ord("A") + i) for i in range(26)]
     phn2num = {c: i for i, c in enumerate(symbols)}
     prompt_text = "".join(symbols[int(i)] for i in torch.randint(0, 52, (20,), generator=g))
@@ -220,6 +247,7 @@ def rtf_leg(model, args_lm, dev, tmpdir):
                "lm_inference_ms": round(1000 * (lr["t_end"] - lr["t_start"]), 2)}
         if best is None or rec["rtf"] < best["rtf"]:
             best = rec
+    best["prompt"] = "demo/5895_34622_000026_000002.wav, first 160 frames" if fn == DEMO_PROMPT else "randn x 0.1, 160 frames"
     best["note"] = ("inference_one_sample(wav -> wav): read wav, wmencodec encode of the 3.2 s prompt, prefill, sampled decode with the torch CPU RNG "
                     "stream drawn 16 steps ahead of the GPU, wmencodec decode of all frames; the prompt part is cut from the output (tts)")
     return best
@@ -489,7 +517,8 @@ def main():
     args_lm = W.lm_args_830m()
     sd = W.lm_state_dict(args_lm, seed=0, device=dev)
     arena = LMWeightsArena(args_lm, sd, dev)
-    x, y, unc = synth_inputs(args_lm, rank)
+    demo_y = demo_prompt_codes(dev)
+    x, y, unc = synth_inputs(args_lm, rank, prompt_codes=demo_y)
     L, N = x.shape[1], y.shape[1]
     total = a.warmup + a.steps
     cated, _, num_task, _ = LY.build_layout(y[0].T.numpy(), np.asarray([[N, N]]), args_lm)
@@ -612,7 +641,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"English-830M-shape zero-shot TTS decode, cfg_stride=5, top_k=40/top_p=0.8 sampling, batch={U} ({2 * U} CFG rows) per GPU; "
-                                   f"L={L} phonemes, {N}-frame prompt, context {L + T0 + a.warmup}..{L + T0 + total}",
+                                   f"L={L} phonemes, {N}-frame prompt ({'demo/5895_34622_000026_000002.wav, first 3.2 s, wmencodec codes' if demo_y is not None else 'random codes'}), "
+                                   f"context {L + T0 + a.warmup}..{L + T0 + total}",
                        "utterances_per_gpu": U, "rows": 2 * U, "graph": not a.no_graph, "steps_completed": int(st.n_steps),
                        "pair_launches": bool(eng.pairing), "pair_launches_why": eng.pairing_why},
             "per_gpu_value": round(value / world, 1),

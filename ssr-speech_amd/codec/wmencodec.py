@@ -42,6 +42,20 @@ def _empty(*shape, dtype, device):
     return t
 
 
+class _NoLaunch:
+    """Stands in for the library during a sizing pass (`WMEncodecModel._sized`): every entry point "succeeds" without launching anything."""
+
+    def __getattr__(self, name):
+        if not name.startswith("ssrhip_"):
+            raise AttributeError(name)
+        return lambda *args: 0
+
+
+def _device_mallocs(device) -> int:
+    """How many times the caching allocator has gone to the driver for memory on this device (hipMalloc calls)."""
+    return int(torch.cuda.memory_stats(device).get("num_device_alloc", 0))
+
+
 class TM:
     """Time-major activation buffer with halo rows."""
 
@@ -244,6 +258,13 @@ class WMEncodecModel:
         self.lanes = int(os.environ.get("SSRHIP_CODEC_LANES", "1"))
         self.lane_min_items = int(os.environ.get("SSRHIP_CODEC_LANE_MIN", "8"))
         self._side_streams, self._keep = {}, {}
+        # Round 6 — NO DEVICE MEMORY IS MAPPED WHILE CODEC KERNELS ARE IN FLIGHT (`_sized`; DESIGN.md "the multi-stream failure"):
+        # SSRHIP_CODEC_PRESIZE=0 switches the sizing passes off (the A/B arm of tools/race_trials.py).
+        self.presize = os.environ.get("SSRHIP_CODEC_PRESIZE", "1") not in ("", "0")
+        self._envelopes = {}                 # (entry point, stream) -> [(items, samples-or-frames)] already sized
+        self._dry_hold = []
+        self.mallocs_in_flight = 0           # hipMallocs that happened during a call although it had been sized (tests assert 0)
+        self.sizing_passes = 0
         env = os.environ.get("SSRHIP_RESBLOCK_FUSE")
         self.fuse_channels = tuple(int(v) for v in env.split(",") if v) if env is not None else (64, 128)
         sd = {k: v.detach().to(torch.float32).cpu() for k, v in state_dict.items()}
@@ -299,6 +320,49 @@ class WMEncodecModel:
                 self._planes(Wa)
             self._planes(self.wm_predictor.W)
         torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------ sizing passes
+    def _sized(self, kind: str, B: int, T: int, run):
+        """Run one dense codec pass `run()` so that the caching allocator never has to map device memory (hipMalloc) while the pass's
+        kernels are in flight.
+
+        Why (round 6, DESIGN.md "the multi-stream failure"): on this platform a kernel that runs while ANOTHER hardware queue of the
+        process is busy and the host maps fresh device memory can come back with wrong values — one register of one quarter-wave, in
+        the codec's plainest kernel; 6 of 25 fresh processes against 0 of 25 with a warm allocator or a single hardware queue
+        (tools/race_trials.py, profiles/r06_microbench/). A codec pass IS several queues — the two LSTM layers run on two streams —
+        and a cold process maps memory for every layer, so the first call of every process was exposed, single-stream callers
+        included. What the pass will allocate is a deterministic function of (entry point, items, length): the first time a shape is
+        not covered by one already seen on this stream, the pass runs once DRY — the device idle (synchronised), every library launch
+        a no-op, the same tensors allocated and freed in the same order — which leaves the allocator holding exactly the blocks the
+        real pass then reuses. Later calls of that size or smaller find them there. `mallocs_in_flight` counts the driver allocations
+        that still happened during real passes (a smaller shape can fall into another size class); such a call drops the stream's
+        envelopes, so the next one is sized again."""
+        if not self.presize:
+            return run()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._keep.pop(stream, None)           # the previous call's LSTM state: its kernels are behind us on this stream
+        env = self._envelopes.setdefault((kind, stream), [])
+        if not any(b >= B and t >= T for b, t in env):
+            torch.cuda.synchronize(self.device)                  # nothing in flight, on any stream, while memory is mapped
+            real, self.lib = self.lib, _NoLaunch()
+            self._dry_hold = []
+            try:
+                run()
+            finally:
+                self.lib = real
+                self._keep.pop(stream, None)
+                self._dry_hold = []
+            torch.cuda.synchronize(self.device)                  # the dry pass's own fills and copies (torch kernels on garbage)
+            self.sizing_passes += 1
+            env[:] = [(b, t) for b, t in env if not (b <= B and t <= T)] + [(B, T)]
+        n0 = _device_mallocs(self.device)
+        out = run()
+        grown = _device_mallocs(self.device) - n0
+        if grown:
+            self.mallocs_in_flight += grown
+            for k in [k for k in self._envelopes if k[1] == stream]:
+                self._envelopes[k] = []
+        return out
 
     # ------------------------------------------------------------------ low-level launches
     def _s(self):
@@ -530,7 +594,13 @@ class WMEncodecModel:
         out = outs[-1]
         out.elu = post_elu
         self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
-        self._keep[torch.cuda.current_stream(dev).cuda_stream] = (gins, hbufs, cbufs, outs, hsplits)
+        key = torch.cuda.current_stream(dev).cuda_stream
+        if isinstance(self.lib, _NoLaunch) and key in self._keep:
+            # sizing pass: buffers the side stream touched come back to the pool only when the GPU has passed the event recorded at their
+            # release (record_stream) — in a real pass the host is far ahead of the GPU, so the NEXT LSTM of the same call cannot reuse
+            # them yet. The dry pass has no GPU work to wait for; holding every generation until its end sizes the pool for the worst case.
+            self._dry_hold.append(self._keep[key])
+        self._keep[key] = (gins, hbufs, cbufs, outs, hsplits)
         return out
 
     def _side_stream(self):
@@ -610,7 +680,7 @@ class WMEncodecModel:
                                                   self.cfg.n_q, self.cfg.bins, emb.bstride, self._s()), "ssrhip_rvq_encode")
             return codes.to(torch.int64), emb.interior_view().transpose(1, 2).contiguous()
 
-        parts = self._in_lanes(x.shape[0], body)
+        parts = self._in_lanes(x.shape[0], lambda lo, hi: self._sized("encode", hi - lo, int(x.shape[-1]), lambda: body(lo, hi)))
         return self._join(parts, 0), None, self._join(parts, 1)
 
     def _codes32(self, codes: torch.Tensor) -> torch.Tensor:
@@ -643,7 +713,8 @@ class WMEncodecModel:
 
     @torch.no_grad()
     def decode_latent(self, codes: torch.Tensor) -> torch.Tensor:
-        return self._dequant(self._codes32(codes), None).interior_view().transpose(1, 2).contiguous()
+        c32 = self._codes32(codes)
+        return self._sized("latent", int(c32.shape[0]), int(c32.shape[-1]), lambda: self._dequant(c32, None).interior_view().transpose(1, 2).contiguous())
 
     @torch.no_grad()
     def decode(self, codes: torch.Tensor, scale=None) -> torch.Tensor:
@@ -654,7 +725,7 @@ class WMEncodecModel:
             z = self._dequant(c32[lo:hi], self.decoder.nodes[0])
             return (self._channel_major(self._run(self.decoder.nodes, z)),)
 
-        return self._join(self._in_lanes(c32.shape[0], body), 0)
+        return self._join(self._in_lanes(c32.shape[0], lambda lo, hi: self._sized("decode", hi - lo, int(c32.shape[-1]), lambda: body(lo, hi))), 0)
 
     # ------------------------------------------------------------------ ragged batches (items of different lengths in one pass)
     # cost model of one dense pass over a bucket, in microseconds per frame of its longest item: every frame is one LSTM time step
@@ -710,8 +781,8 @@ class WMEncodecModel:
             dense, lens = self._stack_ragged(codes, idx, 1, torch.int64)
             c32 = self._codes32(dense)
             rg = Ragged(lens, self.device) if min(lens) != max(lens) else None
-            z = self._dequant(c32, self.decoder.nodes[0], rg)
-            wav = self._channel_major(self._run(self.decoder.nodes, z))
+            # (a ragged pass allocates what the dense pass of its longest item allocates: same envelope family as `decode`)
+            wav = self._sized("decode", len(idx), max(lens), lambda: self._channel_major(self._run(self.decoder.nodes, self._dequant(c32, self.decoder.nodes[0], rg))))
             for j, i in enumerate(idx):
                 out[i] = wav[j: j + 1, :, : lens[j] * hop]
         return out
@@ -737,7 +808,8 @@ class WMEncodecModel:
             lab, _ = self._stack_ragged(labels, idx, 0, torch.int64)
             wv, _ = self._stack_ragged(wavforms, idx, 0, torch.float32)
             rg = Ragged(lens, self.device) if min(lens) != max(lens) else None
-            w, m = self._wmdecode_dense(self._codes32(dense), self._labels32(lab), wv.unsqueeze(1), with_mark, rg)
+            c32, l32, wv1 = self._codes32(dense), self._labels32(lab), wv.unsqueeze(1)
+            w, m = self._sized("wmdecode" + ("+mark" if with_mark else ""), len(idx), max(lens), lambda: self._wmdecode_dense(c32, l32, wv1, with_mark, rg))
             for j, i in enumerate(idx):
                 wavs[i] = w[j: j + 1, :, : lens[j] * hop]
                 if m is not None:
@@ -774,7 +846,9 @@ class WMEncodecModel:
         assert scale is None and self.has_wm
         lab_all = self._labels32(labels)
         c32 = self._codes32(codes)
-        parts = self._in_lanes(c32.shape[0], lambda b0, b1: self._wmdecode_dense(c32[b0:b1], lab_all[b0:b1].contiguous(), wavform[b0:b1], with_mark, None))
+        parts = self._in_lanes(c32.shape[0], lambda b0, b1: self._sized(
+            "wmdecode" + ("+mark" if with_mark else ""), b1 - b0, int(c32.shape[-1]),
+            lambda: self._wmdecode_dense(c32[b0:b1], lab_all[b0:b1].contiguous(), wavform[b0:b1], with_mark, None)))
         return self._join(parts, 0), self._join(parts, 1)
 
     def _wmdecode_dense(self, c32: torch.Tensor, lab: torch.Tensor, wavform: torch.Tensor, with_mark: bool, lens: Optional[Ragged]):
@@ -815,4 +889,4 @@ class WMEncodecModel:
             mk = self._conv(self.wm_predictor, m, None).interior_view().transpose(1, 2)      # [B,2,T']
             return (torch.argmax(mk.squeeze(-1), dim=-1),)
 
-        return self._join(self._in_lanes(x.shape[0], body), 0)
+        return self._join(self._in_lanes(x.shape[0], lambda lo, hi: self._sized("detect", hi - lo, int(x.shape[-1]), lambda: body(lo, hi))), 0)

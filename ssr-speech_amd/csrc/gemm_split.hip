@@ -232,8 +232,33 @@ __device__ unsigned* g_gd_prof = nullptr;                  // [sampled workgroup
 // GEMM — time mask tm_c > 0 with N % tm_c == 0 and tm_c % 4 == 0, nothing added behind the activation (the launcher checks) — take the
 // 16-byte epilogue with the mask as a per-row predicate: element (m, n) belongs to time row (m N + n) / tm_c = m (N / tm_c) + n / tm_c, the
 // second term one 32-bit division per LANE. The general loop those launches take today pays a 64-bit division per OUTPUT (32 per lane).
+//
+// Round 6 — which tile a workgroup takes (flags bit 1, default on; SSRHIP_GEMM_XCD=0 = the plain blockIdx order): the hardware deals
+// workgroups to the 8 XCDs round-robin in launch order (x fastest), so the N-tiles that share an A row-tile — neighbours in x — ran on
+// DIFFERENT XCDs and every one of their L2s pulled its own copy of the tile across the fabric: rocprofv3 FETCH_SIZE 134.6 GB for a 31.5 GB
+// operand at `60001 x 512 x 512 x 256` (4 N-tiles), 197 GB for 12.6 GB at `12001 x 1280 x 1024 x 256` (10 N-tiles)
+// (profiles/r05_codec_b256_pmc_fetch_size.md). Now workgroup w (linear launch index) runs on XCD w % 8 as the
+// (w / 8)-th workgroup of that XCD and takes logical tile start(w % 8) + w / 8, where XCD c owns the contiguous range of logical tiles
+// [start(c), start(c + 1)) and logical tiles are numbered x fastest: the N-tiles of one row-tile run on ONE XCD, back to back, and
+// its L2 fetches the A tile once. A bijection of the grid onto itself (tests/test_split_gemm_addressing_model.py), results unchanged.
+__device__ __forceinline__ void xcd_tile(const int flags, int& bx, int& by, int& bz) {
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+  if (!(flags & 2)) return;
+  const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+  const unsigned w = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+  const unsigned c = w & 7u, j = w >> 3, q = total >> 3, r = total & 7u;
+  const unsigned L = c * q + (c < r ? c : r) + j;                    // XCD c owns q + (c < r) logical tiles
+  bx = (int)(L % nx);
+  const unsigned t2 = L / nx;
+  by = (int)(t2 % ny);
+  bz = (int)(t2 / ny);
+}
+
 template <int BM, bool ELU, int KO = 0, bool TMF = false>
-__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_split_dma_kernel(const ssrhip_gemm_args a0, const int wide) {
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_split_dma_kernel(const ssrhip_gemm_args a0, const int flags) {
+  const int wide = flags & 1;
+  int bx, by, bz;
+  xcd_tile(flags, bx, by, bz);
   constexpr int MT = BM / 64, LA = BM / 64, APL = BM * 64;           // accumulators per wave, A loader passes, bytes per A plane
   extern __shared__ __attribute__((aligned(1024))) char ldsb[];
   char* const As = ldsb;                                             // [3][BM][64 B]
@@ -249,19 +274,20 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   // its epilogue and a sample of the workgroups copies the stamps out
   struct Dump {
     unsigned* st;
+    int bx_, by_, bz_;
     __device__ ~Dump() {
       if constexpr ((KO & GD_PROF) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) st[125] = (unsigned)wall_clock64();
         __syncthreads();
-        if (blockIdx.x == 0 && blockIdx.y % 37 == 5 && blockIdx.z % 8 == 3 && threadIdx.x < GD_NSTAMP)
-          g_gd_prof[((size_t)(blockIdx.z / 8) * ((gridDim.y + 31) / 37) + blockIdx.y / 37) * GD_NSTAMP + threadIdx.x] = st[threadIdx.x];
+        if (bx_ == 0 && by_ % 37 == 5 && bz_ % 8 == 3 && threadIdx.x < GD_NSTAMP)
+          g_gd_prof[((size_t)(bz_ / 8) * ((gridDim.y + 31) / 37) + by_ / 37) * GD_NSTAMP + threadIdx.x] = st[threadIdx.x];
       }
     }
-  } dump{stamps};
+  } dump{stamps, bx, by, bz};
   ssrhip_gemm_args a = a0;
   {   // batched problems: grid.z
-    const size_t z = blockIdx.z;
+    const size_t z = (size_t)bz;
     a.A += z * (size_t)a.strideA;
     a.C += z * (size_t)a.strideC;
     if (a.R) a.R += z * (size_t)a.strideR;
@@ -270,7 +296,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = (wave >> 2) & 1, wn = wave & 3;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int n0 = bx * BN, m0 = by * BM;
   const int lr = t >> 3, lc = (t & 7) * 4;                           // A loader: 8 threads per row (32 k), 64 rows per pass, 2 passes
   const int M = a.M, N = a.N, K = a.K;
   const short* Wp = reinterpret_cast<const short*>(a.W_split);
@@ -535,10 +561,13 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
   // the DMA kernels address a tile through 32-bit buffer offsets: 128 rows of A (and of a W plane) have to stay below 2 GiB
   static const bool dma_off = getenv("SSRHIP_GEMM_SPLIT_DMA") && getenv("SSRHIP_GEMM_SPLIT_DMA")[0] == '0';   // A/B knob: the 4-wave kernels
   const bool dma = !dma_off && ((size_t)127 * a->lda + a->K) * 4 < 0x7FFFFFF0ull && (size_t)128 * a->K * 2 < 0x7FFFFFF0ull;
-  static const int wide = !(getenv("SSRHIP_EPILOGUE_WIDE") && getenv("SSRHIP_EPILOGUE_WIDE")[0] == '0');      // A/B knob: 0 = dword epilogue
+  static const int wide1 = !(getenv("SSRHIP_EPILOGUE_WIDE") && getenv("SSRHIP_EPILOGUE_WIDE")[0] == '0');     // A/B knob: 0 = dword epilogue
+  // XCD-aware tile order of the DMA kernels (read at every launch: tests flip it inside one process); total tiles must fit 32 bits
+  const char* xe = getenv("SSRHIP_GEMM_XCD");
+  const int flags0 = wide1 | ((xe && xe[0] == '0') ? 0 : 2);
   // the transposed convolutions' time mask as a row predicate of the 16-byte epilogue (SSRHIP_EPILOGUE_TM=0: the general per-element loop)
   static const bool tm_knob = !(getenv("SSRHIP_EPILOGUE_TM") && getenv("SSRHIP_EPILOGUE_TM")[0] == '0');
-  const bool tmf = tm_knob && wide && a->tm_c > 0 && a->N % a->tm_c == 0 && a->tm_c % 4 == 0 && !a->R && !a->residual && !a->rbias && a->ldc % 4 == 0 &&
+  const bool tmf = tm_knob && wide1 && a->tm_c > 0 && a->N % a->tm_c == 0 && a->tm_c % 4 == 0 && !a->R && !a->residual && !a->rbias && a->ldc % 4 == 0 &&
                    a->strideC % 4 == 0 && ((uintptr_t)a->C & 15) == 0 && (long)a->M * (a->N / a->tm_c) < 0x7FFFFFFFL;
   if (dma) {
     static ssr_once_per_device once;
@@ -556,6 +585,7 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
   if (tiles128 >= 384 && !half_empty) {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 127) / 128, (unsigned)nb);
     ssr_gemm_log(a, grid.x, grid.y, grid.z, 1);
+    const int wide = ((long)grid.x * grid.y * grid.z > 0x7FFFFFFFL) ? (flags0 & 1) : flags0;      // the remap counts tiles in 32 bits
     if (dma && tmf) {
       if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<128, true, 0, true>), grid, dim3(512), dma_lds(128), s, *a, wide);
       else hipLaunchKernelGGL((gemm_split_dma_kernel<128, false, 0, true>), grid, dim3(512), dma_lds(128), s, *a, wide);
@@ -567,6 +597,7 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
   } else {
     dim3 grid((a->N + BN - 1) / BN, (a->M + 63) / 64, (unsigned)nb);
     ssr_gemm_log(a, grid.x, grid.y, grid.z, 1);
+    const int wide = ((long)grid.x * grid.y * grid.z > 0x7FFFFFFFL) ? (flags0 & 1) : flags0;
     if (dma) {
       if (elu) hipLaunchKernelGGL((gemm_split_dma_kernel<64, true>), grid, dim3(512), dma_lds(64), s, *a, wide);
       else hipLaunchKernelGGL((gemm_split_dma_kernel<64, false>), grid, dim3(512), dma_lds(64), s, *a, wide);

@@ -477,6 +477,125 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
   MSTAMP(5);
 }
 
+// Round 6: the LayerNorm launches at K = 2048 with the LayerNorm OFF the streaming waves. Round 5's stamps
+// (above) say where such a launch loses against the chain floor: a wave is in-order, posting its weight requests blocks it for ~4 us (the CU
+// accepts misses at the rate earlier ones return), and everything else a streaming wave has to do — fetch its x slice, the two LayerNorm
+// passes, the statistics barrier, the normalisation — happens either in front of the requests (then HBM starts late) or behind the first 16
+// of them (then HBM runs dry while the LayerNorm computes: as shipped, ~2 us with nothing requested). Three re-orderings inside the
+// 8-wave kernel did not pay. Here the workgroup has 12 waves:
+//   * waves 0-7 (streaming) post ALL weight requests of the workgroup's NT tiles at entry — 2 x 16 KiB per wave, nothing in front of them,
+//     nothing between them — and then wait;
+//   * waves 8-11 (edge) fetch x (32 k-steps = 32 KiB each, L2 hits, their own request queues), compute the LayerNorm statistics in
+//     EXACTLY the eight 256-column slices, the order and the expressions of gemv_rows_xreg_kernel (so the normalised x, and with it every
+//     output, is bit-identical to that kernel), normalise, and leave x' in LDS in k-step order (128 KiB of the CU's 160);
+//   * two workgroup barriers (statistics complete, x' complete) — the streaming waves reach them when their requests are posted, the
+//     edge waves long before — then the streaming waves read their 16 KiB slice of x' from LDS k-step by k-step and run the MFMA chains of
+//     both tiles on weights that are resident or in flight. Partial tiles, merge order and epilogue as in gemv_rows_xreg_kernel.
+// 12 waves are 3 per SIMD: 168 VGPRs per wave, of which the resident weights take 128 (NT = 2) — x' therefore stays in LDS and is read
+// one k-step ahead. Host-selected when every workgroup owns exactly NT tiles (QKV: 3 units, FFN1: 4 units -> NT = 2; head MLP: 2 units ->
+// NT = 1), x is tiled and K = 2048; SSRHIP_GEMVM_EDGE=0 (read at every launch) = the 8-wave kernel.
+constexpr int EDGE_XS_BYTES = 128 * 1024;                 // x': 128 k-steps x 1 KiB
+constexpr int edge_lds(int NT) { return EDGE_XS_BYTES + NT * 8 * 1024 + 2 * 8 * 16 * 4; }
+
+template <int NT>
+__global__ __launch_bounds__(768) void gemv_rows_edge_kernel(const GemvR p) {
+  constexpr int SW = 8, SPWX = 16;                        // streaming waves, k-steps per streaming wave (K = 2048: 128 k-steps)
+  extern __shared__ __attribute__((aligned(1024))) char esm[];
+  float4* const xs = reinterpret_cast<float4*>(esm);                                  // [128][64]
+  f4v* const part = reinterpret_cast<f4v*>(esm + EDGE_XS_BYTES);                       // [NT][8][64]
+  float* const red = reinterpret_cast<float*>(esm + EDGE_XS_BYTES + NT * 8 * 1024);    // [2][8][16]
+  const ssrhip_gemv_args& a = p.a;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, ks = lane >> 4;
+  const int grp = blockIdx.y;
+  const int N = a.N, K = a.K;
+  const int u_lo = (int)((long long)blockIdx.x * p.units / p.wgs), u_hi = (int)((long long)(blockIdx.x + 1) * p.units / p.wgs);
+  const int nun = u_hi - u_lo;                                          // host: 2 NT - 1 or 2 NT for every workgroup
+  const int row_lo = u_lo * 8;
+  if (wave >= SW) {
+    // ---------------- edge: x -> LayerNorm -> x' in LDS
+    const int e = wave - SW;
+    const float* xp = a.x + (size_t)grp * K * 16 + (size_t)(32 * e) * 256 + (unsigned)(ks * 16 + c) * 4;   // tiled x: one KiB per k-step
+    float4 xr[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) xr[t] = ld4(xp + t * 256);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                                       // slice v = 2 e + h: what streaming wave v computes in the 8-wave kernel
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < SPWX; ++t) s += (xr[16 * h + t].x + xr[16 * h + t].y) + (xr[16 * h + t].z + xr[16 * h + t].w);
+      s = kslot_sum(s);
+      const float mw = s / (float)(SPWX * 16);
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < SPWX; ++t) {
+        const float dx = xr[16 * h + t].x - mw, dy = xr[16 * h + t].y - mw, dz = xr[16 * h + t].z - mw, dw = xr[16 * h + t].w - mw;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+      q = kslot_sum(q);
+      if (ks == 0) { red[(2 * e + h) * 16 + c] = mw; red[128 + (2 * e + h) * 16 + c] = q; }
+    }
+    __syncthreads();                                                    // (A) the eight slices' statistics are in LDS
+    float mean = 0.f;
+    for (int v = 0; v < SW; ++v) mean += red[v * 16 + c] * (float)(SPWX * 16);
+    mean /= (float)K;
+    float var = 0.f;
+    for (int v = 0; v < SW; ++v) {
+      const float d = red[v * 16 + c] - mean;
+      var += red[128 + v * 16 + c] + (float)(SPWX * 16) * d * d;
+    }
+    var /= (float)K;
+    const float rstd = 1.0f / sqrtf(var + a.ln_eps);
+#pragma unroll
+    for (int t = 0; t < 32; ++t)
+      xs[(32 * e + t) * 64 + lane] = make_float4((xr[t].x - mean) * rstd, (xr[t].y - mean) * rstd, (xr[t].z - mean) * rstd, (xr[t].w - mean) * rstd);
+    __syncthreads();                                                    // (B) x' complete
+    return;
+  }
+  // ---------------- streaming: every weight request of this wave, now
+  const int tbase = wave * SPWX;
+  const float* wbase = a.W + (size_t)grp * (a.w_tiled ? (size_t)p.units * 8 : (size_t)N) * K;
+  const int wstep = a.w_tiled ? 128 : 16;
+  const int kvpos = tile_kvpos(a, lane);                                // the wave's oldest load (QKV launch only)
+  __builtin_amdgcn_sched_barrier(0);
+  float4 w[NT][SPWX];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const float* wp = tile_wptr(wbase, row_lo, nun, i, c, ks, N, K, a.w_tiled);
+#pragma unroll
+    for (int t = 0; t < SPWX; ++t) w[i][t] = ld_nt(wp + (tbase + t) * wstep);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const int ntile = (nun + 1) >> 1;
+  const TileEpi epi0 = tile_epilogue_fetch(a, p.hd, grp, row_lo + wave * 16, wave < ntile ? ((2 * wave + 1 < nun) ? 16 : 8) : 0, lane, kvpos);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();                                                      // (A)
+  __syncthreads();                                                      // (B)
+  const float4* xw = xs + (size_t)tbase * 64 + lane;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    f4v a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    float4 xv = xw[0];
+#pragma unroll
+    for (int t = 0; t < SPWX; ++t) {
+      const float4 wv = w[i][t], xc = xv;
+      if (t + 1 < SPWX) xv = xw[(t + 1) * 64];                          // one k-step ahead (LDS)
+      a0 = mfma4(wv.x, xc.x, a0);
+      a1 = mfma4(wv.y, xc.y, a1);
+      a0 = mfma4(wv.z, xc.z, a0);
+      a1 = mfma4(wv.w, xc.w, a1);
+    }
+    part[(i * 8 + wave) * 64 + lane] = a0 + a1;
+  }
+  __syncthreads();                                                      // (C) partial tiles complete (the edge waves have left)
+  if (wave < ntile) {
+    f4v acc = part[(wave * 8) * 64 + lane];
+    for (int v = 1; v < SW; ++v) acc += part[(wave * 8 + v) * 64 + lane];
+    tile_epilogue_finish(a, epi0, acc, p.hd);
+  }
+}
+
 // K > 2048 without a LayerNorm prologue (FFN2, K = 8192): x no longer fits the registers of 8 waves, so it is streamed like W: per k-step one KiB of W (HBM) and one
 // KiB of x (L2; the tiled layout makes it one contiguous KiB per wave instruction), 16 of each in flight per wave.
 template <bool PAIR>
@@ -695,6 +814,21 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s) {
     dim3 grid(r.wgs, a->groups), block(r.nw * 64);
     // every workgroup owns exactly one 8-row unit (out-proj, FFN2) and the weights are in streaming order: k-step pairs per load
     const bool pair = a->w_tiled && r.units <= r.wgs && r.steps % 2 == 0 && !g_nopair;
+    // round 6: LayerNorm launches with the LayerNorm on four extra waves and every weight request posted at entry (gemv_rows_edge_kernel)
+    const char* ee = getenv("SSRHIP_GEMVM_EDGE");
+    const int per = r.wgs > 0 ? r.units / r.wgs : 0;
+    if (a->pro == SSRHIP_PRO_LAYERNORM && a->K == 2048 && a->x_tiled && !(ee && ee[0] == '0') && g_wpc == 1 && a->groups == 1 &&
+        r.units % r.wgs == 0 && per >= 1 && per <= 4) {
+      static ssr_once_per_device once;
+      if (once.need()) {
+        SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_rows_edge_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds(1)));
+        SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_rows_edge_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, edge_lds(2)));
+      }
+      if (per <= 2) hipLaunchKernelGGL(gemv_rows_edge_kernel<1>, grid, dim3(768), edge_lds(1), s, r);
+      else hipLaunchKernelGGL(gemv_rows_edge_kernel<2>, grid, dim3(768), edge_lds(2), s, r);
+      SSR_LAUNCH_CHECK();
+      return 0;
+    }
     if (!xreg && pair) hipLaunchKernelGGL(gemv_rows_stream_kernel<true>, grid, block, 0, s, r);
     else if (!xreg) hipLaunchKernelGGL(gemv_rows_stream_kernel<false>, grid, block, 0, s, r);
     else if (pair && a->pro == SSRHIP_PRO_NONE && spwx == 16) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_NONE, 16, 16, true>), grid, block, 0, s, r);

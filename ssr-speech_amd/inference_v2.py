@@ -51,6 +51,8 @@ REFERENCE_FLAGS = [
 EXTRA_FLAGS = [
     ("--mask_start", dict(type=float, default=None, help="edit span start in seconds (speech editing)")),
     ("--mask_end", dict(type=float, default=None, help="edit span end in seconds (speech editing)")),
+    ("--mask_spans", dict(type=str, default=None, help="speech editing with up to max_n_spans (3) edits: 'a-b,c-d[,e-f]' in seconds — what the "
+                                                       "reference derives from the word alignment of the edited transcript (one span per edit)")),
     ("--prompt_end", dict(type=float, default=None, help="--tts: cut the prompt audio at this time in seconds (default --prompt_length)")),
     ("--phoneme_ids", dict(type=str, default=None, help="comma separated phoneme ids of the target transcript (skips espeak)")),
     ("--prompt_phoneme_ids", dict(type=str, default=None, help="comma separated phoneme ids of the prompt transcript")),
@@ -58,6 +60,45 @@ EXTRA_FLAGS = [
                                                      "orig_transcript, prompt_end}; all of them are decoded in lock-step (sharded over the ranks of a "
                                                      "torchrun job) and rendered in one ragged codec pass per rank")),
 ]
+
+
+def edit_spans(spans, sub_amount: float, audio_dur: float, codec_sr: int, max_n_spans: int = 3, threshold: float = 0.2):
+    """Word-aligned edit intervals [(start, end)] in seconds -> (morphed spans in seconds, mask_interval [M, 2] in codec frames), the way
+    the reference turns its alignment into the model's spans (inference_v2.py:284-317): more than `max_n_spans` edits is an error BEFORE
+    anything is merged (:284-285); every interval grows by `sub_amount` on both sides, clipped to the file (:307-308); intervals that
+    come within `threshold` seconds of each other after sorting by their start become one (:293-305); frames = round(seconds * codec_sr)."""
+    if len(spans) > max_n_spans:
+        raise RuntimeError(f"Current model only supports maximum {max_n_spans} editings")
+    if not spans:
+        raise ValueError("no edit span given")
+    grown = sorted(([max(float(a) - sub_amount, 0), min(float(b) + sub_amount, audio_dur)] for a, b in spans), key=lambda x: x[0])
+    merged = [grown[0]]
+    for nxt in grown[1:]:
+        if merged[-1][1] >= nxt[0] - threshold:
+            merged[-1][1] = max(merged[-1][1], nxt[1])
+        else:
+            merged.append(nxt)
+    return merged, torch.LongTensor([[round(a * codec_sr), round(b * codec_sr)] for a, b in merged])
+
+
+def parse_mask_spans(text: str):
+    """'0.8-1.2,2.5-3.1' -> [(0.8, 1.2), (2.5, 3.1)]"""
+    out = []
+    for piece in text.split(","):
+        piece = piece.strip()
+        if not piece:
+            continue
+        a, sep, b = piece.partition("-")
+        if not sep:
+            raise SystemExit(f"--mask_spans: '{piece}' is not 'start-end' (seconds)")
+        try:
+            a, b = float(a), float(b)
+        except ValueError:
+            raise SystemExit(f"--mask_spans: '{piece}' is not 'start-end' (seconds, both >= 0)")
+        if not (0 <= a <= b):
+            raise SystemExit(f"--mask_spans: '{piece}' needs 0 <= start <= end")
+        out.append((a, b))
+    return out
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -227,15 +268,17 @@ def main(argv=None):
         prompt_text = args.orig_transcript or ""
         target_text = (prompt_text + " " + args.target_transcript).strip()           # :273
     else:
-        if args.mask_start is None or args.mask_end is None:
-            raise SystemExit("speech editing without WhisperX needs --mask_start and --mask_end (seconds)")
+        if args.mask_spans is not None:
+            spans = parse_mask_spans(args.mask_spans)
+        elif args.mask_start is not None and args.mask_end is not None:
+            spans = [(args.mask_start, args.mask_end)]
+        else:
+            raise SystemExit("speech editing without WhisperX needs --mask_spans 'a-b[,c-d[,e-f]]' or --mask_start and --mask_end (seconds)")
         audio_fn = os.path.join(work_dir, f"{args.savename}_16k.wav")
         write_wav(audio_fn, wav, sr)
-        s = max(args.mask_start - args.sub_amount, 0.0)                              # :307-312 (margins around the edited words)
-        e = min(args.mask_end + args.sub_amount, audio_dur)
-        morphed_span = [[s, e]]                                                      # :312-317 (one span: no WhisperX word alignment here)
+        # :284-317: the alignment's edit intervals -> margins, merge, frames (here the intervals come from the command line)
+        morphed_span, mask_interval = edit_spans(spans, args.sub_amount, audio_dur, args.codec_sr, int(config.get("max_n_spans", 3)))
         torch.save(morphed_span, os.path.join(args.output_dir, f"{args.savename}_mask.pt"))
-        mask_interval = torch.LongTensor([[round(s * args.codec_sr), round(e * args.codec_sr)]])
         prompt_text = args.orig_transcript or ""
         target_text = args.target_transcript
 

@@ -1,7 +1,7 @@
 """GPU: BASELINE.json's configurations at their STATED shapes, each against the oracle on this box's CPU
 plus size-independent properties:
 
-  config 2   830M, L=130 phonemes, 160-frame prompt, cfg_stride=5, top_k=40 / top_p=0.8 sampling — tokens identical to the
+  config 2   830M, L=130 phonemes, the 160-frame prompt cut from demo/5895_34622_000026_000002.wav (tests/golden/), cfg_stride=5, top_k=40 / top_p=0.8 sampling — tokens identical to the
              oracle's under the same seed (the sampler consumes torch's CPU stream), 20 steps.
   config 3   830M speech editing on the reference's demo prompt demo/84_121550_000074_000000.wav (tests/golden/, 126,880 samples =
              397 frames, oracle/make_golden_demo.py): wav -> wmencodec codes -> single-span edit [150, 250) -> watermarked wav; the first
@@ -40,7 +40,19 @@ def test_config2_830m_sampled_top_k40_top_p08_matches_oracle():
     gen = torch.Generator().manual_seed(2024)
     L, N, steps = 130, 160, 20
     x = torch.randint(0, 100, (1, L), generator=gen)
-    y = torch.randint(0, 2048, (1, N, 4), generator=gen)
+    # the prompt BASELINE configs 1-2 name: demo/5895_34622_000026_000002.wav, first 160 frames (tests/golden/, oracle/make_golden_demo.py),
+    # tokenised by wmencodec (synthetic weights: there are no pretrained ones) — the LM and the oracle are fed the SAME codes
+    import json
+    from ssr_speech_amd.data.tokenizer import AudioTokenizer, tokenize_audio
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    facts = json.load(open(os.path.join(gold, "demo_5895_34622_000026_000002_160f.json")))
+    ccfg = W.codec_config_full()
+    tok = AudioTokenizer(device="cuda", config=ccfg, state_dict=W.codec_state_dict(ccfg, seed=0))
+    codes, _, _ = tokenize_audio(tok, os.path.join(gold, "demo_5895_34622_000026_000002_160f.wav"))
+    assert tuple(codes.shape) == (1, 4, facts["frames_320"]) == (1, 4, N)
+    y = codes.transpose(2, 1).cpu().contiguous()
+    assert len(np.unique(y.numpy())) > 100                              # real audio through the RVQ: not a constant
+    del tok
     unc = torch.randint(0, 101, (1, L), generator=gen)
     mi = torch.LongTensor([[[N, N]]])
     kw = dict(top_k=40, top_p=0.8, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=5, aug_text=True)
@@ -54,6 +66,7 @@ def test_config2_830m_sampled_top_k40_top_p08_matches_oracle():
                       uncond_x=unc, max_new_steps=steps, **kw)
     assert out is None and m.last_run["steps"] == steps
     eng = next(iter(m._engines.values()))
+    assert eng.pairing, f"the default 2-row step on a 256-CU part runs the pair launches: {eng.pairing_why}"
     got_tok = eng.generated[0, :steps].cpu().numpy()
     assert np.array_equal(got_tok, ref_tok), (got_tok, ref_tok)
     assert len({tuple(t) for t in ref_tok.tolist()}) > 5            # it really sampled (not one token repeated)
@@ -63,6 +76,7 @@ def test_config2_830m_sampled_top_k40_top_p08_matches_oracle():
     # (SSRHIP_GEMV_PAIR=0, read when the step is enqueued) must sample the same tokens from bit-identical logits
     logits_paired = eng.dbg_logits.clone() if getattr(eng, "dbg_logits", None) is not None else None
     m._engines.clear()
+    eng.close()
     os.environ["SSRHIP_GEMV_PAIR"] = "0"
     try:
         torch.manual_seed(4242)
@@ -71,6 +85,7 @@ def test_config2_830m_sampled_top_k40_top_p08_matches_oracle():
     finally:
         del os.environ["SSRHIP_GEMV_PAIR"]
     eng0 = next(iter(m._engines.values()))
+    assert not eng0.pairing and "SSRHIP_GEMV_PAIR=0" in eng0.pairing_why
     assert np.array_equal(eng0.generated[0, :steps].cpu().numpy(), ref_tok)
     if logits_paired is not None and getattr(eng0, "dbg_logits", None) is not None:
         assert torch.equal(eng0.dbg_logits, logits_paired)

@@ -159,6 +159,66 @@ def test_gemv_mfma_tiled_activations(L, B, G, N, K, pro, act, epi, wt):
     assert L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()) != 0       # tiled operands are a 5..16-row feature
 
 
+@pytest.mark.parametrize("B", [5, 16])
+@pytest.mark.parametrize("N,act,epi", [(6144, 0, 2), (8192, 1, 0), (4096, 2, 0), (2048, 0, 0)])
+def test_gemv_rows_edge_kernel_is_bit_identical_to_the_eight_wave_kernel(L, monkeypatch, B, N, act, epi):
+    """Round 6 (`gemv_rows_edge_kernel`, csrc/gemv_mfma.hip): the 5..16-row LayerNorm launches at K = 2048 with the LayerNorm on four extra
+    waves (x' handed over through LDS) and every weight request posted at entry. It computes the statistics in the same slices, order
+    and expressions as `gemv_rows_xreg_kernel`, so outputs — q, the appended K / V rows, the FFN hidden, the head hidden — must be
+    BIT-identical with the knob on and off (SSRHIP_GEMVM_EDGE, read at every launch), and within the GEMV tolerance of torch.
+    Shapes: QKV with the cache append (3 units per workgroup: a 16-row and an 8-row tile), FFN1 (two 16-row tiles), the head MLP (one
+    tile), and N = 2048 (one 8-row unit per workgroup)."""
+    from ssr_speech_amd.engine import to_streaming_order
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the row split assumes 256 workgroups")
+    K = 2048
+    g = torch.Generator().manual_seed(N + B)
+    Wt = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    x = torch.randn(B, K, generator=g) * 1.3 + 0.4
+    ref = F.linear(F.layer_norm(x, (K,), None, None, 1e-5), Wt, bias)
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    dW, db, dx = dev(to_streaming_order(Wt)), dev(bias), dev(_to_tiled(x))
+    H, hd, n_layer, max_pages, layer = 16, 128, 2, 3, 1
+    pool, table = _make_cache(B, max_pages, n_layer, H, hd, g)
+    pos = torch.randint(0, max_pages * _lib.PAGE, (B,), generator=g).to(torch.int32)
+    dtable, dpos = dev(table), dev(pos)
+
+    def run():
+        dpool = dev(pool.clone())
+        if epi == 2:
+            dy = torch.zeros(B, K, device="cuda")
+        else:
+            dy = dev(_to_tiled(torch.zeros(B, N)))
+        a = _lib.GemvArgs()
+        a.W, a.bias, a.x, a.y = dW.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr()
+        a.B, a.N, a.K, a.groups, a.x_stride, a.y_stride = B, N, K, 1, 0, (K if epi == 2 else 0)
+        a.pro, a.act, a.epi, a.ln_eps = _lib.PRO_LAYERNORM, act, epi, 1e-5
+        a.x_tiled, a.y_tiled, a.w_tiled = 1, (0 if epi == 2 else 1), 1
+        if epi == 2:
+            a.kv = _lib.KV(dpool.data_ptr(), dtable.data_ptr(), max_pages, n_layer, H, hd)
+            a.layer, a.kv_pos = layer, dpos.data_ptr()
+        _lib.check(L.ssrhip_gemv(C.byref(a), _lib.stream_ptr()))
+        sync()
+        return dy.cpu(), dpool.cpu()
+
+    y_edge, pool_edge = run()
+    monkeypatch.setenv("SSRHIP_GEMVM_EDGE", "0")
+    y_old, pool_old = run()
+    monkeypatch.delenv("SSRHIP_GEMVM_EDGE")
+    assert torch.equal(y_edge, y_old) and torch.equal(pool_edge, pool_old)
+    if epi == 2:
+        torch.testing.assert_close(y_edge, ref[:, :K], rtol=3e-5, atol=3e-5)
+        for b in range(B):
+            p_ = int(pos[b])
+            page = int(table[b, p_ // _lib.PAGE])
+            for which in (0, 1):
+                got = pool_edge[page, layer, which, :, p_ % _lib.PAGE, :].reshape(-1)
+                torch.testing.assert_close(got, ref[b, (1 + which) * K:(2 + which) * K], rtol=3e-5, atol=3e-5)
+    else:
+        torch.testing.assert_close(_from_tiled(y_edge, B, N), ref, rtol=3e-5, atol=3e-5)
+
+
 def test_gemv_mfma_grouped_heads_and_qkv_append(L):
     g = torch.Generator().manual_seed(4)
     G, B, N, K = 4, 11, 72, 1024
@@ -1101,6 +1161,52 @@ def test_gemm_split_result_of_an_item_does_not_depend_on_the_batch(L):
 
     alone, many = run(1), run(B)
     assert torch.equal(alone[0], many[0])
+
+
+@pytest.mark.parametrize("M,N,K,B,tm", [(1500, 512, 1024, 12, False), (777, 1280, 256, 5, False), (130, 640, 64, 3, False), (901, 512, 128, 7, True)])
+def test_gemm_split_xcd_tile_order_changes_nothing(L, monkeypatch, M, N, K, B, tm):
+    """Round 6: `gemm_split_dma_kernel` takes its tile from an XCD-aware remap of the launch index (the N-tiles of a row-tile on one XCD:
+    one fabric read of A instead of one per XCD). The remap only decides WHICH workgroup computes a tile: with it and without it
+    (SSRHIP_GEMM_XCD=0, read at every launch) the outputs must be BIT-identical — grids whose tile count is not a multiple of 8, ragged
+    last tiles in M and N, batches, the residual add, and the transposed convolutions' masked epilogue (`tm`)."""
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(B, M, K, generator=g)
+    Wt = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    R = torch.randn(B, M, N, generator=g)
+    dA, dW, db, dR = dev(A), dev(Wt), dev(bias), dev(R)
+    planes = _split_planes(L, dW)
+
+    def run():
+        out = torch.full((B, M, N), -3.0, device="cuda")
+        a = _lib.GemmArgs()
+        a.A, a.W, a.bias, a.C = dA.data_ptr(), dW.data_ptr(), db.data_ptr(), out.data_ptr()
+        a.M, a.N, a.K, a.lda, a.ldc = M, N, K, K, N
+        a.act_in, a.batch, a.strideA, a.strideC = _lib.ACT_ELU, B, M * K, M * N
+        if tm:
+            a.tm_c, a.tm_lo, a.tm_hi = N // 2, 3, 2 * M - 5
+        else:
+            a.R, a.ldr, a.strideR = dR.data_ptr(), N, M * N
+        a.W_split = planes.data_ptr()
+        _lib.check(L.ssrhip_gemm(C.byref(a), _lib.stream_ptr()))
+        sync()
+        return out.cpu()
+
+    with_remap = run()
+    monkeypatch.setenv("SSRHIP_GEMM_XCD", "0")
+    plain = run()
+    monkeypatch.delenv("SSRHIP_GEMM_XCD")
+    assert torch.equal(with_remap, plain)
+    if tm:
+        assert (with_remap.view(B, 2 * M, N // 2)[:, :3] == -3.0).all() and (with_remap.view(B, 2 * M, N // 2)[:, 2 * M - 5:] == -3.0).all()
+    ref = torch.nn.functional.elu(A[1].double()) @ Wt.double().t() + bias.double() + (0 if tm else R[1].double())
+    got = with_remap[1].double()
+    if tm:
+        keep = torch.zeros(2 * M, dtype=torch.bool)
+        keep[3:2 * M - 5] = True
+        torch.testing.assert_close(got.view(2 * M, N // 2)[keep], ref.view(2 * M, N // 2)[keep], rtol=3e-5, atol=3e-5)
+    else:
+        torch.testing.assert_close(got, ref, rtol=3e-5, atol=3e-5)
 
 
 @pytest.mark.parametrize("Cc", [64, 128])

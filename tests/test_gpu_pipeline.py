@@ -237,6 +237,56 @@ def test_cli_sample_batch_equals_the_sequential_loop(tmp_path):
     assert len(lens) > 1 or True                                 # samples usually differ in length; not required
 
 
+def test_cli_mask_spans_two_and_three_edits_equal_a_direct_call_with_those_intervals(tmp_path):
+    """`--mask_spans 'a-b,c-d[,e-f]'` (inference_v2.py:277-327 derives such spans from the alignment): the command line
+    must hand `inference_one_sample` the merged, frame-rounded intervals and write them to `<savename>_mask.pt`; the wav it writes must
+    equal a direct call with the same `mask_interval` under the same seed. Two far-apart edits, then three of which two merge."""
+    from ssr_speech_amd import inference_v2 as CLI
+    from ssr_speech_amd.data.tokenizer import TextTokenizer, read_wav
+    ccfg = W.CodecConfig(dimension=64, n_filters=8, ratios=(8, 5, 4, 2), bins=64)
+    csd = W.codec_state_dict(ccfg, seed=7)
+    args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
+    lsd = W.lm_state_dict(args, seed=8)
+    for k in range(4):
+        lsd[f"predict_layer.{k}.2.bias"][64:] = -30.0
+    phn2num = {c: i for i, c in enumerate("abcdefghijklmnopqrstuvwxyz")}
+    lm_ckpt, codec_ckpt = str(tmp_path / "lm.pth"), str(tmp_path / "codec.th")
+    torch.save({"config": argparse.Namespace(**vars(args)), "model": lsd, "phn2num": phn2num}, lm_ckpt)
+    torch.save({"codec_config": {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(ccfg).items()}, "model": csd}, codec_ckpt)
+    g = torch.Generator().manual_seed(5)
+    wav_fn = str(tmp_path / "orig.wav")
+    n_frames = 90
+    write_wav(wav_fn, torch.randn(1, n_frames * 320, generator=g) * 0.2, 16000)
+    ids = lambda t: ",".join(str(phn2num[c]) for c in t if c != " ")
+    prompt_text, target = "hello world again", "hello brave new world"
+    for tag, spans, want_frames in [("two", "0.16-0.20,1.20-1.26", [[2, 16], [54, 69]]),
+                                    ("three", "1.20-1.26,0.16-0.20,0.50-0.54", [[2, 33], [54, 69]])]:
+        out_dir = str(tmp_path / tag)
+        CLI.main(["--model_path", lm_ckpt, "--codec_path", codec_ckpt, "--orig_audio", wav_fn, "--orig_transcript", prompt_text,
+                  "--target_transcript", target, "--output_dir", out_dir, "--temp_folder", str(tmp_path / "tmp"), "--savename", "utt",
+                  "--seed", "9", "--top_k", "1", "--top_p", "1.0", "--cfg_stride", "2", "--aug_text", "--mask_spans", spans,
+                  "--phoneme_ids", ids(target), "--prompt_phoneme_ids", ids(prompt_text)])
+        morphed = torch.load(os.path.join(out_dir, "utt_mask.pt"))
+        assert [[round(a * 50), round(b * 50)] for a, b in morphed] == want_frames, morphed
+        got, sr = read_wav(os.path.join(out_dir, "utt_new_seed9.wav"))
+        # the direct call (what the CLI must have done)
+        model = SSR_Speech(argparse.Namespace(**vars(args)))
+        model.load_state_dict(lsd)
+        model = model.to("cuda").eval()
+        tok = AudioTokenizer(device="cuda", signature=codec_ckpt)
+        CLI.seed_everything(9)
+        wav = inference_one_sample(model, argparse.Namespace(**vars(args)), phn2num, FakePhonemizer(), tok, os.path.join(str(tmp_path / "tmp"), "utt_16k.wav"),
+                                   prompt_text, target, torch.LongTensor(want_frames), 1.5, 2, True, False, False, False, "cuda",
+                                   {"top_k": 1, "top_p": 1.0, "temperature": 1, "stop_repetition": 2, "kvcache": 1, "codec_audio_sr": 16000, "codec_sr": 50})
+        write_wav(str(tmp_path / f"direct_{tag}.wav"), wav[0].cpu(), 16000)
+        want, _ = read_wav(str(tmp_path / f"direct_{tag}.wav"))
+        assert sr == 16000 and got.shape == want.shape and torch.equal(got, want), tag
+    with pytest.raises(RuntimeError, match="maximum 3 editings"):
+        CLI.main(["--model_path", lm_ckpt, "--codec_path", codec_ckpt, "--orig_audio", wav_fn, "--orig_transcript", prompt_text,
+                  "--target_transcript", target, "--output_dir", str(tmp_path / "four"), "--savename", "utt", "--mask_spans",
+                  "0.1-0.2,0.5-0.6,1.0-1.1,1.5-1.6", "--phoneme_ids", ids(target), "--prompt_phoneme_ids", ids(prompt_text)])
+
+
 def test_cli_accepts_a_24k_stereo_prompt(tmp_path):
     """The reference resamples --orig_audio to 16 kHz before anything else (inference_v2.py:216-219, librosa); here the same step is
     `data/resample.py`: a 24 kHz stereo prompt gives the outputs of the 16 kHz mono file that the resampler makes of it."""

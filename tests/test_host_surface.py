@@ -115,3 +115,26 @@ def test_split_phonemized_follows_the_reference_symbol_rule():
         line = "".join(rng.choice(alphabet) for _ in range(rng.randint(0, 24)))
         assert split_phonemized(line) == rule(line), line
     assert split_phonemized("a-b|c", word_sep="-", phone_sep="|") == ["a", "-", "b", "c"]
+
+
+def test_edit_spans_follow_the_reference_alignment_to_span_rule(golden_dir):
+    """`--mask_spans`: margins, clipping, sort, the 0.2 s merge rule (>=, in the reference's float arithmetic), frame
+    rounding and the `maximum 3 editings` error, against cases recorded by executing the reference's own statements
+    (oracle/make_golden_spans.py, inference_v2.py:284-317)."""
+    import json
+    from ssr_speech_amd.inference_v2 import edit_spans, parse_mask_spans
+    cases = json.load(open(os.path.join(golden_dir, "edit_spans.json")))["cases"]
+    assert len(cases) >= 12
+    for c in cases:
+        spans = [tuple(s) for s in c["spans"]]
+        if "error" in c["expect"]:
+            with pytest.raises(RuntimeError, match="maximum 3 editings"):
+                edit_spans(spans, c["sub_amount"], c["audio_dur"], c["codec_sr"])
+            continue
+        morphed, mi = edit_spans(spans, c["sub_amount"], c["audio_dur"], c["codec_sr"])
+        assert morphed == c["expect"]["morphed_span"], (c["spans"], morphed)           # exact: the same float operations
+        assert mi.dtype == torch.int64 and mi.tolist() == c["expect"]["mask_interval"]
+    assert parse_mask_spans("0.8-1.2, 2.5-3.1,") == [(0.8, 1.2), (2.5, 3.1)]
+    for bad in ("1.0", "2-1", "-1-2"):
+        with pytest.raises(SystemExit):
+            parse_mask_spans(bad)

@@ -91,3 +91,34 @@ def test_the_launchers_guard_keeps_every_offset_below_the_marker():
         if ok:
             assert biggest_a <= 0x7FFFFFF0 + 16 and biggest_a < OOB and biggest_w < OOB
     assert not ((127 * 5_000_000 + 4096) * 4 < 0x7FFFFFF0)              # a row pitch that does not fit is refused (4-wave kernel instead)
+
+
+def _xcd_tile(nx, ny, nz):
+    """csrc/gemm_split.hip xcd_tile in NumPy: launch index w (x fastest) -> (bx, by, bz) of the logical tile it takes."""
+    total = nx * ny * nz
+    w = np.arange(total, dtype=np.int64)
+    c, j, q, r = w & 7, w >> 3, total >> 3, total & 7
+    L = c * q + np.minimum(c, r) + j
+    return (L % nx), (L // nx) % ny, L // (nx * ny), c
+
+
+@pytest.mark.parametrize("nx,ny,nz", [(4, 469, 256), (10, 94, 256), (1, 7, 1), (3, 1, 1), (2, 5, 3), (17, 13, 11), (8, 8, 8), (5, 1, 9)])
+def test_xcd_tile_order_is_a_bijection_that_keeps_a_row_tile_on_one_xcd(nx, ny, nz):
+    """Round 6: workgroup w runs on XCD w % 8; the remap must (a) hit every tile of the grid exactly once for any grid,
+    including totals that are not multiples of 8, and (b) put the N-tiles of one (row-tile, item) on ONE XCD except where an XCD's
+    contiguous range ends inside a row — at most 7 rows of the whole launch — and there as consecutive workgroups of that XCD."""
+    bx, by, bz, xcd = _xcd_tile(nx, ny, nz)
+    total = nx * ny * nz
+    assert bx.min() >= 0 and bx.max() < nx and by.max() < ny and bz.max() < nz
+    lin = bx + nx * (by + ny * bz)
+    assert np.array_equal(np.sort(lin), np.arange(total))                 # a bijection
+    rows = by + ny * bz
+    split_rows = 0
+    for rr in np.unique(rows):
+        if len(set(xcd[rows == rr].tolist())) > 1:
+            split_rows += 1
+    assert split_rows <= 7
+    # within an XCD the logical tiles come in launch order (consecutive j -> consecutive L): the x-neighbours run back to back
+    for c in range(8):
+        Lc = lin[xcd == c]
+        assert np.array_equal(Lc, np.arange(Lc[0], Lc[0] + len(Lc))) if len(Lc) else True

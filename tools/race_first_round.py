@@ -6,6 +6,11 @@
   early-streams      create the three caller streams and the model's side streams (and touch them) before the calls made alone
   warm-alloc         before the concurrent round, allocate and free on every caller stream what a call allocates (no kernels):
                      the round runs without a single hipMalloc
+  bg-malloc          (with warm-alloc) a host thread maps fresh device memory (torch.empty of ever new sizes on a private stream, never
+                     touched by a kernel) for as long as the round is being enqueued and run: is hipMalloc BESIDE running kernels enough?
+  rounds=N           N - 1 more concurrent rounds behind the first one (outputs compared, no layer map): with the codec's sizing passes on
+                     (SSRHIP_CODEC_PRESIZE, the default since round 6) the first use of a stream synchronises the device, so the
+                     real overlap of the three callers happens from the second round on
   nopipe             the LSTM layers on ONE stream (no side stream)
   nolayers           do not keep the detector's layer outputs (the plain stress test's memory picture)"""
 import os
@@ -28,14 +33,7 @@ if "prewarm-queues" in opts:
             _held.append((s_, torch.zeros(64, device="cuda") + 1))
     torch.cuda.synchronize()
 cfg = W.codec_config_full()
-_sd_path = "/dev/shm/ssr_race_codec_sd21.pt"               # 144 M parameters take 6 s to generate: once per box, not once per trial
-if os.path.exists(_sd_path):
-    _sd = torch.load(_sd_path, mmap=True)
-else:
-    _sd = W.codec_state_dict(cfg, seed=21)
-    torch.save(_sd, _sd_path + f".{os.getpid()}")
-    os.replace(_sd_path + f".{os.getpid()}", _sd_path)
-m = WMEncodecModel(cfg, _sd, "cuda")
+m = WMEncodecModel(cfg, W.codec_state_dict(cfg, seed=21), "cuda")
 g = torch.Generator().manual_seed(19)
 n = cfg.hop * 70 + 11
 Bs = (9, 7, 9)
@@ -99,6 +97,25 @@ if "warm-alloc" in opts:
             del big, mid, small
     torch.cuda.synchronize()
 n_malloc0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
+bg_stop, bg_thread, bg_count = False, None, [0]
+if "bg-malloc" in opts:
+    import threading
+    bg_stream = torch.cuda.Stream()
+
+    def bg_loop():
+        held = []
+        i = 0
+        while not bg_stop:
+            with torch.cuda.stream(bg_stream):
+                held.append(torch.empty((40 << 20) + i * (2 << 20), dtype=torch.uint8, device="cuda"))    # a size nobody freed: a fresh hipMalloc
+            i += 1
+            bg_count[0] += 1
+            if len(held) >= 48:
+                held.clear()                       # back to the bg stream's pool (no hipFree): the next sizes are larger, so still fresh
+        held.clear()
+
+    bg_thread = threading.Thread(target=bg_loop, daemon=True)
+    bg_thread.start()
 got = [None] * 3
 layers_got = []
 for i in (0, 1, 2):
@@ -111,6 +128,10 @@ rec = None
 for st in streams:
     torch.cuda.current_stream().wait_stream(st)
 torch.cuda.synchronize()
+if bg_thread is not None:
+    bg_stop = True
+    bg_thread.join()
+    print(f"background thread made {bg_count[0]} fresh allocations during the round")
 ok = True
 for i in range(3):
     for k, (a, b) in enumerate(zip(alone[i], got[i])):
@@ -137,9 +158,38 @@ if not ok:
                 seen = {}
                 for it, r, ch in w.tolist():
                     seen.setdefault((it, r), []).append(ch)
+                # where do the wrong values come from? (a) the same lanes' result of ANOTHER row of the same buffer (a stale / replayed store-data
+                # beat: rows r +- 16 k are the same lanes' other iterations), (b) one value for the whole group (an input sample that
+                # overwrote the register), (c) neither
+                for (it, r), chs in list(seen.items())[:8]:
+                    bad = db[it, r, chs]
+                    src = None
+                    for d in range(-256, 257):
+                        if d != 0 and 0 <= r + d < da.shape[1] and torch.equal(da[it, r + d, chs], bad):
+                            src = d
+                            break
+                    same = bool((bad == bad[0]).all())
+                    tl = (r - a.padL) % 16
+                    print(f"        item {it} row {r - a.padL} (row % 16 = {tl}: lanes {16 * (tl % 4)}..{16 * (tl % 4) + 15} of wave {tl // 4}): wrong values == the alone pass's row {('%+d' % src) if src is not None else 'none within +-256'}; "
+                          f"all {len(chs)} equal each other: {same}; max |diff| {float((bad - da[it, r, chs]).abs().max()):.3g}")
                 for (it, r), chs in list(seen.items())[:5]:
                     print(f"        item {it} row {r - a.padL}: channels {chs}; alone {[round(float(da[it, r, c_]), 4) for c_ in chs[:6]]} concurrent {[round(float(db[it, r, c_]), 4) for c_ in chs[:6]]}")
                 break
+for rnd in range(1, int(opts.get("rounds", "1"))):
+    more = [None] * 3
+    for i in ((0, 1, 2) if rnd % 2 == 0 else (2, 0, 1)):
+        streams[i].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(streams[i]):
+            more[i] = call(i)
+    for st in streams:
+        torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    for i in range(3):
+        for k, (a, b) in enumerate(zip(alone[i], more[i])):
+            if not torch.equal(a, b):
+                ok = False
+                print(f"FAIL round {rnd} caller {i} {names[k]}: {int((a != b).sum())} differ, max {float((a.float() - b.float()).abs().max()):.3g}")
+print(f"codec: {m.sizing_passes} sizing passes, {m.mallocs_in_flight} driver allocations during sized calls")
 print(f"device mallocs during the round: {torch.cuda.memory_stats().get('num_device_alloc', 0) - n_malloc0}")
 print("first concurrent round:", "identical" if ok else "DIFFERENT")
 sys.exit(0 if ok else 3)
