@@ -262,7 +262,6 @@ class WMEncodecModel:
         # SSRHIP_CODEC_PRESIZE=0 switches the sizing passes off (the A/B arm of tools/race_trials.py).
         self.presize = os.environ.get("SSRHIP_CODEC_PRESIZE", "1") not in ("", "0")
         self._envelopes = {}                 # (entry point, stream) -> [(items, samples-or-frames)] already sized
-        self._dry_hold = []
         self.mallocs_in_flight = 0           # hipMallocs that happened during a call although it had been sized (tests assert 0)
         self.sizing_passes = 0
         env = os.environ.get("SSRHIP_RESBLOCK_FUSE")
@@ -345,13 +344,11 @@ class WMEncodecModel:
         if not any(b >= B and t >= T for b, t in env):
             torch.cuda.synchronize(self.device)                  # nothing in flight, on any stream, while memory is mapped
             real, self.lib = self.lib, _NoLaunch()
-            self._dry_hold = []
             try:
                 run()
             finally:
                 self.lib = real
                 self._keep.pop(stream, None)
-                self._dry_hold = []
             torch.cuda.synchronize(self.device)                  # the dry pass's own fills and copies (torch kernels on garbage)
             self.sizing_passes += 1
             env[:] = [(b, t) for b, t in env if not (b <= B and t <= T)] + [(B, T)]
@@ -568,25 +565,30 @@ class WMEncodecModel:
         if nl == 2 and T > self.LSTM_CHUNK:
             main = torch.cuda.current_stream(dev)
             side = self._side_stream()
-            # every tensor the side stream touches was allocated on `main`: tell the caching allocator (a block freed while the side
-            # stream still has work queued on it must not be handed to a new allocation of `main`). The event chain below already orders
-            # every access (main waits for `fin` before anything is freed); record_stream makes that independent of who frees what when.
-            if os.environ.get("SSRHIP_NO_RECORD_STREAM", "0") in ("", "0"):        # (the knob exists for the experiment in DESIGN.md §4b)
+            # Every tensor the side stream touches was allocated on `main`, and `main` joins the side stream (`fin`) before this function
+            # returns — also when a launch fails half way (the `finally`). A block freed later goes back to MAIN's pool and can only be handed
+            # to an allocation whose kernels run on `main`, i.e. behind `fin`: the stream order alone makes reuse safe. Rounds 4-5 ALSO called
+            # `record_stream(side)` on these tensors; that defers their reuse until the GPU has passed an event recorded at release time — in a
+            # real pass the host is far ahead of the GPU, in a sizing pass (`_sized`) there is nothing to wait for, so the two would allocate
+            # differently and the real pass would map memory while its kernels are in flight. SSRHIP_RECORD_STREAM=1 brings the calls back.
+            if os.environ.get("SSRHIP_RECORD_STREAM", "0") not in ("", "0"):
                 for tns in gins + hbufs + cbufs + [o.data for o in outs] + [x.data] + [h for h in hsplits if h is not None]:
                     tns.record_stream(side)
-            in_gemm(0, 0, T)
-            for t0 in range(0, T, self.LSTM_CHUNK):
-                t1 = min(t0 + self.LSTM_CHUNK, T)
-                steps(0, t0, t1)
-                ev = torch.cuda.Event()
-                ev.record(main)
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)
-                    in_gemm(1, t0, t1)
-                    steps(1, t0, t1)
-            fin = torch.cuda.Event()
-            fin.record(side)
-            main.wait_event(fin)
+            try:
+                in_gemm(0, 0, T)
+                for t0 in range(0, T, self.LSTM_CHUNK):
+                    t1 = min(t0 + self.LSTM_CHUNK, T)
+                    steps(0, t0, t1)
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        in_gemm(1, t0, t1)
+                        steps(1, t0, t1)
+            finally:
+                fin = torch.cuda.Event()
+                fin.record(side)
+                main.wait_event(fin)
         else:
             for l in range(nl):
                 in_gemm(l, 0, T)
@@ -594,13 +596,7 @@ class WMEncodecModel:
         out = outs[-1]
         out.elu = post_elu
         self._fill_pads(out, structural_zero=(nxt is not None and nxt[1] == "convtr"))
-        key = torch.cuda.current_stream(dev).cuda_stream
-        if isinstance(self.lib, _NoLaunch) and key in self._keep:
-            # sizing pass: buffers the side stream touched come back to the pool only when the GPU has passed the event recorded at their
-            # release (record_stream) — in a real pass the host is far ahead of the GPU, so the NEXT LSTM of the same call cannot reuse
-            # them yet. The dry pass has no GPU work to wait for; holding every generation until its end sizes the pool for the worst case.
-            self._dry_hold.append(self._keep[key])
-        self._keep[key] = (gins, hbufs, cbufs, outs, hsplits)
+        self._keep[torch.cuda.current_stream(dev).cuda_stream] = (gins, hbufs, cbufs, outs, hsplits)
         return out
 
     def _side_stream(self):

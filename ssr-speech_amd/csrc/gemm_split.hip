@@ -241,15 +241,26 @@ __device__ unsigned* g_gd_prof = nullptr;                  // [sampled workgroup
 // (w / 8)-th workgroup of that XCD and takes logical tile start(w % 8) + w / 8, where XCD c owns the contiguous range of logical tiles
 // [start(c), start(c + 1)) and logical tiles are numbered x fastest: the N-tiles of one row-tile run on ONE XCD, back to back, and
 // its L2 fetches the A tile once. A bijection of the grid onto itself (tests/test_split_gemm_addressing_model.py), results unchanged.
+// Second measurement of the round (profiles/r06_microbench/codec256_fetch_xcd_*.md): with ALL N-tiles of a row-tile on one XCD the A
+// traffic fell (60001 x 512 x 512: 91 -> 40 GB for a 31.5 GB operand) but launches whose W planes do not fit an XCD's 4 MB L2 got WORSE
+// (12001 x 1280 x 1024 stayed at 161-197 GB, two K >= 1024 shapes tripled): in blockIdx order an XCD only ever touched nx / gcd(nx, 8) of
+// the N-tiles, now it cycles through all of them and re-fetches every 0.4-0.8 MB W tile per workgroup. So the logical order is N-tile
+// GROUPS: GN = flags >> 8 consecutive N-tiles (host: as many as keep GN W tiles within ~2.5 MB) are swept over every row-tile and item
+// before the next group starts; inside a group x is fastest. One fabric read of an A tile per group, W tiles of the group resident.
 __device__ __forceinline__ void xcd_tile(const int flags, int& bx, int& by, int& bz) {
   bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
   if (!(flags & 2)) return;
-  const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+  const unsigned nx = gridDim.x, ny = gridDim.y, nyz = ny * gridDim.z, total = nx * nyz;
   const unsigned w = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
   const unsigned c = w & 7u, j = w >> 3, q = total >> 3, r = total & 7u;
-  const unsigned L = c * q + (c < r ? c : r) + j;                    // XCD c owns q + (c < r) logical tiles
-  bx = (int)(L % nx);
-  const unsigned t2 = L / nx;
+  const unsigned L = c * q + (c < r ? c : r) + j;                    // XCD c owns q + (c < r) logical tiles, a contiguous range
+  unsigned gn = (unsigned)flags >> 8;
+  if (gn == 0 || gn > nx) gn = nx;
+  const unsigned per_group = gn * nyz, g = L / per_group;            // full groups first; the last one may be narrower
+  const unsigned idx = L - g * per_group;
+  const unsigned width = (g * gn + gn <= nx) ? gn : nx - g * gn;
+  bx = (int)(g * gn + idx % width);
+  const unsigned t2 = idx / width;
   by = (int)(t2 % ny);
   bz = (int)(t2 / ny);
 }
@@ -564,7 +575,13 @@ int ssrhip_gemm_split_launch(const ssrhip_gemm_args* a, hipStream_t s) {
   static const int wide1 = !(getenv("SSRHIP_EPILOGUE_WIDE") && getenv("SSRHIP_EPILOGUE_WIDE")[0] == '0');     // A/B knob: 0 = dword epilogue
   // XCD-aware tile order of the DMA kernels (read at every launch: tests flip it inside one process); total tiles must fit 32 bits
   const char* xe = getenv("SSRHIP_GEMM_XCD");
-  const int flags0 = wide1 | ((xe && xe[0] == '0') ? 0 : 2);
+  // N-tile group width of the XCD order: W tiles of one group (3 bf16 planes of 128 rows x K) within ~2.5 MB of an XCD's 4 MB L2
+  const long wtile = 128L * a->K * 6;
+  long gn = wtile > 0 ? (2560L * 1024) / wtile : 1;
+  if (gn < 1) gn = 1;
+  if (gn > 255) gn = 255;
+  if (xe && xe[0] >= '1' && xe[0] <= '9' && xe[1] == ':') gn = atoi(xe + 2) > 0 ? atoi(xe + 2) : gn;   // "1:<GN>": force the group width (lab)
+  const int flags0 = wide1 | ((xe && xe[0] == '0') ? 0 : 2) | (int)(gn << 8);
   // the transposed convolutions' time mask as a row predicate of the 16-byte epilogue (SSRHIP_EPILOGUE_TM=0: the general per-element loop)
   static const bool tm_knob = !(getenv("SSRHIP_EPILOGUE_TM") && getenv("SSRHIP_EPILOGUE_TM")[0] == '0');
   const bool tmf = tm_knob && wide1 && a->tm_c > 0 && a->N % a->tm_c == 0 && a->tm_c % 4 == 0 && !a->R && !a->residual && !a->rbias && a->ldc % 4 == 0 &&

@@ -493,7 +493,14 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
 //     both tiles on weights that are resident or in flight. Partial tiles, merge order and epilogue as in gemv_rows_xreg_kernel.
 // 12 waves are 3 per SIMD: 168 VGPRs per wave, of which the resident weights take 128 (NT = 2) — x' therefore stays in LDS and is read
 // one k-step ahead. Host-selected when every workgroup owns exactly NT tiles (QKV: 3 units, FFN1: 4 units -> NT = 2; head MLP: 2 units ->
-// NT = 1), x is tiled and K = 2048; SSRHIP_GEMVM_EDGE=0 (read at every launch) = the 8-wave kernel.
+// NT = 1), x is tiled and K = 2048.
+// MEASURED (profiles/r06_microbench/gemvm_bench_16_edge.log, bench_n1_8utts_edge*.json; bit-identical outputs): it LOSES — LN + QKV 17.5
+// against 15.3-16.0 us, LN + FFN1 20.3 against 15.8-16.0, head MLP 12.9 against 12.2; the 16-row step 1.521 against 1.410 ms. With every
+// request posted up front the posting phase simply lasts as long as the stream (FFN1: 262 KB per CU in ~12 us = 5.6 TB/s chip-wide —
+// that, not 7.3 TB/s, is what this access pattern gets), and the matrix work that the 8-wave kernel overlaps with its refills now waits
+// behind all of it. The premise "the LayerNorm is what delays the stream" was wrong: the stream is the critical path, the 8-wave kernel
+// already hides the LayerNorm under the first 128 KB per CU. Kept as an OPT-IN (SSRHIP_GEMVM_EDGE=1, read at every launch) with its
+// bit-identity test, like the other recorded negatives.
 constexpr int EDGE_XS_BYTES = 128 * 1024;                 // x': 128 k-steps x 1 KiB
 constexpr int edge_lds(int NT) { return EDGE_XS_BYTES + NT * 8 * 1024 + 2 * 8 * 16 * 4; }
 
@@ -814,10 +821,10 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s) {
     dim3 grid(r.wgs, a->groups), block(r.nw * 64);
     // every workgroup owns exactly one 8-row unit (out-proj, FFN2) and the weights are in streaming order: k-step pairs per load
     const bool pair = a->w_tiled && r.units <= r.wgs && r.steps % 2 == 0 && !g_nopair;
-    // round 6: LayerNorm launches with the LayerNorm on four extra waves and every weight request posted at entry (gemv_rows_edge_kernel)
+    // round 6, opt-in (measured slower): LayerNorm launches with the LayerNorm on four extra waves and every weight request posted at entry
     const char* ee = getenv("SSRHIP_GEMVM_EDGE");
     const int per = r.wgs > 0 ? r.units / r.wgs : 0;
-    if (a->pro == SSRHIP_PRO_LAYERNORM && a->K == 2048 && a->x_tiled && !(ee && ee[0] == '0') && g_wpc == 1 && a->groups == 1 &&
+    if (a->pro == SSRHIP_PRO_LAYERNORM && a->K == 2048 && a->x_tiled && ee && ee[0] == '1' && g_wpc == 1 && a->groups == 1 &&
         r.units % r.wgs == 0 && per >= 1 && per <= 4) {
       static ssr_once_per_device once;
       if (once.need()) {

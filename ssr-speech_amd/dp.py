@@ -123,13 +123,17 @@ def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token
     if caps is not None:
         assert len(caps) == n_total, (len(caps), n_total)
         t_cap = max(max((int(c) for c in caps), default=1), 1)
-        if ok and any(int(t.shape[1]) > t_cap or int(t.shape[0]) != K for t in local):
-            ok = False                                                # a length beyond its bound must not corrupt the block: fail everywhere instead
+        if ok and any(int(t.shape[0]) != K for t in local):
+            ok = False
+        # a result longer than its bound (`token_cap` is derived from the reference's stop rules; an engine-side cap or a caller's own
+        # `caps` may be tighter than what came out) must neither corrupt the block nor abort the job: the rank says so in
+        # its header (2) and EVERY rank — they all read the same headers — then takes the two-collective path that exchanges lengths
+        over = bool(ok) and any(int(t.shape[1]) > t_cap for t in local)
         head = 2 + n_max
         mine = torch.full((head + n_max * K * t_cap,), int(pad_token), dtype=torch.int32)
-        mine[0], mine[1] = int(bool(ok)), len(local) if ok else 0
+        mine[0], mine[1] = (2 if over else int(bool(ok))), len(local) if ok else 0
         mine[2:head] = 0
-        if ok:
+        if ok and not over:
             body = mine[head:].view(n_max, K, t_cap)
             for i, t in enumerate(local):
                 mine[2 + i] = int(t.shape[1])
@@ -138,9 +142,11 @@ def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token
         out = torch.empty(world * mine.numel(), dtype=torch.int32, device=device)
         dist.all_gather_into_tensor(out, mine)
         out = out.view(world, -1).cpu()
-        bad = [r for r in range(world) if int(out[r, 0]) != 1]
+        bad = [r for r in range(world) if int(out[r, 0]) == 0]
         if bad:
             raise RuntimeError(f"dp.gather_tokens: the decode failed on rank(s) {bad}" + (" (this rank among them)" if rank in bad else ""))
+        if any(int(out[r, 0]) == 2 for r in range(world)):
+            return _gather_with_lengths(local, n_total, K, pad_token, device, owners, n_max)
         res: List[torch.Tensor] = [None] * n_total
         for r in range(world):
             assert int(out[r, 1]) == len(owners[r]), (r, int(out[r, 1]), len(owners[r]))
@@ -150,6 +156,14 @@ def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token
         return res
     if not ok:
         raise RuntimeError("dp.gather_tokens: the decode failed on this rank and no `caps` were given (the other ranks cannot be told)")
+    return _gather_with_lengths(local, n_total, K, pad_token, device, owners, n_max)
+
+
+def _gather_with_lengths(local, n_total: int, K: int, pad_token: int, device, owners, n_max: int) -> List[torch.Tensor]:
+    """Two collectives: the lengths, then a block padded to the longest result of the job (callers without a bound on their lengths, and
+    the fall-back of the one-collective path when a result came out longer than its bound)."""
+    import torch.distributed as dist
+    world = dist.get_world_size()
     lens = torch.zeros(n_max, dtype=torch.int32, device=device)
     for i, t in enumerate(local):
         lens[i] = t.shape[1]
@@ -158,7 +172,7 @@ def gather_tokens(local: Sequence[torch.Tensor], n_total: int, K: int, pad_token
     t_max = int(all_lens.max().item())
     block = torch.full((n_max, K, max(t_max, 1)), pad_token, dtype=torch.int32, device=device)
     for i, t in enumerate(local):
-        block[i, :, : t.shape[1]] = t.to(torch.int32)
+        block[i, :, : t.shape[1]] = t.to(device, torch.int32)
     out = torch.empty((world,) + tuple(block.shape), dtype=torch.int32, device=device)
     dist.all_gather_into_tensor(out.view(-1), block.view(-1))
     all_lens = all_lens.view(world, n_max)

@@ -80,10 +80,17 @@ def _worker(rank, world, port, n_total, q):
     calls.clear()
     allt = dp.gather_tokens(local, n_total, 4, pad_token=2048, caps=[16] * n_total)  # bounded lengths: ONE fixed-layout block
     ok = ok and len(allt) == n_total and all(torch.equal(allt[i], _tokens(i)) for i in range(n_total)) and calls == {"all_gather_into_tensor": 1}
-    # a length beyond its bound on ONE rank: that rank reports failure inside the block and every rank raises — nobody hangs
+    # a length beyond its bound on ONE rank (rank 1's results do not fit caps = 4): no abort, no corrupted block — that rank flags it in
+    # the block's header and EVERY rank falls back to the length exchange: the right tokens everywhere, three collectives in all
+    calls.clear()
+    mine = [t[:, :3] for t in local] if rank == 0 else local
+    allt = dp.gather_tokens(mine, n_total, 4, pad_token=2048, caps=[4] * n_total)
+    s0, e0 = dp.shard_range(n_total, world, 0)
+    want = [(_tokens(i)[:, :3] if s0 <= i < e0 else _tokens(i)) for i in range(n_total)]
+    ok = ok and all(torch.equal(allt[i], want[i]) for i in range(n_total)) and calls == {"all_gather_into_tensor": 3}
+    # a rank whose decode FAILED still takes part, and every rank raises naming it — nobody hangs
     try:
-        dp.gather_tokens(local, n_total, 4, pad_token=2048, caps=[16] * n_total if rank == 0 else [16] * (n_total - 1) + [16])
-        dp.gather_tokens([t[:, :3] for t in local] if rank == 0 else local, n_total, 4, pad_token=2048, caps=[4] * n_total)
+        dp.gather_tokens(local if rank == 0 else [], n_total, 4, pad_token=2048, caps=[16] * n_total, ok=(rank == 0))
         ok = False
     except RuntimeError as ex:
         ok = ok and "rank(s) [1]" in str(ex)

@@ -361,8 +361,8 @@ def test_codec_calls_on_concurrent_streams_equal_the_single_stream_results():
     per-process trials (tools/race_trials.py, profiles/r06_microbench/) named the conditions — kernels of several hardware queues in
     flight while the caching allocator maps fresh device memory — and the codec now sizes every new (entry point, stream, shape) with
     the device idle (`WMEncodecModel._sized`): the first use of a stream is a sizing pass, the overlap of the three callers is real
-    from then on, and no real pass may reach the driver for memory (`mallocs_in_flight == 0`, asserted below). Cross-stream tensors are
-    pinned with record_stream and every hand-over is an event (wmencodec._lstm)."""
+    from then on, and no real pass may reach the driver for memory (`mallocs_in_flight == 0`, asserted below). Every hand-over to the LSTM
+    side stream is an event and the calling stream joins it before the layer returns (wmencodec._lstm)."""
     cfg = W.codec_config_full()
     sd = W.codec_state_dict(cfg, seed=21)
     m = WMEncodecModel(cfg, sd, "cuda")
@@ -399,8 +399,8 @@ def test_codec_calls_on_concurrent_streams_equal_the_single_stream_results():
                                          f"{bad.shape[0]} elements differ, max |diff| {float((a.float() - b.float()).abs().max()):.3g}, "
                                          f"first at {bad[0].tolist()}, last at {bad[-1].tolist()}")
     # alone: 3 entry points on the default stream (batch 9 covers batch 7); concurrent: 3 entry points on each of 3 new streams
-    assert m.sizing_passes == 3 + 9, m.sizing_passes
     assert m.mallocs_in_flight == 0, f"{m.mallocs_in_flight} driver allocations happened while sized codec passes were in flight"
+    assert m.sizing_passes == 3 + 9, m.sizing_passes
 
 
 def test_sized_codec_calls_never_reach_the_driver_for_memory_and_change_no_result():
@@ -457,4 +457,7 @@ def test_reference_fixtures_under_every_surviving_codec_knob(knob):
                          env=dict(os.environ, **{name: val}), cwd=root, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-2000:]
+    import re as _re
+    n_passed = int(_re.search(r"(\d+) passed", out.stdout).group(1))
+    assert n_passed >= 8, f"the -k expression selected only {n_passed} tests: {out.stdout[-500:]}"   # (a renamed test must not shrink this silently)
 

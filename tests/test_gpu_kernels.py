@@ -165,7 +165,8 @@ def test_gemv_rows_edge_kernel_is_bit_identical_to_the_eight_wave_kernel(L, monk
     """Round 6 (`gemv_rows_edge_kernel`, csrc/gemv_mfma.hip): the 5..16-row LayerNorm launches at K = 2048 with the LayerNorm on four extra
     waves (x' handed over through LDS) and every weight request posted at entry. It computes the statistics in the same slices, order
     and expressions as `gemv_rows_xreg_kernel`, so outputs — q, the appended K / V rows, the FFN hidden, the head hidden — must be
-    BIT-identical with the knob on and off (SSRHIP_GEMVM_EDGE, read at every launch), and within the GEMV tolerance of torch.
+    BIT-identical with the knob on and off (SSRHIP_GEMVM_EDGE=1, read at every launch; the default is the 8-wave kernel: the edge form
+    measured slower, profiles/r06_microbench/gemvm_bench_16_edge.log), and within the GEMV tolerance of torch.
     Shapes: QKV with the cache append (3 units per workgroup: a 16-row and an 8-row tile), FFN1 (two 16-row tiles), the head MLP (one
     tile), and N = 2048 (one 8-row unit per workgroup)."""
     from ssr_speech_amd.engine import to_streaming_order
@@ -202,10 +203,10 @@ def test_gemv_rows_edge_kernel_is_bit_identical_to_the_eight_wave_kernel(L, monk
         sync()
         return dy.cpu(), dpool.cpu()
 
+    monkeypatch.setenv("SSRHIP_GEMVM_EDGE", "1")
     y_edge, pool_edge = run()
-    monkeypatch.setenv("SSRHIP_GEMVM_EDGE", "0")
-    y_old, pool_old = run()
     monkeypatch.delenv("SSRHIP_GEMVM_EDGE")
+    y_old, pool_old = run()
     assert torch.equal(y_edge, y_old) and torch.equal(pool_edge, pool_old)
     if epi == 2:
         torch.testing.assert_close(y_edge, ref[:, :K], rtol=3e-5, atol=3e-5)

@@ -112,6 +112,9 @@ def test_prefill_on_the_fp32_chain_matches_the_reference_too():
                          env=dict(os.environ, SSRHIP_PREFILL_SPLIT="0"), cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-2000:]
+    import re as _re
+    n_passed = int(_re.search(r"(\d+) passed", out.stdout).group(1))
+    assert n_passed >= 20, f"the -k expression selected only {n_passed} tests: {out.stdout[-500:]}"   # (a renamed test must not shrink this silently)
 
 
 def test_contract_errors():
@@ -261,11 +264,20 @@ def test_dp_generate_single_rank_equals_inference_batch():
     utts = [dict(x=torch.randint(0, 30, (1, 6 + i), generator=g), y=torch.randint(0, 64, (1, 10 + 2 * i, 4), generator=g),
                  mask_interval=torch.LongTensor([[[10 + 2 * i, 10 + 2 * i]]])) for i in range(5)]
     kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, silence_tokens=[3, 7, 11], cfg_coef=1.5, cfg_stride=2, aug_text=True)
+    # two multi-span edits ride along (2 and 3 spans): the one-collective gather relies on `dp.token_cap` being a true upper bound of
+    # every result's length, whatever the span layout
+    utts.append(dict(x=torch.randint(0, 30, (1, 9), generator=g), y=torch.randint(0, 64, (1, 24, 4), generator=g),
+                     mask_interval=torch.LongTensor([[[3, 6], [12, 16]]])))
+    utts.append(dict(x=torch.randint(0, 30, (1, 11), generator=g), y=torch.randint(0, 64, (1, 30, 4), generator=g),
+                     mask_interval=torch.LongTensor([[[2, 5], [10, 13], [20, 26]]])))
     toks, (mine, outs) = dp.generate(m, utts, seed=9, **kw)
     ref = m.inference_batch(utts, seed=9, **kw)
-    assert mine == [0, 1, 2, 3, 4] and len(toks) == 5
-    for i in range(5):
+    assert mine == list(range(7)) and len(toks) == 7
+    for i in range(7):
         assert torch.equal(toks[i], ref[i][0][0])
+        u = utts[i]
+        cap = dp.token_cap(u["x"].shape[-1], u["y"].shape[1], int(u["mask_interval"].shape[-2]), 4)
+        assert toks[i].shape[-1] <= cap, (i, toks[i].shape, cap)
 
 
 def test_full_830m_ten_rows_match_oracle_on_cpu():

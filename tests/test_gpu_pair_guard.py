@@ -143,8 +143,10 @@ def test_two_engines_stepping_concurrently_on_two_streams_equal_their_runs_alone
 
 
 @pytest.mark.parametrize("squat_ms,must_raise", [(150.0, False), (2500.0, False), (9000.0, True)])
-def test_a_kernel_squatting_on_half_the_cus_delays_or_raises_but_never_corrupts(arena, squat_ms, must_raise):
-    """128 workgroups that hold 140 KB of LDS each (nothing else fits on their CUs) spin on a side stream while a paired chain steps.
+def test_a_kernel_squatting_on_most_cus_delays_or_raises_but_never_corrupts(arena, squat_ms, must_raise):
+    """200 workgroups that hold 140 KB of LDS each (nothing else fits on their CUs) spin on a side stream while a paired chain steps: the
+    56 CUs left hold 112 pair workgroups (two fit a CU; with 128 squatters all 256 still found room and a 9 s squat only slowed the step,
+    round 6's second run), so the launch cannot become resident as a whole.
     Leaves in time: the pair launch waits for its missing workgroups and the tokens are the usual ones. Stays longer than the spin
     bound (400,000 gather sweeps: ~1 s on an idle GPU, a few seconds when 128 CUs' worth of waves poll at once — the 2.5 s squatter of
     round 6's first run was waited out): the launch gives up, `states()` raises, and the engine — now without pair launches — decodes
@@ -160,7 +162,7 @@ def test_a_kernel_squatting_on_half_the_cus_delays_or_raises_but_never_corrupts(
     eng.start(rows, [cated], [kn])
     torch.cuda.synchronize()
     t0 = time.time()
-    _lib.check(L.ssrhip_debug_occupy(128, 140 * 1024, squat_ms, side.cuda_stream), "ssrhip_debug_occupy")
+    _lib.check(L.ssrhip_debug_occupy(200, 140 * 1024, squat_ms, side.cuda_stream), "ssrhip_debug_occupy")
     time.sleep(0.02)                                                        # the squatters are resident before the chain starts
     eng.decode(STEPS)
     raised = False

@@ -93,32 +93,45 @@ def test_the_launchers_guard_keeps_every_offset_below_the_marker():
     assert not ((127 * 5_000_000 + 4096) * 4 < 0x7FFFFFF0)              # a row pitch that does not fit is refused (4-wave kernel instead)
 
 
-def _xcd_tile(nx, ny, nz):
-    """csrc/gemm_split.hip xcd_tile in NumPy: launch index w (x fastest) -> (bx, by, bz) of the logical tile it takes."""
+def _xcd_tile(nx, ny, nz, gn=0):
+    """csrc/gemm_split.hip xcd_tile in NumPy: launch index w (x fastest) -> (bx, by, bz) of the logical tile it takes; gn = N-tile group width."""
     total = nx * ny * nz
     w = np.arange(total, dtype=np.int64)
     c, j, q, r = w & 7, w >> 3, total >> 3, total & 7
     L = c * q + np.minimum(c, r) + j
-    return (L % nx), (L // nx) % ny, L // (nx * ny), c
+    if gn == 0 or gn > nx:
+        gn = nx
+    per_group = gn * ny * nz
+    g = L // per_group
+    idx = L - g * per_group
+    width = np.where(g * gn + gn <= nx, gn, nx - g * gn)
+    bx = g * gn + idx % width
+    t2 = idx // width
+    return bx, t2 % ny, t2 // ny, c, L
 
 
-@pytest.mark.parametrize("nx,ny,nz", [(4, 469, 256), (10, 94, 256), (1, 7, 1), (3, 1, 1), (2, 5, 3), (17, 13, 11), (8, 8, 8), (5, 1, 9)])
-def test_xcd_tile_order_is_a_bijection_that_keeps_a_row_tile_on_one_xcd(nx, ny, nz):
-    """Round 6: workgroup w runs on XCD w % 8; the remap must (a) hit every tile of the grid exactly once for any grid,
-    including totals that are not multiples of 8, and (b) put the N-tiles of one (row-tile, item) on ONE XCD except where an XCD's
-    contiguous range ends inside a row — at most 7 rows of the whole launch — and there as consecutive workgroups of that XCD."""
-    bx, by, bz, xcd = _xcd_tile(nx, ny, nz)
+@pytest.mark.parametrize("nx,ny,nz,gn", [(4, 469, 256, 0), (10, 94, 256, 3), (10, 94, 3, 4), (1, 7, 1, 0), (3, 1, 1, 2), (2, 5, 3, 1), (17, 13, 11, 5), (8, 8, 8, 8),
+                                         (5, 1, 9, 2), (64, 47, 2, 13)])
+def test_xcd_tile_order_is_a_bijection_that_keeps_a_row_tile_on_one_xcd(nx, ny, nz, gn):
+    """Round 6: workgroup w runs on XCD w % 8; the remap must (a) hit every tile of the grid exactly once for any grid
+    and any group width, including totals that are not multiples of 8 and a narrower last group, (b) give every XCD a contiguous range of
+    the logical order, in which (c) the N-tiles of one (row-tile, item) that belong to the same group are neighbours, and (d) a group's
+    N-tiles are swept over all row-tiles and items before the next group starts (the W tiles of a group stay in that XCD's L2)."""
+    bx, by, bz, xcd, L = _xcd_tile(nx, ny, nz, gn)
     total = nx * ny * nz
-    assert bx.min() >= 0 and bx.max() < nx and by.max() < ny and bz.max() < nz
+    assert bx.min() >= 0 and bx.max() < nx and by.min() >= 0 and by.max() < ny and bz.min() >= 0 and bz.max() < nz
     lin = bx + nx * (by + ny * bz)
     assert np.array_equal(np.sort(lin), np.arange(total))                 # a bijection
-    rows = by + ny * bz
-    split_rows = 0
-    for rr in np.unique(rows):
-        if len(set(xcd[rows == rr].tolist())) > 1:
-            split_rows += 1
-    assert split_rows <= 7
-    # within an XCD the logical tiles come in launch order (consecutive j -> consecutive L): the x-neighbours run back to back
     for c in range(8):
-        Lc = lin[xcd == c]
-        assert np.array_equal(Lc, np.arange(Lc[0], Lc[0] + len(Lc))) if len(Lc) else True
+        Lc = L[xcd == c]
+        if len(Lc):
+            assert np.array_equal(Lc, np.arange(Lc[0], Lc[0] + len(Lc)))  # contiguous, in launch order
+    g_eff = nx if (gn == 0 or gn > nx) else gn
+    order = np.argsort(L)
+    bxo, byo, bzo = bx[order], by[order], bz[order]
+    grp = bxo // g_eff
+    assert np.all(np.diff(grp) >= 0)                                      # (d) groups in order, each finished before the next
+    same_row = (byo[1:] == byo[:-1]) & (bzo[1:] == bzo[:-1]) & (grp[1:] == grp[:-1])
+    assert np.all(bxo[1:][same_row] == bxo[:-1][same_row] + 1)            # (c) x fastest inside a group
+    n_runs = len(set(zip(grp.tolist(), byo.tolist(), bzo.tolist())))            # one run of neighbours per (group, row-tile, item)
+    assert same_row.sum() == total - n_runs
