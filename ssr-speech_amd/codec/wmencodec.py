@@ -51,6 +51,15 @@ class _NoLaunch:
         return lambda *args: 0
 
 
+def _tensors_of(obj):
+    """the tensors inside a (nested) tuple / list result"""
+    if isinstance(obj, torch.Tensor):
+        return [obj]
+    if isinstance(obj, (tuple, list)):
+        return [t for o in obj for t in _tensors_of(o)]
+    return []
+
+
 def _device_mallocs(device) -> int:
     """How many times the caching allocator has gone to the driver for memory on this device (hipMalloc calls)."""
     return int(torch.cuda.memory_stats(device).get("num_device_alloc", 0))
@@ -345,7 +354,11 @@ class WMEncodecModel:
             torch.cuda.synchronize(self.device)                  # nothing in flight, on any stream, while memory is mapped
             real, self.lib = self.lib, _NoLaunch()
             try:
-                run()
+                dry_out = run()
+                # room for ONE more generation of the results: a caller that still holds the previous call's outputs while this one runs
+                # (`out = codec.decode(...)` in a loop) must not push the real pass to the driver either
+                spare = [torch.empty_like(t) for t in _tensors_of(dry_out)]
+                del spare, dry_out
             finally:
                 self.lib = real
                 self._keep.pop(stream, None)

@@ -894,12 +894,13 @@ __global__ __launch_bounds__(SEG_TH, 2) void gemv_segu_kernel(const GemvK p) {
 //     buffers, cyclically closed over the step so that graph replays stay consistent).
 // Every partial sum, every statistic and every epilogue is computed by the same operations in the same order as in the two launches
 // (tests compare bit for bit; tools/layer_edge_lab.hip compared 192 chained edges).
-// The spin is bounded (~1 s): a workgroup that gives up sets ws->gave_up and results are garbage from there on — the host checks the
+// The spin is bounded (1 s of the 100 MHz clock): a workgroup that gives up sets ws->gave_up and results are garbage from there on — the host checks the
 // flag (ssrhip_gemv_pair_status) and raises. The launch needs all its 256 workgroups resident at the same time: true on an otherwise
 // idle or ordinarily busy GPU (other kernels finish and make room), NOT when a second pair launch of another stream / process holds
 // half the CUs at the same moment — one decode chain per device, or SSRHIP_GEMV_PAIR=0.
 constexpr int PAIR_D = 2048, PAIR_NE = 4, PAIR_TH = SEG_TH + 64 * PAIR_NE, PAIR_GRAN = 2 * PAIR_D, PAIR_PF = 3, PAIR_DEPTH = 4, PAIR_NUWA = 8;
-constexpr int PAIR_SPINS = 400000;
+constexpr int PAIR_SPINS = 4000000;                       // a second bound only; the first is PAIR_WAIT_TICKS
+constexpr long long PAIR_WAIT_TICKS = 100000000;           // 1 s of wall_clock64 (100 MHz)
 struct PairK {
   GemvK a, b;
   unsigned long long* gran;        // this launch's granules [PAIR_GRAN]: index n * 2 + row
@@ -1055,6 +1056,9 @@ __device__ __forceinline__ void pair_edge_role(const PairK& p, int e, int lane, 
   pair_v4f g[8];
   bool done = false;
   const int max_spins = (*p.gave_up != 0) ? 64 : PAIR_SPINS;
+  // the bound is TIME (round 6): ~1 s of the constant 100 MHz clock, looked at every 256 sweeps. The sweep count alone (rounds 5) meant
+  // anything from 1 s on an idle GPU to well over 9 s when a hundred CUs' worth of edge waves poll the same lines (tests/test_gpu_pair_guard.py)
+  const long long t_begin = wall_clock64();
   for (int spin = 0; spin < max_spins && !done; ++spin) {
     bool all = true;
     pair_sweep8(p.gran + (size_t)e * 1024 + lane * 2, g);
@@ -1066,7 +1070,10 @@ __device__ __forceinline__ void pair_edge_role(const PairK& p, int e, int lane, 
       xs[PAIR_D + (gi >> 1)] = g[i][2];
     }
     done = __all(all);
-    if (!done) __builtin_amdgcn_s_sleep(2);
+    if (!done) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((spin & 255) == 255 && wall_clock64() - t_begin > PAIR_WAIT_TICKS) break;
+    }
   }
   if (!done && lane == 0) *p.gave_up = 1;
   __syncthreads();                                                  // (2)

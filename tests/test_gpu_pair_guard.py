@@ -142,15 +142,14 @@ def test_two_engines_stepping_concurrently_on_two_streams_equal_their_runs_alone
         e.close()
 
 
-@pytest.mark.parametrize("squat_ms,must_raise", [(150.0, False), (2500.0, False), (9000.0, True)])
+@pytest.mark.parametrize("squat_ms,must_raise", [(150.0, False), (2500.0, True)])
 def test_a_kernel_squatting_on_most_cus_delays_or_raises_but_never_corrupts(arena, squat_ms, must_raise):
     """200 workgroups that hold 140 KB of LDS each (nothing else fits on their CUs) spin on a side stream while a paired chain steps: the
     56 CUs left hold 112 pair workgroups (two fit a CU; with 128 squatters all 256 still found room and a 9 s squat only slowed the step,
     round 6's second run), so the launch cannot become resident as a whole.
     Leaves in time: the pair launch waits for its missing workgroups and the tokens are the usual ones. Stays longer than the spin
-    bound (400,000 gather sweeps: ~1 s on an idle GPU, a few seconds when 128 CUs' worth of waves poll at once — the 2.5 s squatter of
-    round 6's first run was waited out): the launch gives up, `states()` raises, and the engine — now without pair launches — decodes
-    correctly again. The middle case may go either way; it must never return wrong tokens."""
+    bound (1 s of the constant 100 MHz clock since round 6; the sweep count of round 5 waited out a 9 s squatter): the launch gives up,
+    `states()` raises within about a second, and the engine — now without pair launches — decodes correctly again."""
     args, ar = arena
     inp = _inputs(args, 31)
     eng = _engine(ar)
@@ -174,7 +173,7 @@ def test_a_kernel_squatting_on_most_cus_delays_or_raises_but_never_corrupts(aren
         assert "gave up" in str(e)
     dt = time.time() - t0
     torch.cuda.synchronize()
-    assert dt < 4.0 + squat_ms / 1000.0, f"{dt:.1f} s: the wait is bounded"
+    assert dt < 3.0 + (0.0 if must_raise else squat_ms / 1000.0), f"{dt:.1f} s: the wait is bounded by the clock, not by the squatter"
     if must_raise:
         assert raised, f"a {squat_ms:.0f} ms squatter must trip the spin bound"
     if raised:
