@@ -271,6 +271,7 @@ class WMEncodecModel:
         # SSRHIP_CODEC_PRESIZE=0 switches the sizing passes off (the A/B arm of tools/race_trials.py).
         self.presize = os.environ.get("SSRHIP_CODEC_PRESIZE", "1") not in ("", "0")
         self._envelopes = {}                 # (entry point, stream) -> [(items, samples-or-frames)] already sized
+        self._small_reserved = set()
         self.mallocs_in_flight = 0           # hipMallocs that happened during a call although it had been sized (tests assert 0)
         self.sizing_passes = 0
         env = os.environ.get("SSRHIP_RESBLOCK_FUSE")
@@ -358,6 +359,11 @@ class WMEncodecModel:
                 # room for ONE more generation of the results: a caller that still holds the previous call's outputs while this one runs
                 # (`out = codec.decode(...)` in a loop) must not push the real pass to the driver either
                 spare = [torch.empty_like(t) for t in _tensors_of(dry_out)]
+                # ... and for a SMALLER shape later on: every large block can be split for a smaller request, but tensors that shrink below
+                # the allocator's 1 MB class boundary move to its small pool (2 MB segments) — 32 MB of those per stream, once
+                if stream not in self._small_reserved:
+                    spare += [torch.empty((1 << 20) - 4096, dtype=torch.uint8, device=self.device) for _ in range(32)]
+                    self._small_reserved.add(stream)
                 del spare, dry_out
             finally:
                 self.lib = real

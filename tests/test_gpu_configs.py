@@ -51,7 +51,7 @@ def test_config2_830m_sampled_top_k40_top_p08_matches_oracle():
     codes, _, _ = tokenize_audio(tok, os.path.join(gold, "demo_5895_34622_000026_000002_160f.wav"))
     assert tuple(codes.shape) == (1, 4, facts["frames_320"]) == (1, 4, N)
     y = codes.transpose(2, 1).cpu().contiguous()
-    assert len(np.unique(y.numpy())) > 100                              # real audio through the RVQ: not a constant
+    assert len(np.unique(y.numpy())) > 20                               # real audio through a (random-weight) RVQ: not a constant
     del tok
     unc = torch.randint(0, 101, (1, L), generator=gen)
     mi = torch.LongTensor([[[N, N]]])
