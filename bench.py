@@ -64,8 +64,7 @@ def demo_prompt_codes(dev):
     codes, _, _ = tokenize_audio(tok, DEMO_PROMPT)
     y = codes.transpose(2, 1).cpu().contiguous()
     assert tuple(y.shape) == (1, 160, 4), y.shape
-    del tok
-    torch.cuda.empty_cache()
+    del tok            # (no empty_cache here: unmapping memory under `rocprofv3 --pmc` crashed the profiler's collector thread, round 6)
     return y
 
 

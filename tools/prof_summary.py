@@ -60,8 +60,16 @@ def main(path, out=None, gemm_log=None):
     # sampler launch 100 steps later, picked where the gaps are smallest (the eager / per-slot timing passes have large gaps)
     samp = [i for i, r in enumerate(dec) if "sample_kernel" in r["Kernel_Name"]]
     best = None
+    # only windows of WHOLE steps: the per-category timing passes of bench.py replay graphs that hold one kernel category (e.g. 50 sampler
+    # launches back to back) — such a window has far fewer launches than 100 steps; the whole-step windows share the most common count
+    counts = {}
+    for j in range(0, max(len(samp) - 100, 0), 10):
+        counts[samp[j + 100] - samp[j]] = counts.get(samp[j + 100] - samp[j], 0) + 1
+    full = max(counts, key=lambda k: (counts[k], k)) if counts else 0
     for j in range(0, max(len(samp) - 100, 0), 10):
         i0, i1 = samp[j], samp[j + 100]
+        if i1 - i0 != full:
+            continue
         span = int(dec[i1]["End_Timestamp"]) - int(dec[i0]["End_Timestamp"])
         if best is None or span < best[0]:
             best = (span, i0, i1)
