@@ -242,7 +242,7 @@ def test_cli_mask_spans_two_and_three_edits_equal_a_direct_call_with_those_inter
     must hand `inference_one_sample` the merged, frame-rounded intervals and write them to `<savename>_mask.pt`; the wav it writes must
     equal a direct call with the same `mask_interval` under the same seed. Two far-apart edits, then three of which two merge."""
     from ssr_speech_amd import inference_v2 as CLI
-    from ssr_speech_amd.data.tokenizer import TextTokenizer, read_wav
+    from ssr_speech_amd.data.tokenizer import read_wav
     ccfg = W.CodecConfig(dimension=64, n_filters=8, ratios=(8, 5, 4, 2), bins=64)
     csd = W.codec_state_dict(ccfg, seed=7)
     args = W.lm_args_tiny(d_model=128, nhead=2, layers=2, vocab=64)
