@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 #             + 34.09 (head-MLP2) = 3,330.0 MB read + 4.6 MB written per step; algorithmic 3,290.2 MB: ratio 1.0135
 #   16 rows: (59.30 x33 + 71.66 x16 + 18.17 x16 + 36.04) = 3,432 MB read + 20 MB written (x re-read through L2 by the streamed-x kernel; round 2)
 TRAFFIC_BYTES_PER_STEP_GEMVS = {2: 3334.6e6, 16: 66 * 52.3e6}
-TRAFFIC_SOURCE = {2: "profiles/r05_pmc_fetch_size.md + profiles/r05_pmc_write_size.md (3,330.0 MB read + 4.6 MB written by the 34 GEMV launches of a step)",
+TRAFFIC_SOURCE = {2: "profiles/r06_pmc_fetch_size.md + profiles/r06_pmc_write_size.md (3,330.0 MB read + 4.6 MB written by the 34 GEMV launches of a step; the same as round 5's passes)",
                   16: "profiles/r02_pmc_fetch_size_16rows.md + profiles/r02_pmc_write_size_16rows.md"}
 
 
@@ -493,6 +493,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--utts", type=int, default=1, help="utterances decoded in lock-step per GPU (default 1 = the headline configuration)")
     ap.add_argument("--no-extras", action="store_true", help="skip the rtf_10s_tts / dp64 / dp64_ragged / codec256 / wmencodec legs")
+    ap.add_argument("--no-ctx700", action="store_true", help="skip the second timed region around context 700 (counter-collection runs: rocprofv3 --pmc "
+                    "crashed with ~400 graph replays in flight behind one synchronisation, round 6)")
     ap.add_argument("--legs", type=str, default="", help="comma separated subset of the extra legs to run (default: all)")
     a = ap.parse_args()
 
@@ -608,7 +610,7 @@ def main():
         # had reached when it was timed) / the region's ms per step — an upper bound for the headline region (its average context is lower)
         attn_share = {f"headline_region(attention timed at context {L + T0 + total + 8})": round(n_attn * attn_us / (1000.0 * ms_per_step), 4)}
         pre, n_t = 700 - (L + T0) - 10, 20
-        if dist is None and pre > 0 and pre + n_t + 8 <= eng.max_steps and T0 + 1 + pre + n_t <= 10 * L:
+        if dist is None and not a.no_ctx700 and pre > 0 and pre + n_t + 8 <= eng.max_steps and T0 + 1 + pre + n_t <= 10 * L:
             for seed_try2 in range(4):
                 kns2 = [dataclasses.replace(kn, seed=777 + u + 1000 * seed_try2) for u in range(U)]
                 eng.start(text_rows, [cated] * U, kns2, noise=None)
@@ -675,7 +677,7 @@ def main():
             "decode_rtf_10s": round((500 * ms_per_step / 1000) / 10.0, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r05_pmc_*.md), gfx950 x2 correction
+                         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r06_pmc_*.md; `--no-ctx700`), gfx950 x2 correction
                          # for wide reads applied: per step 3,330.0 MB read + 4.6 MB written vs 3,290.2 MB algorithmic (divided by the step's GEMV launch count)
                          "traffic": (round(TRAFFIC_BYTES_PER_STEP_GEMVS[2 * U] / n_gemv) if (2 * U in TRAFFIC_BYTES_PER_STEP_GEMVS and arena.D == 2048 and arena.L == 16) else None),
                          "traffic_source": TRAFFIC_SOURCE.get(2 * U, "not measured for this row count") + " (rocprofv3 --pmc passes of this command, gfx950 x2 FETCH_SIZE correction)",

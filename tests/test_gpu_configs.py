@@ -1,6 +1,7 @@
 """GPU: BASELINE.json's configurations at their STATED shapes, each against the oracle on this box's CPU
 plus size-independent properties:
 
+  config 1   the same prompt and text, greedy: the first 12 steps against the oracle (token ids identical).
   config 2   830M, L=130 phonemes, the 160-frame prompt cut from demo/5895_34622_000026_000002.wav (tests/golden/), cfg_stride=5, top_k=40 / top_p=0.8 sampling — tokens identical to the
              oracle's under the same seed (the sampler consumes torch's CPU stream), 20 steps.
   config 3   830M speech editing on the reference's demo prompt demo/84_121550_000074_000000.wav (tests/golden/, 126,880 samples =
@@ -34,14 +35,10 @@ def _model_830m():
     return args, m.to("cuda").eval(), sd_gpu, sd_cpu
 
 
-def test_config2_830m_sampled_top_k40_top_p08_matches_oracle():
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
-    args, m, _, sd_cpu = _model_830m()
-    gen = torch.Generator().manual_seed(2024)
-    L, N, steps = 130, 160, 20
-    x = torch.randint(0, 100, (1, L), generator=gen)
-    # the prompt BASELINE configs 1-2 name: demo/5895_34622_000026_000002.wav, first 160 frames (tests/golden/, oracle/make_golden_demo.py),
-    # tokenised by wmencodec (synthetic weights: there are no pretrained ones) — the LM and the oracle are fed the SAME codes
+def _demo_prompt_codes(N=160):
+    """The prompt BASELINE configs 1-2 name: demo/5895_34622_000026_000002.wav, first 160 frames (tests/golden/, oracle/make_golden_demo.py),
+    tokenised by wmencodec (synthetic weights: there are no pretrained ones) -> int64 [1, N, 4] on the CPU. The LM and the oracle are fed
+    the SAME codes."""
     import json
     from ssr_speech_amd.data.tokenizer import AudioTokenizer, tokenize_audio
     gold = os.path.join(os.path.dirname(__file__), "golden")
@@ -52,7 +49,41 @@ def test_config2_830m_sampled_top_k40_top_p08_matches_oracle():
     assert tuple(codes.shape) == (1, 4, facts["frames_320"]) == (1, 4, N)
     y = codes.transpose(2, 1).cpu().contiguous()
     assert len(np.unique(y.numpy())) > 20                               # real audio through a (random-weight) RVQ: not a constant
-    del tok
+    return y
+
+
+def test_config1_830m_greedy_on_the_demo_prompt_matches_oracle():
+    """BASELINE config 1 as SURVEY 8(d) spells it out: the 160-frame cut of demo/5895_34622_000026_000002.wav, L = 130 phoneme ids, empty
+    span at the prompt's end, greedy (top_k = 1), cfg_stride 5, aug_text — the first 12 steps on the GPU against the oracle on this
+    box's CPU: identical token ids."""
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    args, m, _, sd_cpu = _model_830m()
+    gen = torch.Generator().manual_seed(2024)
+    L, N, steps = 130, 160, 12
+    x = torch.randint(0, 100, (1, L), generator=gen)
+    y = _demo_prompt_codes(N)
+    unc = torch.randint(0, 101, (1, L), generator=gen)
+    mi = torch.LongTensor([[[N, N]]])
+    kw = dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=5, aug_text=True)
+    trace = {}
+    O.inference(sd_cpu, args, x, y, mi, uncond_x=unc, max_steps=steps, trace=trace, **kw)
+    ref_tok = torch.stack(trace["samples"]).numpy()
+    out = m.inference(x.cuda(), torch.LongTensor([L]), x.cuda(), torch.LongTensor([L]), y.cuda(), y.cuda(), mi.cuda(), uncond_x=unc, max_new_steps=steps, **kw)
+    assert out is None and m.last_run["steps"] == steps
+    eng = next(iter(m._engines.values()))
+    assert np.array_equal(eng.tokens(0, steps), ref_tok)
+    eng.close()                                                          # (hands the device's pairing slot on)
+
+
+def test_config2_830m_sampled_top_k40_top_p08_matches_oracle():
+    import gc
+    gc.collect()                                                         # engines of earlier tests give the pairing slot back when collected
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    args, m, _, sd_cpu = _model_830m()
+    gen = torch.Generator().manual_seed(2024)
+    L, N, steps = 130, 160, 20
+    x = torch.randint(0, 100, (1, L), generator=gen)
+    y = _demo_prompt_codes(N)
     unc = torch.randint(0, 101, (1, L), generator=gen)
     mi = torch.LongTensor([[[N, N]]])
     kw = dict(top_k=40, top_p=0.8, temperature=1.0, stop_repetition=2, kvcache=1, cfg_coef=1.5, cfg_stride=5, aug_text=True)

@@ -10,7 +10,7 @@ cd /tmp; export TMPDIR=/tmp
 if [ "$part" = all ] || [ "$part" = prof1 ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python $R/bench.py --steps 200 --warmup 20 --no-extras --no-cpu-baseline > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc1_$c -- python $R/bench.py --steps 40 --warmup 5 --no-extras --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc1_$c -- python $R/bench.py --steps 40 --warmup 5 --no-extras --no-cpu-baseline --no-ctx700 > /dev/null 2>&1
 done
 cd $R
 python tools/prof_summary.py $(ls $O/kt1/*/*kernel_trace.csv | head -1) $O/r06_decode_kernel_trace_summary.md > /dev/null
