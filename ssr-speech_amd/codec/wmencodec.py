@@ -337,8 +337,8 @@ class WMEncodecModel:
 
         Why (round 6, DESIGN.md "the multi-stream failure"): on this platform a kernel that runs while ANOTHER hardware queue of the
         process is busy and the host maps fresh device memory can come back with wrong values — one register of one quarter-wave, in
-        the codec's plainest kernel; 6 of 25 fresh processes against 0 of 25 with a warm allocator or a single hardware queue
-        (tools/race_trials.py, profiles/r06_microbench/). A codec pass IS several queues — the two LSTM layers run on two streams —
+        the codec's plainest kernel; 36 of 206 fresh processes on round 5's code path against 0 of 260 with these sizing passes
+        (and 0 of 147 with a warm allocator or a single hardware queue; tools/race_trials.py, profiles/r06_microbench/). A codec pass IS several queues — the two LSTM layers run on two streams —
         and a cold process maps memory for every layer, so the first call of every process was exposed, single-stream callers
         included. What the pass will allocate is a deterministic function of (entry point, items, length): the first time a shape is
         not covered by one already seen on this stream, the pass runs once DRY — the device idle (synchronised), every library launch
