@@ -307,7 +307,9 @@ __device__ __forceinline__ const float* tile_wptr(const float* wbase, int row_lo
 // c >= 8 load the NEXT k-step's block of the same 8 rows (adjacent in memory: one contiguous KiB per load, half as many loads), the
 // k-steps are consumed in pairs — MFMAs against x[2i] are right in tile rows 0..7, MFMAs against x[2i+1] in rows 8..15 — and the
 // two half-results are added across lanes l <-> l+32 at the end. Same matrix-core work, half the load instructions.
-template <int PRO, int SPWX, int DEP = 16, bool PAIR = false>
+// WFIRST (round 6 experiment, SSRHIP_GEMVM_WFIRST=1, LayerNorm launches): the first DEP weight requests in FRONT of the x requests — the HBM
+// stream starts ~1 us earlier; x (L2 hits) then returns behind the first 16 KiB of weights, which the LayerNorm waited for anyway.
+template <int PRO, int SPWX, int DEP = 16, bool PAIR = false, bool WFIRST = false>
 __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
   static_assert(SPWX >= DEP && SPWX % DEP == 0, "SPWX must be a multiple of the pipeline depth");
   __shared__ float red[2][8][16];
@@ -335,15 +337,20 @@ __global__ __launch_bounds__(512) void gemv_rows_xreg_kernel(const GemvR p) {
   float4 xr[SPWX];
   const int kvpos = tile_kvpos(a, lane);                                // the wave's oldest load (QKV launch only)
   __builtin_amdgcn_sched_barrier(0);
+  const float* wp = tile_wptr(wbase, row_lo, nun, 0, c, ks, N, K, a.w_tiled) + (PAIR ? (c >> 3) * 128 : 0);
+  if (WFIRST && !PAIR) {
+#pragma unroll
+    for (int i = 0; i < DEP; ++i) w[i] = ld_nt(wp + min(tbase + i, last) * wstep);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int t = 0; t < SPWX; ++t) xr[t] = ld4(xbase + min(tbase + t, last) * xstep + xvoff);
   __builtin_amdgcn_sched_barrier(0);
   MSTAMP(6);
-  const float* wp = tile_wptr(wbase, row_lo, nun, 0, c, ks, N, K, a.w_tiled) + (PAIR ? (c >> 3) * 128 : 0);
   if (PAIR) {
 #pragma unroll
     for (int i = 0; i < SPWX / 2; ++i) w[i] = ld_nt(wp + min(tbase + 2 * i, last - 1) * wstep);   // host: steps even, SPWX / 2 <= DEP
-  } else {
+  } else if (!WFIRST) {
 #pragma unroll
     for (int i = 0; i < DEP; ++i) w[i] = ld_nt(wp + min(tbase + i, last) * wstep);
   }
@@ -840,6 +847,8 @@ int ssrhip_gemv_mfma_launch(const ssrhip_gemv_args* a, hipStream_t s) {
     else if (!xreg) hipLaunchKernelGGL(gemv_rows_stream_kernel<false>, grid, block, 0, s, r);
     else if (pair && a->pro == SSRHIP_PRO_NONE && spwx == 16) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_NONE, 16, 16, true>), grid, block, 0, s, r);
     else if (g_dep8 && a->pro == SSRHIP_PRO_LAYERNORM && spwx == 16) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_LAYERNORM, 16, 8>), grid, block, 0, s, r);
+    else if (a->pro == SSRHIP_PRO_LAYERNORM && spwx == 16 && getenv("SSRHIP_GEMVM_WFIRST") && getenv("SSRHIP_GEMVM_WFIRST")[0] == '1')
+      hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_LAYERNORM, 16, 16, false, true>), grid, block, 0, s, r);
     else if (a->pro == SSRHIP_PRO_LAYERNORM && spwx == 16) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_LAYERNORM, 16>), grid, block, 0, s, r);
     else if (a->pro == SSRHIP_PRO_LAYERNORM) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_LAYERNORM, 32>), grid, block, 0, s, r);
     else if (spwx == 16) hipLaunchKernelGGL((gemv_rows_xreg_kernel<SSRHIP_PRO_NONE, 16>), grid, block, 0, s, r);

@@ -208,6 +208,11 @@ def test_gemv_rows_edge_kernel_is_bit_identical_to_the_eight_wave_kernel(L, monk
     monkeypatch.delenv("SSRHIP_GEMVM_EDGE")
     y_old, pool_old = run()
     assert torch.equal(y_edge, y_old) and torch.equal(pool_edge, pool_old)
+    # the other request-order experiment of the round (first weight requests in front of the x requests): same arithmetic, same bits
+    monkeypatch.setenv("SSRHIP_GEMVM_WFIRST", "1")
+    y_wf, pool_wf = run()
+    monkeypatch.delenv("SSRHIP_GEMVM_WFIRST")
+    assert torch.equal(y_wf, y_old) and torch.equal(pool_wf, pool_old)
     if epi == 2:
         torch.testing.assert_close(y_edge, ref[:, :K], rtol=3e-5, atol=3e-5)
         for b in range(B):
