@@ -442,8 +442,10 @@ int ssrhip_lm_embed_pending(ssrhip_lm* lm, ssrhip_stream_t stream);
 int ssrhip_lm_pair_status(ssrhip_lm* lm, ssrhip_stream_t stream);
 
 /* Test hook (tests/test_gpu_lm.py: the pair launches' give-up path): `n_wg` workgroups that each hold `lds_bytes` of LDS (<= 160 KB) and
- * spin for `ms` milliseconds of the constant 100 MHz clock — a foreign kernel that keeps CUs away from everybody else. */
-int ssrhip_debug_occupy(int32_t n_wg, int32_t lds_bytes, float ms, ssrhip_stream_t stream);
+ * spin for `ms` milliseconds of the constant 100 MHz clock — a foreign kernel that keeps CUs away from everybody else. `started` (may be
+ * NULL): an int32 the device can reach (pinned host memory), incremented once by every workgroup when it has become resident, so that the
+ * caller can wait for all of them before it starts what the squatters are meant to starve. */
+int ssrhip_debug_occupy(int32_t n_wg, int32_t lds_bytes, float ms, int32_t* started, ssrhip_stream_t stream);
 
 /* run `n_steps` eager decode steps with a hipEvent pair around EVERY kernel launch (bench.py roofline).
  * out_us[i] = average microseconds of launch slot i of a step, out_kind[i] = 0 gemv | 1 attention | 2 sampler;

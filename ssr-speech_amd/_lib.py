@@ -187,7 +187,7 @@ SYMBOLS = [
     ("ssrhip_lm_embed_pending", C.c_int, [C.c_void_p, C.c_void_p]),
     ("ssrhip_lm_pairing", C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     ("ssrhip_lm_pair_status", C.c_int, [C.c_void_p, C.c_void_p]),
-    ("ssrhip_debug_occupy", C.c_int, [C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    ("ssrhip_debug_occupy", C.c_int, [C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     ("ssrhip_lm_time_steps", C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, c_f32p, c_i32p, C.c_int32]),
     ("ssrhip_lm_time_category", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, c_f32p, c_i32p]),
 ]

@@ -117,10 +117,11 @@ void pair_slot_release(int dev) {
   if (sl.fd >= 0) { flock(sl.fd, LOCK_UN); close(sl.fd); sl.fd = -1; }
 }
 
-__global__ void occupy_kernel(long long ticks, int lds_floats) {
+__global__ void occupy_kernel(long long ticks, int lds_floats, int* started) {
   extern __shared__ float occ[];
   for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) occ[i] = (float)i;
   __syncthreads();
+  if (started && threadIdx.x == 0) __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // "this workgroup is resident"
   const long long t0 = wall_clock64();
   float acc = 0.f;
   while (wall_clock64() - t0 < ticks) { acc += occ[(threadIdx.x * 7) % (lds_floats > 0 ? lds_floats : 1)]; __builtin_amdgcn_s_sleep(32); }
@@ -468,11 +469,11 @@ extern "C" int ssrhip_lm_pair_status(ssrhip_lm* lm, ssrhip_stream_t stream) {
   return ssrhip_gemv_pair_status(lm->pair_ws, stream);
 }
 
-extern "C" int ssrhip_debug_occupy(int32_t n_wg, int32_t lds_bytes, float ms, ssrhip_stream_t stream) {
+extern "C" int ssrhip_debug_occupy(int32_t n_wg, int32_t lds_bytes, float ms, int32_t* started, ssrhip_stream_t stream) {
   SSR_REQUIRE(n_wg > 0 && n_wg <= 65535 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && ms >= 0.f && ms <= 20000.f, "ssrhip_debug_occupy: bad argument");
   if (lds_bytes > 64 * 1024)
     SSR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-  hipLaunchKernelGGL(occupy_kernel, dim3(n_wg), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, (long long)(ms * 100000.0f), lds_bytes / 4);
+  hipLaunchKernelGGL(occupy_kernel, dim3(n_wg), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, (long long)(ms * 100000.0f), lds_bytes / 4, started);
   SSR_LAUNCH_CHECK();
   return 0;
 }

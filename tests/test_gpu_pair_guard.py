@@ -159,9 +159,13 @@ def test_a_kernel_squatting_on_most_cus_delays_or_raises_but_never_corrupts(aren
     rows, cated, kn = inp
     eng.start(rows, [cated], [kn])
     torch.cuda.synchronize()
+    started = torch.zeros(1, dtype=torch.int32).pin_memory()                # every squatter workgroup counts itself in when it is resident
+    _lib.check(L.ssrhip_debug_occupy(200, 158 * 1024, squat_ms, started.data_ptr(), side.cuda_stream), "ssrhip_debug_occupy")
+    t_wait = time.time()
+    while int(started[0]) < 200:                                            # (a fresh stream's first launch can take tens of ms: two of five runs of the
+        assert time.time() - t_wait < 5.0, f"only {int(started[0])} of 200 squatters became resident"      # round started the chain too early and starved nobody)
+        time.sleep(0.001)
     t0 = time.time()
-    _lib.check(L.ssrhip_debug_occupy(200, 158 * 1024, squat_ms, side.cuda_stream), "ssrhip_debug_occupy")
-    time.sleep(0.02)                                                        # the squatters are resident before the chain starts
     eng.decode(STEPS)
     raised = False
     try:
