@@ -923,10 +923,13 @@ __device__ __forceinline__ void pair_sweep8(const unsigned long long* p, pair_v4
 }
 
 // ---- the streaming role from barrier (1) on: B = LayerNorm + Linear on x' (gemv_segu_kernel<2, PRO_LAYERNORM, NUWB, 4>, operation for operation)
-template <int NUWB>
+// EARLY (round 6, the merge form only): B's units 0 .. EARLY - 1 were requested at kernel ENTRY into the ring slots A does not use
+// (unit j lives in w[(j + EARLY) % DEPTH]); what is requested here starts behind them. Same arithmetic, same order of operations.
+template <int NUWB, int EARLY = 0>
 __device__ __forceinline__ void pair_stream_b(const PairK& p, int t, int lane, int wave, float4 (&xr)[2][4], float4 (&w)[PAIR_DEPTH][4],
                                               const RowEpi& efinB, float* partB, float* aux, const float* xs, const size_t* kvoff) {
   constexpr int B = 2, DEPTH = PAIR_DEPTH, PF = PAIR_PF, SB = 2, SHB = 1, RB = NUWB * SEG_NW / SB;
+  static_assert(EARLY == 0 || EARLY == 2, "ring slots 2 and 3 are the ones the merge form's A phase leaves free");
   const ssrhip_gemv_args& bb = p.b.a;
   const int rB0 = (int)blockIdx.x * RB, segB = wave & (SB - 1);
   const int bfin = t % B, rfinB = min(t / B, RB - 1), nfinB = rB0 + rfinB;
@@ -934,9 +937,9 @@ __device__ __forceinline__ void pair_stream_b(const PairK& p, int t, int lane, i
   __syncthreads();                                                  // (1b) wave 8 has issued the publish
   // B's first units: PF of them now, the rest behind the gather
 #pragma unroll
-  for (int j = 0; j < PF; ++j)
+  for (int j = EARLY; j < PF; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(WgB + (size_t)((wave + SEG_NW * j) >> SHB) * bb.K + i * 256);
+    for (int i = 0; i < 4; ++i) w[(j + EARLY) % DEPTH][i] = ld_nt(WgB + (size_t)((wave + SEG_NW * j) >> SHB) * bb.K + i * 256);
   __syncthreads();                                                  // (2) x' is in LDS
 #pragma unroll
   for (int b = 0; b < B; ++b)
@@ -945,7 +948,7 @@ __device__ __forceinline__ void pair_stream_b(const PairK& p, int t, int lane, i
 #pragma unroll
   for (int j = PF; j < DEPTH; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(WgB + (size_t)((wave + SEG_NW * j) >> SHB) * bb.K + i * 256);
+    for (int i = 0; i < 4; ++i) w[(j + EARLY) % DEPTH][i] = ld_nt(WgB + (size_t)((wave + SEG_NW * j) >> SHB) * bb.K + i * 256);
   // LayerNorm
   {
     float m[B], q[B];
@@ -981,7 +984,7 @@ __device__ __forceinline__ void pair_stream_b(const PairK& p, int t, int lane, i
   // units
 #pragma unroll
   for (int j = 0; j < NUWB; ++j) {
-    float4 (&wj)[4] = w[j % DEPTH];
+    float4 (&wj)[4] = w[(j + EARLY) % DEPTH];
     float acc[B][2];
 #pragma unroll
     for (int b = 0; b < B; ++b) acc[b][0] = acc[b][1] = 0.f;
@@ -1152,7 +1155,10 @@ __global__ __launch_bounds__(PAIR_TH, 2) void gemv_pair_kernel(const PairK p) {
 // A = split-KV merge + out-projection + residual (K = 2048): gemv_seg_kernel<2, PRO_ATTN_COMBINE, TWO = true> at one workgroup per CU,
 // operation for operation — thread t owns float4 column t * 4 of both rows in the merge, wave w the units w and w + 8 (both requested at
 // entry). The merged rows pass through the LDS buffer that later receives x' (its A-phase use ends before barrier (1)).
-template <int NUWB>
+// EARLY = 2 (round 6, SSRHIP_GEMV_PAIR_EARLY, default on): A streams only 64 KB per CU and the edge follows — for ~4 us of this launch HBM
+// has next to nothing to do while B's 67 MB wait for barrier (1b). B's weights depend on nothing: its first two units are requested at
+// kernel entry, right behind A's two, into the ring slots A leaves free (no extra registers), and stream while the merge, A and the edge run.
+template <int NUWB, int EARLY = 0>
 __global__ __launch_bounds__(PAIR_TH, 2) void gemv_pair_merge_kernel(const PairK p) {
   constexpr int B = 2, DEPTH = PAIR_DEPTH, SEG_CS = SegCS<B>::v;
   constexpr int RA = 8, SA = 2, SHA = 1;                           // A: 8 rows per workgroup, K = 2048 = 2 segments, 16 units = 2 per wave
@@ -1199,6 +1205,14 @@ __global__ __launch_bounds__(PAIR_TH, 2) void gemv_pair_merge_kernel(const PairK
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) w[j][i] = ld_nt(WgA + (size_t)((wave + SEG_NW * j) >> SHA) * K + i * 256);
+    if constexpr (EARLY == 2) {
+      // B's units 0 and 1 (pair_stream_b's addresses: SB = 2 segments per row, unit u = row (wave + 8 u) / 2 of this workgroup's RB rows)
+      const float* WgB = bb.W + (size_t)((int)blockIdx.x * RB) * bb.K + (wave & 1) * SEG + lane * 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[2 + j][i] = ld_nt(WgB + (size_t)((wave + SEG_NW * j) >> 1) * bb.K + i * 256);
+    }
     // ---- 3. merge, under the latency of the units. EVERY thread computes the softmax-merge weights of (row, head) = t % (B * H), threads
     // 0 .. B * H - 1 store them: inside an `if (t < B * H)` hipcc sinks the (m, l) loads into the branch, behind the weight requests, and
     // their first use drains the whole queue (read off the ISA; in gemv_seg_kernel the same source keeps them in front)
@@ -1276,7 +1290,7 @@ __global__ __launch_bounds__(PAIR_TH, 2) void gemv_pair_merge_kernel(const PairK
       if (lane < B) partA[(wave + SEG_NW * j) * B + lane] = mine;
     }
     __syncthreads();                                                // (1) A's partial sums are parked
-    pair_stream_b<NUWB>(p, t, lane, wave, xr, w, efinB, partB, aux, xs, kvoff);
+    pair_stream_b<NUWB, EARLY>(p, t, lane, wave, xr, w, efinB, partB, aux, xs, kvoff);
   }
 }
 
@@ -1406,7 +1420,7 @@ static const char* pair_device_refusal(int num_cu) {
   hipError_t e0 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[0], gemv_pair_kernel<4>, PAIR_TH, 0);
   hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[1], gemv_pair_kernel<6>, PAIR_TH, 0);
   hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[2], gemv_pair_kernel<8>, PAIR_TH, 0);
-  hipError_t e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[3], gemv_pair_merge_kernel<8>, PAIR_TH, 16 * 1024);
+  hipError_t e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb[3], gemv_pair_merge_kernel<8, 2>, PAIR_TH, 16 * 1024);
   if (e0 != hipSuccess || e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || nb[0] < 1 || nb[1] < 1 || nb[2] < 1 || nb[3] < 1) {
     snprintf(buf, sizeof(buf), "the occupancy calculator places %d / %d / %d / %d workgroups of the pair kernels on a CU (need >= 1 each)", nb[0], nb[1], nb[2], nb[3]);
     return verdict = buf;
@@ -1491,7 +1505,9 @@ extern "C" int ssrhip_gemv_pair(const ssrhip_gemv_args* a, const ssrhip_gemv_arg
   hipStream_t s = (hipStream_t)stream;
   if (merge) {
     const size_t sm = ((size_t)2 * (a->K / a->kv.head_dim) * a->max_splits * sizeof(float) + 15) / 16 * 16;
-    hipLaunchKernelGGL((gemv_pair_merge_kernel<8>), dim3(256), dim3(PAIR_TH), sm, s, p);
+    const char* ee = getenv("SSRHIP_GEMV_PAIR_EARLY");             // read at every call (graph capture): A/B inside one process
+    if (ee && ee[0] == '0') hipLaunchKernelGGL((gemv_pair_merge_kernel<8, 0>), dim3(256), dim3(PAIR_TH), sm, s, p);
+    else hipLaunchKernelGGL((gemv_pair_merge_kernel<8, 2>), dim3(256), dim3(PAIR_TH), sm, s, p);
   } else if (nuwb == 4) hipLaunchKernelGGL((gemv_pair_kernel<4>), dim3(256), dim3(PAIR_TH), 0, s, p);
   else if (nuwb == 6) hipLaunchKernelGGL((gemv_pair_kernel<6>), dim3(256), dim3(PAIR_TH), 0, s, p);
   else hipLaunchKernelGGL((gemv_pair_kernel<8>), dim3(256), dim3(PAIR_TH), 0, s, p);

@@ -143,9 +143,9 @@ def test_two_engines_stepping_concurrently_on_two_streams_equal_their_runs_alone
 @pytest.mark.parametrize("squat_ms,must_raise", [(150.0, False), (2500.0, True)])
 def test_a_kernel_squatting_on_most_cus_delays_or_raises_but_never_corrupts(arena, squat_ms, must_raise):
     """200 workgroups that hold 158 of a CU's 160 KB of LDS each spin on a side stream while a paired chain steps: a pair workgroup needs
-    ~18 KB, so nothing of it fits on their CUs, and the 56 CUs left hold 112 pair workgroups (two fit a CU) — the launch cannot become
-    resident as a whole. (Round 6's first three runs squatted too politely: 128 workgroups left room for all 256, and 140 KB of LDS left
-    the 20 KB a pair workgroup needs — a 9 s squat only slowed the step.)
+    ~18 KB, so nothing of it fits on their CUs, and the 56 CUs left hold 56 pair workgroups — the launch cannot become resident as a
+    whole. (Round 6's first runs squatted too politely: with 140 KB of LDS per squatter a pair workgroup simply became resident BESIDE
+    it — a 9 s squat only slowed the step.)
     Leaves in time: the pair launch waits for its missing workgroups and the tokens are the usual ones. Stays longer than the spin
     bound (1 s of the constant 100 MHz clock since round 6; the sweep count of round 5 waited out a 9 s squatter): the launch gives up,
     `states()` raises within about a second, and the engine — now without pair launches — decodes correctly again."""
