@@ -925,10 +925,12 @@ __device__ __forceinline__ void pair_sweep8(const unsigned long long* p, pair_v4
 // ---- the streaming role from barrier (1) on: B = LayerNorm + Linear on x' (gemv_segu_kernel<2, PRO_LAYERNORM, NUWB, 4>, operation for operation)
 // EARLY (round 6, the merge form only): B's units 0 .. EARLY - 1 were requested at kernel ENTRY into the ring slots A does not use
 // (unit j lives in w[(j + EARLY) % DEPTH]); what is requested here starts behind them. Same arithmetic, same order of operations.
-template <int NUWB, int EARLY = 0>
+// PFX = units in flight behind barrier (1b), i.e. in front of the gather's loads (PAIR_PF = 3 for the forms without early units).
+template <int NUWB, int EARLY = 0, int PFX = PAIR_PF>
 __device__ __forceinline__ void pair_stream_b(const PairK& p, int t, int lane, int wave, float4 (&xr)[2][4], float4 (&w)[PAIR_DEPTH][4],
                                               const RowEpi& efinB, float* partB, float* aux, const float* xs, const size_t* kvoff) {
-  constexpr int B = 2, DEPTH = PAIR_DEPTH, PF = PAIR_PF, SB = 2, SHB = 1, RB = NUWB * SEG_NW / SB;
+  constexpr int B = 2, DEPTH = PAIR_DEPTH, PF = PFX, SB = 2, SHB = 1, RB = NUWB * SEG_NW / SB;
+  static_assert(PFX >= EARLY && PFX <= PAIR_DEPTH, "units requested at (1b) start behind the early ones and fit the ring");
   static_assert(EARLY == 0 || EARLY == 2, "ring slots 2 and 3 are the ones the merge form's A phase leaves free");
   const ssrhip_gemv_args& bb = p.b.a;
   const int rB0 = (int)blockIdx.x * RB, segB = wave & (SB - 1);
@@ -1158,7 +1160,7 @@ __global__ __launch_bounds__(PAIR_TH, 2) void gemv_pair_kernel(const PairK p) {
 // EARLY = 2 (round 6, SSRHIP_GEMV_PAIR_EARLY, default on): A streams only 64 KB per CU and the edge follows — for ~4 us of this launch HBM
 // has next to nothing to do while B's 67 MB wait for barrier (1b). B's weights depend on nothing: its first two units are requested at
 // kernel entry, right behind A's two, into the ring slots A leaves free (no extra registers), and stream while the merge, A and the edge run.
-template <int NUWB, int EARLY = 0>
+template <int NUWB, int EARLY = 0, int PFX = PAIR_PF>
 __global__ __launch_bounds__(PAIR_TH, 2) void gemv_pair_merge_kernel(const PairK p) {
   constexpr int B = 2, DEPTH = PAIR_DEPTH, SEG_CS = SegCS<B>::v;
   constexpr int RA = 8, SA = 2, SHA = 1;                           // A: 8 rows per workgroup, K = 2048 = 2 segments, 16 units = 2 per wave
@@ -1290,7 +1292,7 @@ __global__ __launch_bounds__(PAIR_TH, 2) void gemv_pair_merge_kernel(const PairK
       if (lane < B) partA[(wave + SEG_NW * j) * B + lane] = mine;
     }
     __syncthreads();                                                // (1) A's partial sums are parked
-    pair_stream_b<NUWB, EARLY>(p, t, lane, wave, xr, w, efinB, partB, aux, xs, kvoff);
+    pair_stream_b<NUWB, EARLY, PFX>(p, t, lane, wave, xr, w, efinB, partB, aux, xs, kvoff);
   }
 }
 
@@ -1506,7 +1508,10 @@ extern "C" int ssrhip_gemv_pair(const ssrhip_gemv_args* a, const ssrhip_gemv_arg
   if (merge) {
     const size_t sm = ((size_t)2 * (a->K / a->kv.head_dim) * a->max_splits * sizeof(float) + 15) / 16 * 16;
     const char* ee = getenv("SSRHIP_GEMV_PAIR_EARLY");             // read at every call (graph capture): A/B inside one process
+    // 0 = round 5's order; 1 = early units, three in flight behind (1b) as before; 2 = early units and BOTH free ring slots filled at (1b)
     if (ee && ee[0] == '0') hipLaunchKernelGGL((gemv_pair_merge_kernel<8, 0>), dim3(256), dim3(PAIR_TH), sm, s, p);
+    else if (ee && ee[0] == '2') hipLaunchKernelGGL((gemv_pair_merge_kernel<8, 2, 4>), dim3(256), dim3(PAIR_TH), sm, s, p);
+    else if (ee && ee[0] == '3') hipLaunchKernelGGL((gemv_pair_merge_kernel<8, 2, 2>), dim3(256), dim3(PAIR_TH), sm, s, p);   // nothing in front of the gather
     else hipLaunchKernelGGL((gemv_pair_merge_kernel<8, 2>), dim3(256), dim3(PAIR_TH), sm, s, p);
   } else if (nuwb == 4) hipLaunchKernelGGL((gemv_pair_kernel<4>), dim3(256), dim3(PAIR_TH), 0, s, p);
   else if (nuwb == 6) hipLaunchKernelGGL((gemv_pair_kernel<6>), dim3(256), dim3(PAIR_TH), 0, s, p);
