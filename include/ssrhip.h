@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SSRHIP_VERSION 106
+#define SSRHIP_VERSION 107
 #define SSRHIP_PAGE 128          /* KV-cache page = 128 positions */
 #define SSRHIP_MAX_CODEBOOKS 4
 #define SSRHIP_MAX_SILENCE 8
@@ -140,6 +140,10 @@ typedef struct ssrhip_attn_args {
   float scale;             /* 1/sqrt(head_dim) */
   float* part_o; float* part_ml;
   int32_t out_tiled;       /* ssrhip_attn_combine only: write `out` in the SSRHIP_TILED layout (R <= 16) */
+  /* ssrhip_attn_decode only, optional (NULL = off; an experiment that did not pay, DESIGN.md Part I.5): while this latency-bound launch runs, workgroup i (linear launch index, the first 256)
+   * touches floats [i * prefetch_floats, (i + 1) * prefetch_floats) of `prefetch` with plain loads whose results nobody reads — the weights
+   * the NEXT launch's workgroup i will stream (workgroup i of both launches runs on XCD i % 8, so they land in the right L2). */
+  const float* prefetch; int32_t prefetch_floats;
 } ssrhip_attn_args;
 
 int ssrhip_attn_decode(const ssrhip_attn_args* a, ssrhip_stream_t stream);

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libssrhip.so")
 
-ABI_VERSION = 106          # include/ssrhip.h SSRHIP_VERSION
+ABI_VERSION = 107          # include/ssrhip.h SSRHIP_VERSION
 PAGE = 128
 MAX_CODEBOOKS = 4
 MAX_SILENCE = 8
@@ -51,7 +51,8 @@ class GemvArgs(C.Structure):
 class AttnArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("q_stride", C.c_int32), ("kv", KV), ("layer", C.c_int32),
                 ("row_seq", C.c_void_p), ("row_len", C.c_void_p), ("R", C.c_int32), ("max_splits", C.c_int32),
-                ("scale", C.c_float), ("part_o", C.c_void_p), ("part_ml", C.c_void_p), ("out_tiled", C.c_int32)]
+                ("scale", C.c_float), ("part_o", C.c_void_p), ("part_ml", C.c_void_p), ("out_tiled", C.c_int32),
+                ("prefetch", C.c_void_p), ("prefetch_floats", C.c_int32)]
 
 
 class EmbedArgs(C.Structure):

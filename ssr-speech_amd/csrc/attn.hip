@@ -36,6 +36,20 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args
   // makes the head the fastest dimension: the live (page, head, row) items spread over all XCDs whatever the context.
   const int split = head_fastest ? blockIdx.y : blockIdx.x, h = head_fastest ? blockIdx.x : blockIdx.y, r = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (!SEQ && a.prefetch) {
+    // Round 6: this launch is latency-bound (a few dependent round trips for 10 MB of K / V) and most of its workgroups at short contexts
+    // have nothing to do at all, while the launch behind it starts by streaming 64 KB of W_o per CU from HBM. Workgroup i touches the
+    // slice workgroup i of that launch will read (same XCD: i % 8) — plain loads, the wave's OLDEST, results never used: whatever the
+    // compiler waits for later (`vmcnt(n)` = all but the n youngest) is unaffected, and the lines sit in this XCD's L2 when they are wanted.
+    const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (wg < 256u) {
+      const float* pf = a.prefetch + (size_t)wg * a.prefetch_floats + threadIdx.x * 4;
+      for (int i = 0; i < a.prefetch_floats; i += 1024) {
+        float4 junk;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(junk) : "v"(pf + i) : "memory");
+      }
+    }
+  }
   const int sub = lane / LPK;         // which key row inside one wave-instruction
   const int c4 = (lane % LPK) * 4;    // this lane's 4 columns
   const int H = a.kv.n_head;

@@ -288,6 +288,14 @@ int enqueue_step(ssrhip_lm* lm, hipStream_t s, Timer* tm) {
     at.q = b.q; at.kv = b.kv; at.layer = l; at.row_seq = nullptr; at.row_len = b.row_len;
     at.R = B; at.max_splits = b.max_splits; at.scale = 1.0f / sqrtf((float)(D / d.n_head));
     at.part_o = b.part_o; at.part_ml = b.part_ml;
+    // 2-row paired step, OPT-IN experiment (SSRHIP_ATTN_PREFETCH=1, read when the step is enqueued): the attention launch pre-touches the
+    // out-projection slice the merge pair launch behind it starts with (include/ssrhip.h ssrhip_attn_args.prefetch). Measured: the attention
+    // launch pays for the 16.8 MB (6.55 -> 8.80 us) and the pair launch gains nothing (18.33 vs 18.35 us): 0.7477 -> 0.7707 ms/step
+    // (profiles/r06_microbench/decode_ab_attn_prefetch.log). Like every cross-launch prefetch tried since round 1, it loses.
+    if (pair_ffn1 && D % 256 == 0 && getenv("SSRHIP_ATTN_PREFETCH") && getenv("SSRHIP_ATTN_PREFETCH")[0] == '1') {
+      at.prefetch = w.out_proj_w[l];
+      at.prefetch_floats = (D / 256) * D;                    // workgroup i of the pair launch owns rows [8 i, 8 i + 8) of W_o [D][D]
+    }
     // 5..16 rows with enough (row, head) pairs to give every CU one: the fused walk over the pages (no partials, no merge
     // launch); its output goes to b.h (free until FFN1 of this layer) because q is still being read by other workgroups
     const bool fused_attn = B > 4 && B * d.n_head >= 192 && b.kv.max_pages <= 256 && !getenv_flag("SSRHIP_ATTN_SPLIT");   // 256 pages: the kernel's page-id registers

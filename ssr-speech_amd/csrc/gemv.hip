@@ -1508,10 +1508,9 @@ extern "C" int ssrhip_gemv_pair(const ssrhip_gemv_args* a, const ssrhip_gemv_arg
   if (merge) {
     const size_t sm = ((size_t)2 * (a->K / a->kv.head_dim) * a->max_splits * sizeof(float) + 15) / 16 * 16;
     const char* ee = getenv("SSRHIP_GEMV_PAIR_EARLY");             // read at every call (graph capture): A/B inside one process
-    // 0 = round 5's order; 1 = early units, three in flight behind (1b) as before; 2 = early units and BOTH free ring slots filled at (1b)
+    // 0 = round 5's order. (With the early units in place, FOUR units in flight behind (1b) measured 0.759 ms/step and TWO — nothing between
+    // the publish and the gather — 0.767 against 0.745-0.748 for three: PFX stays PAIR_PF; profiles/r06_microbench/decode_ab_pair_early_pf*.log.)
     if (ee && ee[0] == '0') hipLaunchKernelGGL((gemv_pair_merge_kernel<8, 0>), dim3(256), dim3(PAIR_TH), sm, s, p);
-    else if (ee && ee[0] == '2') hipLaunchKernelGGL((gemv_pair_merge_kernel<8, 2, 4>), dim3(256), dim3(PAIR_TH), sm, s, p);
-    else if (ee && ee[0] == '3') hipLaunchKernelGGL((gemv_pair_merge_kernel<8, 2, 2>), dim3(256), dim3(PAIR_TH), sm, s, p);   // nothing in front of the gather
     else hipLaunchKernelGGL((gemv_pair_merge_kernel<8, 2>), dim3(256), dim3(PAIR_TH), sm, s, p);
   } else if (nuwb == 4) hipLaunchKernelGGL((gemv_pair_kernel<4>), dim3(256), dim3(PAIR_TH), 0, s, p);
   else if (nuwb == 6) hipLaunchKernelGGL((gemv_pair_kernel<6>), dim3(256), dim3(PAIR_TH), 0, s, p);

@@ -31,7 +31,7 @@ def test_header_symbols_are_exported(built):
 
 def test_version_and_error_string(built):
     L = _lib.lib()
-    assert L.ssrhip_version() == 106 == _lib.ABI_VERSION
+    assert L.ssrhip_version() == 107 == _lib.ABI_VERSION
     assert isinstance(L.ssrhip_last_error(), bytes)
 
 
