@@ -36,20 +36,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args
   // makes the head the fastest dimension: the live (page, head, row) items spread over all XCDs whatever the context.
   const int split = head_fastest ? blockIdx.y : blockIdx.x, h = head_fastest ? blockIdx.x : blockIdx.y, r = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (!SEQ && a.prefetch) {
-    // Round 6: this launch is latency-bound (a few dependent round trips for 10 MB of K / V) and most of its workgroups at short contexts
-    // have nothing to do at all, while the launch behind it starts by streaming 64 KB of W_o per CU from HBM. Workgroup i touches the
-    // slice workgroup i of that launch will read (same XCD: i % 8) — plain loads, the wave's OLDEST, results never used: whatever the
-    // compiler waits for later (`vmcnt(n)` = all but the n youngest) is unaffected, and the lines sit in this XCD's L2 when they are wanted.
-    const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (wg < 256u) {
-      const float* pf = a.prefetch + (size_t)wg * a.prefetch_floats + threadIdx.x * 4;
-      for (int i = 0; i < a.prefetch_floats; i += 1024) {
-        float4 junk;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(junk) : "v"(pf + i) : "memory");
-      }
-    }
-  }
   const int sub = lane / LPK;         // which key row inside one wave-instruction
   const int c4 = (lane % LPK) * 4;    // this lane's 4 columns
   const int H = a.kv.n_head;
@@ -64,11 +50,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const ssrhip_attn_args
   cint* c_tab = (cint*)(uintptr_t)a.kv.table;
   cint* c_seq = (cint*)(uintptr_t)a.row_seq;
   asm volatile("; kernel arguments in one batch" :: "s"(a.q), "s"(a.kv.pool), "s"(a.kv.max_pages), "s"(a.kv.n_layer), "s"(a.layer), "s"(a.scale),
-               "s"(a.part_o), "s"(a.part_ml), "s"(a.max_splits), "s"(a.q_stride), "s"(H), "s"(c_len), "s"(c_tab), "s"(c_seq));
+               "s"(a.part_o), "s"(a.part_ml), "s"(a.max_splits), "s"(a.q_stride), "s"(H), "s"(c_len), "s"(c_tab), "s"(c_seq), "s"(a.prefetch),
+               "s"(a.prefetch_floats));
   const int len = c_len[r];
   const int page = SEQ ? c_tab[(size_t)c_seq[r] * a.kv.max_pages + split]      // rows mapped to another sequence: one more round trip
                        : c_tab[(size_t)r * a.kv.max_pages + split];            // the row's own sequence (decode step): together with its length
   const float4 q = ld4(a.q + (size_t)r * (a.q_stride ? a.q_stride : H * HD) + h * HD + c4);
+  if (!SEQ && a.prefetch) {
+    // Round 6: this launch is latency-bound (a few dependent round trips for 10 MB of K / V) and most of its workgroups at short contexts
+    // have nothing to do at all, while the launch behind it starts by streaming 64 KB of W_o per CU from HBM. Workgroup i touches the
+    // slice workgroup i of that launch will read (same XCD: i % 8) — plain loads behind the scalar requests and q, results never used: extra
+    // loads the compiler does not know of only make its later waits (`vmcnt(n)` = all but the n youngest) stricter, never laxer, and the lines sit in this XCD's L2 when they are wanted.
+    const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (wg < 256u) {
+      const float* pf = a.prefetch + (size_t)wg * a.prefetch_floats + threadIdx.x * 4;
+      for (int i = 0; i < a.prefetch_floats; i += 1024) {
+        float4 junk;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(junk) : "v"(pf + i) : "memory");
+      }
+    }
+  }
   asm volatile("; row length and page id arrive together" :: "s"(len), "s"(page));
   const int base = split * SSRHIP_PAGE;
   if (base >= len) return;            // uniform per block
