@@ -397,7 +397,8 @@ def test_codec_calls_on_concurrent_streams_equal_the_single_stream_results():
                     bad = (a != b).nonzero()
                     raise AssertionError(f"round {rnd}, caller {i} (batch {Bs[i]}), output {k} of (codes, emb, dec, wm, mark), shape {tuple(a.shape)}: "
                                          f"{bad.shape[0]} elements differ, max |diff| {float((a.float() - b.float()).abs().max()):.3g}, "
-                                         f"first at {bad[0].tolist()}, last at {bad[-1].tolist()}")
+                                         f"first at {bad[0].tolist()}, last at {bad[-1].tolist()}; codec: {m.sizing_passes} sizing passes, "
+                                         f"{m.mallocs_in_flight} driver allocations in flight, {m.passes_repeated} passes repeated")
     # alone: 3 entry points on the default stream (batch 9 covers batch 7); concurrent: 3 entry points on each of 3 new streams
     assert m.mallocs_in_flight == 0, f"{m.mallocs_in_flight} driver allocations happened while sized codec passes were in flight"
     assert m.sizing_passes == 3 + 9, m.sizing_passes

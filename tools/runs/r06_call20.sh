@@ -23,4 +23,4 @@ for f in ("r06_bench_n1.json","r06_bench_n1_driver_cmd.json"):
         if k in d: print("  ", k, {kk: vv for kk, vv in d[k].items() if kk in ("rtf","wall_ms","time_to_first_16_frames_ms","encode_ms","decode_ms","wmdecode_ms","wmdecode_with_detector_ms")})
     if "dp64" in d: print("  dp64", d["dp64"]["codec_tokens_per_s_per_gpu"], d["dp64"]["wall_ms_with_codec"], "ragged", d["dp64_ragged"]["speedup"])
 PY
-timeout 2400 python -m pytest tests/ -q -m gpu -p no:cacheprovider --durations=15 -rs > $O/pytest_gpu_full.log 2>&1; echo "suite rc=$?"; grep -n "passed\|failed" $O/pytest_gpu_full.log | tail -2
+timeout 2400 python -m pytest tests/ -q -m gpu -p no:cacheprovider --durations=15 -rs > $O/pytest_gpu_full.log 2>&1; echo "suite rc=$?"; grep -n "passed\|failed" $O/pytest_gpu_full.log | tail -2; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep "smoke ok"
