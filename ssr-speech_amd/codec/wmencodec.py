@@ -267,6 +267,10 @@ class WMEncodecModel:
         self.lanes = int(os.environ.get("SSRHIP_CODEC_LANES", "1"))
         self.lane_min_items = int(os.environ.get("SSRHIP_CODEC_LANE_MIN", "8"))
         self._side_streams, self._keep = {}, {}
+        # the two-stream LSTM pipeline (`_lstm`) only where it pays: from this many items on (SSRHIP_LSTM_PIPE_MIN_B). Below it the two layers
+        # run one after the other on the calling stream — at batch 1 the pipeline saves ~3 ms of a 10 s utterance's codec time, and a second
+        # hardware queue in flight is one half of the trigger of DESIGN.md Part I.4: a single-utterance call keeps to ONE queue.
+        self.lstm_pipe_min_b = int(os.environ.get("SSRHIP_LSTM_PIPE_MIN_B", "8"))
         # Round 6 — NO DEVICE MEMORY IS MAPPED WHILE CODEC KERNELS ARE IN FLIGHT (`_sized`; DESIGN.md "the multi-stream failure"):
         # SSRHIP_CODEC_PRESIZE=0 switches the sizing passes off (the A/B arm of tools/race_trials.py).
         self.presize = os.environ.get("SSRHIP_CODEC_PRESIZE", "1") not in ("", "0")
@@ -589,7 +593,7 @@ class WMEncodecModel:
             a.out_act = _lib.ACT_ELU if (post_elu and l == nl - 1) else 0
             _lib.check(self.lib.ssrhip_lstm_layer(C.byref(a), self._s()), "ssrhip_lstm_layer")
 
-        if nl == 2 and T > self.LSTM_CHUNK:
+        if nl == 2 and T > self.LSTM_CHUNK and B >= self.lstm_pipe_min_b:
             main = torch.cuda.current_stream(dev)
             side = self._side_stream()
             # Every tensor the side stream touches was allocated on `main`, and `main` joins the side stream (`fin`) before this function

@@ -257,6 +257,7 @@ def test_lstm_two_stream_pipeline_equals_sequential_layers(B):
     cfg = W.codec_config_full()
     sd = W.codec_state_dict(cfg, seed=12)
     m = WMEncodecModel(cfg, sd, "cuda")
+    m.lstm_pipe_min_b = 1                        # (the product pipelines from 8 items on: SSRHIP_LSTM_PIPE_MIN_B)
     g = torch.Generator().manual_seed(4)
     wav = (torch.randn(B, 1, cfg.hop * 150, generator=g) * 0.2).cuda()
     c1, _, e1 = m.encode(wav)
@@ -366,6 +367,7 @@ def test_codec_calls_on_concurrent_streams_equal_the_single_stream_results():
     cfg = W.codec_config_full()
     sd = W.codec_state_dict(cfg, seed=21)
     m = WMEncodecModel(cfg, sd, "cuda")
+    m.lstm_pipe_min_b = 1                        # the two-stream LSTM pipeline for every caller (the product: from 8 items on)
     g = torch.Generator().manual_seed(19)
     n = cfg.hop * 70 + 11
     Bs = (9, 7, 9)

@@ -48,6 +48,7 @@ wavs = [(torch.randn(b, 1, n, generator=g) * 0.2).cuda() for b in Bs]
 labels = [torch.randint(0, 2, (b, 71), generator=g).cuda() for b in Bs]
 tracks = [torch.nn.functional.pad(w, (0, 71 * cfg.hop - n)) for w in wavs]
 names = ("codes", "emb", "dec", "wm", "mark")
+m.lstm_pipe_min_b = int(opts.get("pipe-min-b", "1"))       # the two-stream LSTM pipeline for every caller, as in all trials of round 6 (product: 8)
 if "nopipe" in opts:
     m.LSTM_CHUNK = 10 ** 9
 streams = [torch.cuda.Stream() for _ in range(3)]
